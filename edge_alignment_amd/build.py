@@ -1,0 +1,36 @@
+"""Compiles the HIP sources for gfx950 into lib/libea_hip.so with an explicit hipcc command
+(in-tree, so the built library travels with the repository snapshot)."""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["csrc/ea_kernels.hip", "csrc/ea_capi.hip"]
+HEADERS = ["csrc/ea_types.h", "csrc/ea_lm.h", "../include/ea_hip.h"]
+LIB = os.path.join(_HERE, "lib", "libea_hip.so")
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def build_library(force=False, verbose=False):
+    srcs = [os.path.join(_HERE, s) for s in SOURCES]
+    deps = srcs + [os.path.join(_HERE, h) for h in HEADERS]
+    if (not force and os.path.exists(LIB)
+            and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps)):
+        return LIB
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wall", "-Wno-unused-function", "-o", LIB] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=_HERE)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

@@ -1,0 +1,297 @@
+"""ctypes binding of libea_hip.so (include/ea_hip.h) — the Python stub a maintainer of a Python
+harness would write; the tests and bench.py drive the C-ABI through it.
+
+There is no CPU fallback: if the shared library is missing or no gfx950 device is present the
+calls raise `EAError` (never a silent numpy path).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libea_hip.so")
+
+EA_F64, EA_F32 = 0, 1
+LOSS_TRIVIAL, LOSS_CAUCHY, LOSS_HUBER = 0, 1, 2
+CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
+STRATEGY_LM, STRATEGY_DOGLEG = 0, 1
+WHY = ["none", "function_tolerance", "gradient_tolerance", "parameter_tolerance",
+       "max_iterations", "min_radius", "initial_eval_failed", "too_many_invalid_steps",
+       "eval_failed"]
+MAX_TRACE = 128
+
+EXPORTED = [
+    "ea_last_error", "ea_version", "ea_device_count", "ea_default_options",
+    "ea_problem_create", "ea_problem_destroy", "ea_problem_set_points",
+    "ea_problem_set_points_device", "ea_problem_set_dt", "ea_problem_set_dt_image_device",
+    "ea_problem_set_loss", "ea_problem_set_flavour", "ea_problem_num_points",
+    "ea_eval", "ea_eval_points", "ea_cost", "ea_solve",
+    "ea_batch_create", "ea_batch_destroy", "ea_batch_count", "ea_batch_eval", "ea_batch_solve",
+    "ea_batch_bench_eval", "ea_batch_set_tuning", "ea_batch_get_info",
+]
+
+
+class EAError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libea_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double)]
+
+
+class Options(C.Structure):
+    _fields_ = [("max_num_iterations", C.c_int),
+                ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+                ("parameter_tolerance", C.c_double),
+                ("initial_trust_region_radius", C.c_double),
+                ("max_trust_region_radius", C.c_double), ("min_trust_region_radius", C.c_double),
+                ("min_relative_decrease", C.c_double),
+                ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+                ("max_num_consecutive_invalid_steps", C.c_int),
+                ("jacobi_scaling", C.c_int), ("strategy", C.c_int),
+                ("minimizer_progress_to_stdout", C.c_int), ("iterations_per_sync", C.c_int)]
+
+
+class Summary(C.Structure):
+    _fields_ = [("termination", C.c_int), ("why", C.c_int), ("num_iterations", C.c_int),
+                ("num_successful_steps", C.c_int), ("num_unsuccessful_steps", C.c_int),
+                ("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("num_point_evals", C.c_int64), ("total_time_ms", C.c_double),
+                ("it_cost", C.c_double * MAX_TRACE), ("it_cost_change", C.c_double * MAX_TRACE),
+                ("it_gradient_max_norm", C.c_double * MAX_TRACE),
+                ("it_step_norm", C.c_double * MAX_TRACE),
+                ("it_relative_decrease", C.c_double * MAX_TRACE),
+                ("it_radius", C.c_double * MAX_TRACE), ("it_successful", C.c_int * MAX_TRACE)]
+
+
+_lib = None
+
+
+def load():
+    """dlopen libea_hip.so and declare every prototype of include/ea_hip.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EAError(-3, "%s not built — run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                          "there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    dp, vp = C.POINTER(C.c_double), C.c_void_p
+    i64p = C.POINTER(C.c_int64)
+    L.ea_last_error.restype = C.c_char_p
+    L.ea_version.restype = C.c_char_p
+    L.ea_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.ea_default_options.argtypes = [C.POINTER(Options)]
+    L.ea_default_options.restype = None
+    L.ea_problem_create.argtypes = [C.POINTER(vp), C.POINTER(Camera), C.c_int, C.c_int]
+    L.ea_problem_destroy.argtypes = [vp]
+    L.ea_problem_destroy.restype = None
+    L.ea_problem_set_points.argtypes = [vp, dp, C.c_int64, C.c_int64]
+    L.ea_problem_set_points_device.argtypes = [vp, vp, vp, vp, C.c_int64]
+    L.ea_problem_set_dt.argtypes = [vp, dp, C.c_int, C.c_int]
+    L.ea_problem_set_dt_image_device.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.ea_problem_set_loss.argtypes = [vp, C.c_int, C.c_double]
+    L.ea_problem_set_flavour.argtypes = [vp, C.c_double, C.c_double, C.c_int]
+    L.ea_problem_num_points.argtypes = [vp]
+    L.ea_problem_num_points.restype = C.c_int64
+    L.ea_eval.argtypes = [vp, dp, dp, dp, dp, dp, i64p]
+    L.ea_eval_points.argtypes = [vp, dp, dp, dp, dp, C.c_int]
+    L.ea_cost.argtypes = [vp, dp, dp, dp, i64p]
+    L.ea_solve.argtypes = [vp, C.POINTER(Options), dp, dp, C.POINTER(Summary)]
+    L.ea_batch_create.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_int]
+    L.ea_batch_destroy.argtypes = [vp]
+    L.ea_batch_destroy.restype = None
+    L.ea_batch_count.argtypes = [vp]
+    L.ea_batch_eval.argtypes = [vp, dp, dp, dp, dp, dp, i64p]
+    L.ea_batch_solve.argtypes = [vp, C.POINTER(Options), dp, dp, C.POINTER(Summary)]
+    L.ea_batch_bench_eval.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp, dp]
+    L.ea_batch_set_tuning.argtypes = [vp, C.c_char_p, C.c_int]
+    L.ea_batch_get_info.argtypes = [vp, C.c_char_p, i64p]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise EAError(rc, load().ea_last_error().decode())
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = load().ea_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def default_options(**kw):
+    o = Options()
+    load().ea_default_options(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise KeyError(k)
+        setattr(o, k, v)
+    return o
+
+
+def summary_to_dict(s):
+    ni = min(s.num_iterations + 1, MAX_TRACE)
+    return dict(termination=s.termination, why=WHY[s.why], num_iterations=s.num_iterations,
+                num_successful_steps=s.num_successful_steps,
+                num_unsuccessful_steps=s.num_unsuccessful_steps,
+                initial_cost=s.initial_cost, final_cost=s.final_cost,
+                num_point_evals=s.num_point_evals, total_time_ms=s.total_time_ms,
+                it_cost=np.array(s.it_cost[:ni]), it_cost_change=np.array(s.it_cost_change[:ni]),
+                it_gradient_max_norm=np.array(s.it_gradient_max_norm[:ni]),
+                it_step_norm=np.array(s.it_step_norm[:ni]),
+                it_relative_decrease=np.array(s.it_relative_decrease[:ni]),
+                it_radius=np.array(s.it_radius[:ni]),
+                it_successful=np.array(s.it_successful[:ni]))
+
+
+class Problem:
+    """One frame pair: the N residual blocks + interpolator + loss of the reference's set-up
+    block (standalone_edge_align.cpp:256-278), resident in HBM."""
+
+    def __init__(self, fx, fy, cx, cy, dtype=EA_F64, device=0):
+        self._h = C.c_void_p()
+        cam = Camera(fx, fy, cx, cy)
+        _check(load().ea_problem_create(C.byref(self._h), C.byref(cam), dtype, device))
+        self.dtype = dtype
+        self._keep = []
+
+    def close(self):
+        if self._h:
+            load().ea_problem_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_points(self, xyz):
+        xyz = _f64(xyz)
+        if xyz.ndim != 2 or xyz.shape[1] < 3:
+            raise ValueError("xyz must be (n, >=3)")
+        _check(load().ea_problem_set_points(self._h, _dp(xyz), xyz.shape[0], xyz.shape[1]))
+
+    def set_points_device(self, x_ptr, y_ptr, z_ptr, n):
+        _check(load().ea_problem_set_points_device(self._h, x_ptr, y_ptr, z_ptr, n))
+
+    def set_dt_grid(self, grid):
+        """grid: the Grid2D view (rows = u extent, cols = v extent), row-major float64."""
+        grid = _f64(grid)
+        _check(load().ea_problem_set_dt(self._h, _dp(grid), grid.shape[0], grid.shape[1]))
+
+    def set_dt_image_device(self, ptr, height, width):
+        _check(load().ea_problem_set_dt_image_device(self._h, ptr, height, width))
+
+    def set_loss(self, kind, a=1.0):
+        _check(load().ea_problem_set_loss(self._h, kind, a))
+
+    def set_flavour(self, z_guard=0.01, z_eps=0.0, rot_transposed=False):
+        _check(load().ea_problem_set_flavour(self._h, z_guard, z_eps, int(rot_transposed)))
+
+    @property
+    def num_points(self):
+        return load().ea_problem_num_points(self._h)
+
+    def eval(self, q, t):
+        q, t = _f64(q), _f64(t)
+        cost = C.c_double()
+        JtJ, Jtr = np.zeros((6, 6)), np.zeros(6)
+        bad = C.c_int64()
+        _check(load().ea_eval(self._h, _dp(q), _dp(t), C.byref(cost), _dp(JtJ), _dp(Jtr),
+                              C.byref(bad)))
+        return dict(cost=cost.value, JtJ=JtJ, Jtr=Jtr, n_invalid=bad.value)
+
+    def eval_points(self, q, t, corrected=True):
+        q, t = _f64(q), _f64(t)
+        n = self.num_points
+        r, J = np.zeros(n), np.zeros((n, 6))
+        _check(load().ea_eval_points(self._h, _dp(q), _dp(t), _dp(r), _dp(J), int(corrected)))
+        return r, J
+
+    def cost(self, q, t):
+        q, t = _f64(q), _f64(t)
+        cost, bad = C.c_double(), C.c_int64()
+        _check(load().ea_cost(self._h, _dp(q), _dp(t), C.byref(cost), C.byref(bad)))
+        return cost.value, bad.value
+
+    def solve(self, q, t, **opts):
+        q, t = _f64(q).copy(), _f64(t).copy()
+        o = default_options(**opts)
+        s = Summary()
+        _check(load().ea_solve(self._h, C.byref(o), _dp(q), _dp(t), C.byref(s)))
+        return q, t, summary_to_dict(s)
+
+
+class Batch:
+    """Several independent frame pairs evaluated / solved by the same launch sequence."""
+
+    def __init__(self, problems):
+        self.problems = list(problems)
+        arr = (C.c_void_p * len(self.problems))(*[p.handle for p in self.problems])
+        self._h = C.c_void_p()
+        _check(load().ea_batch_create(C.byref(self._h), arr, len(self.problems)))
+
+    def close(self):
+        if self._h:
+            load().ea_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return len(self.problems)
+
+    def eval(self, q, t):
+        q, t = _f64(q).reshape(-1, 4), _f64(t).reshape(-1, 3)
+        n = len(self)
+        cost, JtJ, Jtr = np.zeros(n), np.zeros((n, 6, 6)), np.zeros((n, 6))
+        bad = np.zeros(n, dtype=np.int64)
+        _check(load().ea_batch_eval(self._h, _dp(q), _dp(t), _dp(cost), _dp(JtJ), _dp(Jtr),
+                                    bad.ctypes.data_as(C.POINTER(C.c_int64))))
+        return dict(cost=cost, JtJ=JtJ, Jtr=Jtr, n_invalid=bad)
+
+    def solve(self, q, t, **opts):
+        q = _f64(q).reshape(-1, 4).copy()
+        t = _f64(t).reshape(-1, 3).copy()
+        o = default_options(**opts)
+        s = (Summary * len(self))()
+        _check(load().ea_batch_solve(self._h, C.byref(o), _dp(q), _dp(t), s))
+        return q, t, [summary_to_dict(x) for x in s]
+
+    def bench_eval(self, q, t, warmup, steps):
+        q, t = _f64(q).reshape(-1, 4), _f64(t).reshape(-1, 3)
+        ms_total, ms_kernel = C.c_double(), C.c_double()
+        _check(load().ea_batch_bench_eval(self._h, _dp(q), _dp(t), warmup, steps,
+                                          C.byref(ms_total), C.byref(ms_kernel)))
+        return ms_total.value, ms_kernel.value
+
+    def set_tuning(self, key, value):
+        _check(load().ea_batch_set_tuning(self._h, key.encode(), int(value)))
+
+    def info(self, key):
+        v = C.c_int64()
+        _check(load().ea_batch_get_info(self._h, key.encode(), C.byref(v)))
+        return v.value

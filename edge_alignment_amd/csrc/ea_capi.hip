@@ -1,0 +1,682 @@
+// ea_capi.hip — host driver behind include/ea_hip.h: HBM residency, tile lists, launches,
+// the device-resident trust-region loop, and the measurement hooks.  No CPU compute fallback:
+// without a gfx950 device every compute entry point returns EA_ERR_NO_DEVICE.
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ea_hip.h"
+#include "ea_lm.h"
+#include "ea_types.h"
+
+namespace ea {
+hipError_t launch_eval_fused(int dtype, int ppt, const ProblemDesc *probs, const Tile *tiles, int ntiles,
+                             int xcd_remap, const PoseState *poses, double *partials, int lds_bytes,
+                             hipStream_t stream);
+hipError_t launch_eval_points(int dtype, const ProblemDesc *probs, int problem, int n, const PoseState *poses,
+                              double *r_out, double *J_out, int corrected, hipStream_t stream);
+hipError_t launch_reduce(const ProblemDesc *probs, int count, const double *partials, EvalOut *out,
+                         hipStream_t stream);
+hipError_t launch_lm_step(const ProblemDesc *probs, int count, const double *partials, PoseState *poses,
+                          LMState *states, const LMOptions &opt, int *running_flags, hipStream_t stream);
+hipError_t launch_pad_image(int dtype, const void *src, int H, int W, void *dst, int pitch, hipStream_t stream);
+}  // namespace ea
+
+using namespace ea;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(e_ == hipErrorNoDevice ? EA_ERR_NO_DEVICE : EA_ERR_HIP,                     \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+  } while (0)
+
+struct ea_problem {
+  int device = 0;
+  int dtype = EA_F64;
+  ea_camera cam{};
+  int loss_kind = EA_LOSS_CAUCHY;  // the reference's `new CauchyLoss(1.)`
+  double loss_a = 1.0;
+  double z_guard = 0.01, z_eps = 0.0;
+  int rot_transposed = 0;
+  int64_t n = 0;
+  void *d_x = nullptr, *d_y = nullptr, *d_z = nullptr;
+  bool own_points = false;
+  void *d_dt = nullptr;
+  int W = 0, H = 0, pitch = 0;
+  uint64_t version = 1;  // bumped by every setter; batches rebuild their descriptors lazily
+  ea_batch *self = nullptr;
+  hipStream_t stream = nullptr;
+};
+
+struct ea_batch {
+  std::vector<ea_problem *> probs;
+  std::vector<uint64_t> versions;
+  int device = 0, dtype = EA_F64;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // device
+  ProblemDesc *d_probs = nullptr;
+  Tile *d_tiles = nullptr;
+  int ntiles = 0, tiles_cap = 0;
+  PoseState *d_poses = nullptr;
+  double *d_partials = nullptr;
+  EvalOut *d_out = nullptr;
+  LMState *d_states = nullptr;
+  int *d_running = nullptr;
+  // pinned host mirrors
+  PoseState *h_poses = nullptr;
+  EvalOut *h_out = nullptr;
+  LMState *h_states = nullptr;
+  int *h_running = nullptr;
+  // tuning (-1 = heuristic)
+  int t_lds_bytes = -1, t_ppt = -1, t_use_lds = -1, t_xcd = -1;
+  int ppt = 1, lds_bytes = 0, xcd_remap = 1;
+  bool built = false;
+};
+
+static int check_device(int device) {
+  int cnt = 0;
+  hipError_t e = hipGetDeviceCount(&cnt);
+  if (e != hipSuccess || cnt <= 0)
+    return fail(EA_ERR_NO_DEVICE, "no HIP device available (libea_hip has no CPU fallback)");
+  if (device < 0 || device >= cnt) return fail(EA_ERR_INVALID_ARG, "device index out of range");
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(EA_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+  return EA_OK;
+}
+
+extern "C" const char *ea_last_error(void) { return g_err.c_str(); }
+extern "C" const char *ea_version(void) { return "edge_alignment_amd 0.1 (gfx950)"; }
+
+extern "C" int ea_device_count(int *count) {
+  if (!count) return fail(EA_ERR_INVALID_ARG, "count is NULL");
+  int cnt = 0;
+  hipError_t e = hipGetDeviceCount(&cnt);
+  if (e != hipSuccess) { *count = 0; return fail(EA_ERR_NO_DEVICE, hipGetErrorString(e)); }
+  int n950 = 0;
+  for (int i = 0; i < cnt; ++i) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, i) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++n950;
+  }
+  *count = n950;
+  return EA_OK;
+}
+
+extern "C" void ea_default_options(ea_options *o) {
+  if (!o) return;
+  o->max_num_iterations = 50;
+  o->function_tolerance = 1e-6;
+  o->gradient_tolerance = 1e-10;
+  o->parameter_tolerance = 1e-8;
+  o->initial_trust_region_radius = 1e4;
+  o->max_trust_region_radius = 1e16;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->max_num_consecutive_invalid_steps = 5;
+  o->jacobi_scaling = 1;
+  o->strategy = EA_STRATEGY_LM;
+  o->minimizer_progress_to_stdout = 0;
+  o->iterations_per_sync = 0;
+}
+
+// ---- problem ------------------------------------------------------------------------------------
+
+extern "C" int ea_problem_create(ea_problem **out, const ea_camera *cam, int dtype, int device) {
+  if (!out || !cam) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  if (dtype != EA_F64 && dtype != EA_F32) return fail(EA_ERR_INVALID_ARG, "dtype must be EA_F64 or EA_F32");
+  int rc = check_device(device);
+  if (rc != EA_OK) return rc;
+  ea_problem *p = new (std::nothrow) ea_problem();
+  if (!p) return fail(EA_ERR_ALLOC, "out of host memory");
+  p->device = device;
+  p->dtype = dtype;
+  p->cam = *cam;
+  *out = p;
+  return EA_OK;
+}
+
+static void free_points(ea_problem *p) {
+  if (p->own_points) {
+    (void)hipFree(p->d_x); (void)hipFree(p->d_y); (void)hipFree(p->d_z);
+  }
+  p->d_x = p->d_y = p->d_z = nullptr;
+  p->own_points = false;
+  p->n = 0;
+}
+
+extern "C" void ea_batch_destroy(ea_batch *b);
+
+extern "C" void ea_problem_destroy(ea_problem *p) {
+  if (!p) return;
+  (void)hipSetDevice(p->device);
+  if (p->self) ea_batch_destroy(p->self);
+  free_points(p);
+  if (p->d_dt) (void)hipFree(p->d_dt);
+  delete p;
+}
+
+extern "C" int64_t ea_problem_num_points(const ea_problem *p) { return p ? p->n : 0; }
+
+extern "C" int ea_problem_set_points(ea_problem *p, const double *xyz, int64_t n, int64_t stride) {
+  if (!p || (n > 0 && !xyz)) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  if (n < 0 || n > 0x7fffff00LL) return fail(EA_ERR_INVALID_ARG, "n out of range");
+  if (stride < 3) return fail(EA_ERR_INVALID_ARG, "stride_elems must be >= 3");
+  HIPCHK(hipSetDevice(p->device));
+  free_points(p);
+  p->version++;
+  if (n == 0) return EA_OK;
+  const size_t esz = p->dtype == EA_F32 ? 4 : 8;
+  std::vector<unsigned char> soa(3 * (size_t)n * esz);
+  for (int c = 0; c < 3; ++c) {
+    if (p->dtype == EA_F32) {
+      float *dst = reinterpret_cast<float *>(soa.data()) + (size_t)c * n;
+      for (int64_t i = 0; i < n; ++i) dst[i] = (float)xyz[i * stride + c];
+    } else {
+      double *dst = reinterpret_cast<double *>(soa.data()) + (size_t)c * n;
+      for (int64_t i = 0; i < n; ++i) dst[i] = xyz[i * stride + c];
+    }
+  }
+  HIPCHK(hipMalloc(&p->d_x, n * esz));
+  HIPCHK(hipMalloc(&p->d_y, n * esz));
+  HIPCHK(hipMalloc(&p->d_z, n * esz));
+  p->own_points = true;
+  HIPCHK(hipMemcpy(p->d_x, soa.data(), n * esz, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(p->d_y, soa.data() + (size_t)n * esz, n * esz, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(p->d_z, soa.data() + 2 * (size_t)n * esz, n * esz, hipMemcpyHostToDevice));
+  p->n = n;
+  return EA_OK;
+}
+
+extern "C" int ea_problem_set_points_device(ea_problem *p, const void *x, const void *y, const void *z, int64_t n) {
+  if (!p || (n > 0 && (!x || !y || !z))) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  if (n < 0 || n > 0x7fffff00LL) return fail(EA_ERR_INVALID_ARG, "n out of range");
+  HIPCHK(hipSetDevice(p->device));
+  free_points(p);
+  p->d_x = const_cast<void *>(x); p->d_y = const_cast<void *>(y); p->d_z = const_cast<void *>(z);
+  p->own_points = false;
+  p->n = n;
+  p->version++;
+  return EA_OK;
+}
+
+static int alloc_dt(ea_problem *p, int W, int H) {
+  if (p->d_dt) { (void)hipFree(p->d_dt); p->d_dt = nullptr; }
+  p->W = W; p->H = H;
+  p->pitch = (W + 2 * kImagePad + 3) & ~3;
+  const size_t esz = p->dtype == EA_F32 ? 4 : 8;
+  HIPCHK(hipMalloc(&p->d_dt, (size_t)p->pitch * (size_t)(H + 2 * kImagePad) * esz));
+  return EA_OK;
+}
+
+extern "C" int ea_problem_set_dt(ea_problem *p, const double *data, int grid_rows, int grid_cols) {
+  if (!p || !data) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  if (grid_rows < 1 || grid_cols < 1 || grid_rows > 32768 || grid_cols > 32768)
+    return fail(EA_ERR_INVALID_ARG, "grid extent out of range");
+  HIPCHK(hipSetDevice(p->device));
+  // Grid2D rows index u, cols index v (ref: standalone_edge_align.cpp:258, utils.h:77).
+  const int W = grid_rows, H = grid_cols;
+  int rc = alloc_dt(p, W, H);
+  if (rc != EA_OK) return rc;
+  const size_t esz = p->dtype == EA_F32 ? 4 : 8;
+  const int PH = H + 2 * kImagePad, PW = W + 2 * kImagePad;
+  std::vector<unsigned char> img((size_t)p->pitch * PH * esz, 0);
+  for (int v = 0; v < PH; ++v) {
+    const int sv = std::min(std::max(v - kImagePad, 0), H - 1);
+    for (int u = 0; u < PW; ++u) {
+      const int su = std::min(std::max(u - kImagePad, 0), W - 1);
+      const double val = data[(size_t)su * (size_t)grid_cols + sv];
+      if (p->dtype == EA_F32) reinterpret_cast<float *>(img.data())[(size_t)v * p->pitch + u] = (float)val;
+      else reinterpret_cast<double *>(img.data())[(size_t)v * p->pitch + u] = val;
+    }
+  }
+  HIPCHK(hipMemcpy(p->d_dt, img.data(), img.size(), hipMemcpyHostToDevice));
+  p->version++;
+  return EA_OK;
+}
+
+extern "C" int ea_problem_set_dt_image_device(ea_problem *p, const void *image, int height, int width) {
+  if (!p || !image) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  if (height < 1 || width < 1 || height > 32768 || width > 32768)
+    return fail(EA_ERR_INVALID_ARG, "image extent out of range");
+  HIPCHK(hipSetDevice(p->device));
+  int rc = alloc_dt(p, width, height);
+  if (rc != EA_OK) return rc;
+  HIPCHK(launch_pad_image(p->dtype, image, height, width, p->d_dt, p->pitch, nullptr));
+  HIPCHK(hipDeviceSynchronize());
+  p->version++;
+  return EA_OK;
+}
+
+extern "C" int ea_problem_set_loss(ea_problem *p, int kind, double a) {
+  if (!p) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  if (kind < EA_LOSS_TRIVIAL || kind > EA_LOSS_HUBER) return fail(EA_ERR_INVALID_ARG, "unknown loss kind");
+  if (kind != EA_LOSS_TRIVIAL && !(a > 0.0)) return fail(EA_ERR_INVALID_ARG, "loss scale must be > 0");
+  p->loss_kind = kind;
+  p->loss_a = a;
+  p->version++;
+  return EA_OK;
+}
+
+extern "C" int ea_problem_set_flavour(ea_problem *p, double z_guard, double z_eps, int rot_transposed) {
+  if (!p) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  if (z_guard < 0.0) return fail(EA_ERR_INVALID_ARG, "z_guard must be >= 0");
+  p->z_guard = z_guard; p->z_eps = z_eps; p->rot_transposed = rot_transposed ? 1 : 0;
+  p->version++;
+  return EA_OK;
+}
+
+// ---- batch --------------------------------------------------------------------------------------
+
+static void batch_free_device(ea_batch *b) {
+  (void)hipFree(b->d_probs); (void)hipFree(b->d_tiles); (void)hipFree(b->d_poses);
+  (void)hipFree(b->d_partials); (void)hipFree(b->d_out); (void)hipFree(b->d_states); (void)hipFree(b->d_running);
+  (void)hipHostFree(b->h_poses); (void)hipHostFree(b->h_out); (void)hipHostFree(b->h_states); (void)hipHostFree(b->h_running);
+  b->d_probs = nullptr; b->d_tiles = nullptr; b->d_poses = nullptr; b->d_partials = nullptr;
+  b->d_out = nullptr; b->d_states = nullptr; b->d_running = nullptr;
+  b->h_poses = nullptr; b->h_out = nullptr; b->h_states = nullptr; b->h_running = nullptr;
+}
+
+extern "C" int ea_batch_create(ea_batch **out, ea_problem *const *problems, int count) {
+  if (!out || !problems || count < 1) return fail(EA_ERR_INVALID_ARG, "need at least one problem");
+  for (int i = 0; i < count; ++i) {
+    if (!problems[i]) return fail(EA_ERR_INVALID_ARG, "NULL problem in batch");
+    if (problems[i]->device != problems[0]->device || problems[i]->dtype != problems[0]->dtype)
+      return fail(EA_ERR_INVALID_ARG, "all problems of a batch must share device and dtype");
+  }
+  ea_batch *b = new (std::nothrow) ea_batch();
+  if (!b) return fail(EA_ERR_ALLOC, "out of host memory");
+  b->probs.assign(problems, problems + count);
+  b->versions.assign(count, 0);
+  b->device = problems[0]->device;
+  b->dtype = problems[0]->dtype;
+  hipError_t e = hipSetDevice(b->device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete b; return fail(EA_ERR_HIP, hipGetErrorString(e)); }
+  b->own_stream = true;
+  const size_t c = (size_t)count;
+  e = hipMalloc(&b->d_probs, c * sizeof(ProblemDesc));
+  if (e == hipSuccess) e = hipMalloc(&b->d_poses, c * sizeof(PoseState));
+  if (e == hipSuccess) e = hipMalloc(&b->d_out, c * sizeof(EvalOut));
+  if (e == hipSuccess) e = hipMalloc(&b->d_states, c * sizeof(LMState));
+  if (e == hipSuccess) e = hipMalloc(&b->d_running, c * sizeof(int));
+  if (e == hipSuccess) e = hipHostMalloc(&b->h_poses, c * sizeof(PoseState));
+  if (e == hipSuccess) e = hipHostMalloc(&b->h_out, c * sizeof(EvalOut));
+  if (e == hipSuccess) e = hipHostMalloc(&b->h_states, c * sizeof(LMState));
+  if (e == hipSuccess) e = hipHostMalloc(&b->h_running, c * sizeof(int));
+  if (e != hipSuccess) {
+    batch_free_device(b);
+    (void)hipStreamDestroy(b->stream);
+    delete b;
+    return fail(EA_ERR_ALLOC, std::string("batch allocation: ") + hipGetErrorString(e));
+  }
+  *out = b;
+  return EA_OK;
+}
+
+extern "C" void ea_batch_destroy(ea_batch *b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  batch_free_device(b);
+  if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
+  for (ea_problem *p : b->probs)
+    if (p && p->self == b) p->self = nullptr;
+  delete b;
+}
+
+extern "C" int ea_batch_count(const ea_batch *b) { return b ? (int)b->probs.size() : 0; }
+
+// (re)build descriptors and the tile list when any problem changed
+static int batch_build(ea_batch *b) {
+  bool dirty = !b->built;
+  for (size_t i = 0; i < b->probs.size(); ++i)
+    if (b->versions[i] != b->probs[i]->version) dirty = true;
+  if (!dirty) return EA_OK;
+  HIPCHK(hipSetDevice(b->device));
+  int64_t total = 0;
+  for (ea_problem *p : b->probs) {
+    if (!p->d_dt) return fail(EA_ERR_STATE, "distance-transform image not set (ea_problem_set_dt)");
+    if (p->n > 0 && !p->d_x) return fail(EA_ERR_STATE, "edge points not set (ea_problem_set_points)");
+    total += p->n;
+  }
+  // points per thread: keep >= ~1024 workgroups (4 per CU) in flight when the batch is large enough
+  int ppt = b->t_ppt;
+  if (ppt != 1 && ppt != 2 && ppt != 4) {
+    const int64_t per = total / ((int64_t)kBlockThreads * 1024);
+    ppt = per >= 4 ? 4 : (per >= 2 ? 2 : 1);
+  }
+  b->ppt = ppt;
+  const int chunk = kBlockThreads * ppt;
+  std::vector<ProblemDesc> descs(b->probs.size());
+  std::vector<Tile> tiles;
+  for (size_t i = 0; i < b->probs.size(); ++i) {
+    ea_problem *p = b->probs[i];
+    ProblemDesc &d = descs[i];
+    std::memset(&d, 0, sizeof(d));
+    d.x = p->d_x; d.y = p->d_y; d.z = p->d_z; d.dt = p->d_dt;
+    d.n = (int32_t)p->n; d.W = p->W; d.H = p->H; d.pitch = p->pitch;
+    d.fx = p->cam.fx; d.fy = p->cam.fy; d.cx = p->cam.cx; d.cy = p->cam.cy;
+    d.loss_a = p->loss_a; d.z_guard = p->z_guard; d.z_eps = p->z_eps;
+    d.loss_kind = p->loss_kind; d.rot_transposed = p->rot_transposed;
+    d.tile_begin = (int32_t)tiles.size();
+    for (int64_t s = 0; s < p->n; s += chunk) {
+      Tile t;
+      t.problem = (int32_t)i; t.start = (int32_t)s;
+      t.count = (int32_t)std::min<int64_t>(chunk, p->n - s);
+      t.pad_ = 0;
+      tiles.push_back(t);
+    }
+    d.tile_end = (int32_t)tiles.size();
+    b->versions[i] = p->version;
+  }
+  b->ntiles = (int)tiles.size();
+  if (b->ntiles > b->tiles_cap) {
+    (void)hipFree(b->d_tiles); (void)hipFree(b->d_partials);
+    b->d_tiles = nullptr; b->d_partials = nullptr;
+    b->tiles_cap = b->ntiles + b->ntiles / 4 + 16;
+    HIPCHK(hipMalloc(&b->d_tiles, (size_t)b->tiles_cap * sizeof(Tile)));
+    HIPCHK(hipMalloc(&b->d_partials, (size_t)b->tiles_cap * kAccSlots * sizeof(double)));
+  }
+  HIPCHK(hipMemcpy(b->d_probs, descs.data(), descs.size() * sizeof(ProblemDesc), hipMemcpyHostToDevice));
+  if (b->ntiles)
+    HIPCHK(hipMemcpy(b->d_tiles, tiles.data(), tiles.size() * sizeof(Tile), hipMemcpyHostToDevice));
+  int use_lds = b->t_use_lds < 0 ? 1 : b->t_use_lds;
+  int lds = b->t_lds_bytes >= 0 ? b->t_lds_bytes : (b->dtype == EA_F32 ? 32768 : 49152);
+  if (lds > 61440) lds = 61440;
+  b->lds_bytes = use_lds ? lds : 0;
+  b->xcd_remap = b->t_xcd < 0 ? 1 : (b->t_xcd ? 1 : 0);
+  b->built = true;
+  return EA_OK;
+}
+
+static void host_pose_state(const ea_problem *p, const double *q, const double *t, PoseState *ps) {
+  double x[7] = {q[0], q[1], q[2], q[3], t[0], t[1], t[2]};
+  make_pose_state(x, p->rot_transposed, 1, ps);
+}
+
+static int batch_launch_eval(ea_batch *b) {
+  HIPCHK(launch_eval_fused(b->dtype, b->ppt, b->d_probs, b->d_tiles, b->ntiles, b->xcd_remap, b->d_poses,
+                           b->d_partials, b->lds_bytes, b->stream));
+  return EA_OK;
+}
+
+static int batch_upload_poses(ea_batch *b, const double *q, const double *t) {
+  const int count = (int)b->probs.size();
+  for (int i = 0; i < count; ++i) host_pose_state(b->probs[i], q + 4 * i, t + 3 * i, &b->h_poses[i]);
+  HIPCHK(hipMemcpyAsync(b->d_poses, b->h_poses, count * sizeof(PoseState), hipMemcpyHostToDevice, b->stream));
+  return EA_OK;
+}
+
+extern "C" int ea_batch_eval(ea_batch *b, const double *q, const double *t, double *cost, double *JtJ,
+                             double *Jtr, int64_t *n_invalid) {
+  if (!b || !q || !t) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  int rc = batch_build(b);
+  if (rc != EA_OK) return rc;
+  const int count = (int)b->probs.size();
+  rc = batch_upload_poses(b, q, t);
+  if (rc != EA_OK) return rc;
+  rc = batch_launch_eval(b);
+  if (rc != EA_OK) return rc;
+  HIPCHK(launch_reduce(b->d_probs, count, b->d_partials, b->d_out, b->stream));
+  HIPCHK(hipMemcpyAsync(b->h_out, b->d_out, count * sizeof(EvalOut), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  for (int i = 0; i < count; ++i) {
+    const double *acc = b->h_out[i].acc;
+    if (cost) cost[i] = acc[kAccCost];
+    if (JtJ) {
+      int k = 0;
+      for (int a = 0; a < 6; ++a)
+        for (int c = a; c < 6; ++c) {
+          JtJ[36 * i + 6 * a + c] = acc[kAccJtJ + k];
+          JtJ[36 * i + 6 * c + a] = acc[kAccJtJ + k];
+          ++k;
+        }
+    }
+    if (Jtr) for (int a = 0; a < 6; ++a) Jtr[6 * i + a] = acc[kAccJtr + a];
+    if (n_invalid) n_invalid[i] = (int64_t)llround(acc[kAccInvalid]);
+  }
+  return EA_OK;
+}
+
+static void fill_summary(const LMState &s, int64_t npts, double ms, ea_summary *out) {
+  std::memset(out, 0, sizeof(*out));
+  out->termination = s.termination;
+  out->why = s.why;
+  out->num_iterations = s.iteration;
+  out->num_successful_steps = s.num_successful;
+  out->num_unsuccessful_steps = s.num_unsuccessful;
+  out->initial_cost = s.it_cost[0];
+  out->final_cost = s.cost;
+  out->num_point_evals = (int64_t)s.num_evals * npts;
+  out->total_time_ms = ms;
+  const int ni = std::min(s.iteration + 1, (int)EA_MAX_TRACE);
+  for (int i = 0; i < ni; ++i) {
+    out->it_cost[i] = s.it_cost[i];
+    out->it_cost_change[i] = s.it_cost_change[i];
+    out->it_gradient_max_norm[i] = s.it_gradient_max_norm[i];
+    out->it_step_norm[i] = s.it_step_norm[i];
+    out->it_relative_decrease[i] = s.it_relative_decrease[i];
+    out->it_radius[i] = s.it_radius[i];
+    out->it_successful[i] = s.it_successful[i];
+  }
+}
+
+extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, double *t, ea_summary *summaries) {
+  if (!b || !q || !t) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  static_assert(EA_MAX_TRACE == kTrace, "trace length mismatch");
+  const auto t0 = std::chrono::steady_clock::now();
+  ea_options o;
+  if (opt_in) o = *opt_in; else ea_default_options(&o);
+  if (o.max_num_iterations < 0) return fail(EA_ERR_INVALID_ARG, "max_num_iterations < 0");
+  if (o.strategy != EA_STRATEGY_LM && o.strategy != EA_STRATEGY_DOGLEG)
+    return fail(EA_ERR_INVALID_ARG, "unknown trust-region strategy");
+  int rc = batch_build(b);
+  if (rc != EA_OK) return rc;
+  const int count = (int)b->probs.size();
+  LMOptions lo;
+  lo.max_num_iterations = o.max_num_iterations;
+  lo.function_tolerance = o.function_tolerance;
+  lo.gradient_tolerance = o.gradient_tolerance;
+  lo.parameter_tolerance = o.parameter_tolerance;
+  lo.initial_trust_region_radius = o.initial_trust_region_radius;
+  lo.max_trust_region_radius = o.max_trust_region_radius;
+  lo.min_trust_region_radius = o.min_trust_region_radius;
+  lo.min_relative_decrease = o.min_relative_decrease;
+  lo.min_lm_diagonal = o.min_lm_diagonal;
+  lo.max_lm_diagonal = o.max_lm_diagonal;
+  lo.max_num_consecutive_invalid_steps = o.max_num_consecutive_invalid_steps;
+  lo.jacobi_scaling = o.jacobi_scaling;
+  lo.strategy = o.strategy;
+  for (int i = 0; i < count; ++i) {
+    lm_init(&b->h_states[i], &lo, q + 4 * i, t + 3 * i, b->probs[i]->rot_transposed);
+    host_pose_state(b->probs[i], q + 4 * i, t + 3 * i, &b->h_poses[i]);
+    b->h_running[i] = 1;
+  }
+  HIPCHK(hipMemcpyAsync(b->d_states, b->h_states, count * sizeof(LMState), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_poses, b->h_poses, count * sizeof(PoseState), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_running, b->h_running, count * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  const int chunk = o.iterations_per_sync > 0 ? o.iterations_per_sync : 8;
+  // every (evaluate, step) pair consumes at least one iteration, so max+2 pairs always suffice
+  int budget = o.max_num_iterations + 2;
+  while (budget > 0) {
+    const int m = std::min(chunk, budget);
+    for (int k = 0; k < m; ++k) {
+      rc = batch_launch_eval(b);
+      if (rc != EA_OK) return rc;
+      HIPCHK(launch_lm_step(b->d_probs, count, b->d_partials, b->d_poses, b->d_states, lo, b->d_running, b->stream));
+    }
+    budget -= m;
+    HIPCHK(hipMemcpyAsync(b->h_running, b->d_running, count * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    bool any = false;
+    for (int i = 0; i < count; ++i) any = any || (b->h_running[i] != 0);
+    if (!any) break;
+  }
+  HIPCHK(hipMemcpyAsync(b->h_states, b->d_states, count * sizeof(LMState), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  for (int i = 0; i < count; ++i) {
+    const LMState &s = b->h_states[i];
+    for (int k = 0; k < 4; ++k) q[4 * i + k] = s.x[k];
+    for (int k = 0; k < 3; ++k) t[3 * i + k] = s.x[4 + k];
+    if (summaries) fill_summary(s, b->probs[i]->n, ms, &summaries[i]);
+    if (o.minimizer_progress_to_stdout) {
+      std::printf("problem %d\niter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n", i);
+      const int ni = std::min(s.iteration + 1, (int)kTrace);
+      for (int it = 0; it < ni; ++it)
+        std::printf("%4d  %.6e  % .2e    %.2e   %.2e  % .2e  %.2e\n", it, s.it_cost[it], s.it_cost_change[it],
+                    s.it_gradient_max_norm[it], s.it_step_norm[it], s.it_relative_decrease[it], s.it_radius[it]);
+    }
+  }
+  return EA_OK;
+}
+
+extern "C" int ea_batch_bench_eval(ea_batch *b, const double *q, const double *t, int warmup, int steps,
+                                   double *ms_total, double *ms_eval_kernel) {
+  if (!b || !q || !t || steps < 1 || warmup < 0) return fail(EA_ERR_INVALID_ARG, "bad argument");
+  int rc = batch_build(b);
+  if (rc != EA_OK) return rc;
+  const int count = (int)b->probs.size();
+  rc = batch_upload_poses(b, q, t);
+  if (rc != EA_OK) return rc;
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  auto one_step = [&]() -> int {
+    int r = batch_launch_eval(b);
+    if (r != EA_OK) return r;
+    HIPCHK(launch_reduce(b->d_probs, count, b->d_partials, b->d_out, b->stream));
+    return EA_OK;
+  };
+  for (int i = 0; i < warmup; ++i) if ((rc = one_step()) != EA_OK) return rc;
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipEventRecord(e0, b->stream));
+  for (int i = 0; i < steps; ++i) if ((rc = one_step()) != EA_OK) return rc;
+  HIPCHK(hipEventRecord(e1, b->stream));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  if (ms_total) *ms_total = ms;
+  if (ms_eval_kernel) {
+    // second pass over the same steps: an event pair around every launch of the per-point kernel
+    const int m = std::min(steps, 64);
+    std::vector<hipEvent_t> ev(2 * m);
+    for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+    for (int i = 0; i < m; ++i) {
+      HIPCHK(hipEventRecord(ev[2 * i], b->stream));
+      if ((rc = batch_launch_eval(b)) != EA_OK) return rc;
+      HIPCHK(hipEventRecord(ev[2 * i + 1], b->stream));
+      HIPCHK(launch_reduce(b->d_probs, count, b->d_partials, b->d_out, b->stream));
+    }
+    HIPCHK(hipStreamSynchronize(b->stream));
+    double sum = 0.0;
+    for (int i = 0; i < m; ++i) {
+      float k = 0.f;
+      HIPCHK(hipEventElapsedTime(&k, ev[2 * i], ev[2 * i + 1]));
+      sum += k;
+    }
+    *ms_eval_kernel = sum / m;
+    for (auto &e : ev) (void)hipEventDestroy(e);
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return EA_OK;
+}
+
+extern "C" int ea_batch_set_tuning(ea_batch *b, const char *key, int value) {
+  if (!b || !key) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  const std::string k(key);
+  if (k == "lds_bytes") b->t_lds_bytes = value;
+  else if (k == "points_per_thread") b->t_ppt = value;
+  else if (k == "use_lds") b->t_use_lds = value;
+  else if (k == "xcd_remap") b->t_xcd = value;
+  else return fail(EA_ERR_INVALID_ARG, "unknown tuning key: " + k);
+  b->built = false;
+  return EA_OK;
+}
+
+extern "C" int ea_batch_get_info(const ea_batch *b, const char *key, int64_t *value) {
+  if (!b || !key || !value) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  const std::string k(key);
+  if (k == "num_tiles") *value = b->ntiles;
+  else if (k == "points_per_thread") *value = b->ppt;
+  else if (k == "lds_bytes") *value = b->lds_bytes;
+  else if (k == "xcd_remap") *value = b->xcd_remap;
+  else if (k == "num_points") { int64_t s = 0; for (auto *p : b->probs) s += p->n; *value = s; }
+  else return fail(EA_ERR_INVALID_ARG, "unknown info key: " + k);
+  return EA_OK;
+}
+
+// ---- single-problem conveniences = batch of one ------------------------------------------------
+
+static int self_batch(ea_problem *p, ea_batch **out) {
+  if (!p) return fail(EA_ERR_INVALID_ARG, "NULL problem");
+  if (!p->self) {
+    ea_batch *b = nullptr;
+    int rc = ea_batch_create(&b, &p, 1);
+    if (rc != EA_OK) return rc;
+    p->self = b;
+  }
+  *out = p->self;
+  return EA_OK;
+}
+
+extern "C" int ea_eval(ea_problem *p, const double q[4], const double t[3], double *cost, double JtJ[36],
+                       double Jtr[6], int64_t *n_invalid) {
+  ea_batch *b;
+  int rc = self_batch(p, &b);
+  if (rc != EA_OK) return rc;
+  return ea_batch_eval(b, q, t, cost, JtJ, Jtr, n_invalid);
+}
+
+extern "C" int ea_cost(ea_problem *p, const double q[4], const double t[3], double *cost, int64_t *n_invalid) {
+  return ea_eval(p, q, t, cost, nullptr, nullptr, n_invalid);
+}
+
+extern "C" int ea_eval_points(ea_problem *p, const double q[4], const double t[3], double *r, double *J, int corrected) {
+  if (!q || !t) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  ea_batch *b;
+  int rc = self_batch(p, &b);
+  if (rc != EA_OK) return rc;
+  rc = batch_build(b);
+  if (rc != EA_OK) return rc;
+  if (p->n == 0) return EA_OK;
+  rc = batch_upload_poses(b, q, t);
+  if (rc != EA_OK) return rc;
+  double *d_r = nullptr, *d_J = nullptr;
+  if (r) HIPCHK(hipMalloc(&d_r, p->n * sizeof(double)));
+  if (J) HIPCHK(hipMalloc(&d_J, p->n * 6 * sizeof(double)));
+  hipError_t e = launch_eval_points(p->dtype, b->d_probs, 0, (int)p->n, b->d_poses, d_r, d_J, corrected, b->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+  if (e == hipSuccess && r) e = hipMemcpy(r, d_r, p->n * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && J) e = hipMemcpy(J, d_J, p->n * 6 * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(d_r); (void)hipFree(d_J);
+  if (e != hipSuccess) return fail(EA_ERR_HIP, hipGetErrorString(e));
+  return EA_OK;
+}
+
+extern "C" int ea_solve(ea_problem *p, const ea_options *opt, double q[4], double t[3], ea_summary *summary) {
+  ea_batch *b;
+  int rc = self_batch(p, &b);
+  if (rc != EA_OK) return rc;
+  return ea_batch_solve(b, opt, q, t, summary);
+}

@@ -1,0 +1,399 @@
+// ea_lm.h — the 6-dof trust-region state machine, compiled for both the host and gfx950.
+//
+// It replaces what ceres::Solve does around the evaluator for this problem shape
+// (ref: standalone/standalone_edge_align.cpp:277-286, src/SolveEA.cpp:180-198):
+// QuaternionParameterization::Plus, Jacobi scaling, LevenbergMarquardtStrategy (or traditional
+// DoglegStrategy), the monotonic step evaluator, and TrustRegionMinimizer's convergence tests.
+// The N x 6 Jacobian is never materialised: the state machine only consumes the 32 fp64
+// accumulators (JtJ, Jtr, cost, #invalid) the evaluation kernels reduce.
+//
+// One evaluation per iteration: every evaluation computes cost AND JtJ/Jtr at the candidate
+// pose, so an accepted step needs no second pass (Ceres evaluates residuals at the candidate and
+// then residuals+Jacobian again at the same point; the numbers are identical).
+#pragma once
+#include <float.h>
+#include <math.h>
+
+#include "ea_types.h"
+
+namespace ea {
+
+struct LMOptions {
+  int max_num_iterations;
+  double function_tolerance, gradient_tolerance, parameter_tolerance;
+  double initial_trust_region_radius, max_trust_region_radius, min_trust_region_radius;
+  double min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
+  int max_num_consecutive_invalid_steps;
+  int jacobi_scaling;
+  int strategy;  // 0 LM, 1 traditional dogleg
+};
+
+constexpr int kTrace = 128;
+
+struct LMState {
+  double x[7], cand[7];
+  double x_norm, cost;
+  double A[36], g[6];  // unscaled JtJ and Jtr at x
+  double S[6];         // Jacobi column scaling, fixed at iteration 0
+  // LevenbergMarquardtStrategy
+  double radius, decrease_factor, diagonal[6];
+  int reuse_diagonal;
+  // DoglegStrategy (traditional)
+  double mu, alpha, dogleg_step_norm, dl_diag[6], dl_grad[6], dl_gn[6];
+  int dl_reuse;
+  double model_cost_change;
+  double gradient_max_norm;
+  int iteration;
+  int running;      // 1 while the solve needs another evaluation
+  int termination;  // ea_termination
+  int why;          // ea_why
+  int num_successful, num_unsuccessful, num_consecutive_invalid;
+  int num_evals;    // whole-problem evaluations performed
+  int rot_transposed;
+  // trace
+  double it_cost[kTrace], it_cost_change[kTrace], it_gradient_max_norm[kTrace];
+  double it_step_norm[kTrace], it_relative_decrease[kTrace], it_radius[kTrace];
+  int it_successful[kTrace];
+};
+
+// ---- small helpers ---------------------------------------------------------------------------
+
+EA_HD inline double norm_n(const double *v, int n) {
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += v[i] * v[i];
+  return sqrt(s);
+}
+
+// QuaternionParameterization::Plus: x_plus = [cos|d|, sin|d|/|d| d] (x) x
+EA_HD inline void quat_plus(const double x[4], const double d[3], double out[4]) {
+  const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  if (nd > 0.0) {
+    const double s = sin(nd) / nd;
+    const double q0 = cos(nd), q1 = s * d[0], q2 = s * d[1], q3 = s * d[2];
+    out[0] = q0 * x[0] - q1 * x[1] - q2 * x[2] - q3 * x[3];
+    out[1] = q0 * x[1] + q1 * x[0] + q2 * x[3] - q3 * x[2];
+    out[2] = q0 * x[2] - q1 * x[3] + q2 * x[0] + q3 * x[1];
+    out[3] = q0 * x[3] + q1 * x[2] - q2 * x[1] + q3 * x[0];
+  } else {
+    for (int i = 0; i < 4; ++i) out[i] = x[i];
+  }
+}
+
+EA_HD inline void pose_plus(const double x[7], const double delta[6], double out[7]) {
+  quat_plus(x, delta, out);
+  for (int i = 0; i < 3; ++i) out[4 + i] = x[4 + i] + delta[3 + i];
+}
+
+// Pose constants for the kernels.  R follows Eigen's un-normalised toRotationMatrix
+// (ref: standalone/utils.h:51-53); G_j = sum_i dR/dq_i P_ij is the exact tangent derivative for
+// any |q| (P = QuaternionParameterization Jacobian); for |q| = 1 it reduces to -2 [R a]x and the
+// kernels take the short form.
+EA_HD inline void make_pose_state(const double x[7], int rot_transposed, int active,
+                                  PoseState *ps) {
+  const double w = x[0], qx = x[1], qy = x[2], qz = x[3];
+  for (int i = 0; i < 4; ++i) ps->q[i] = x[i];
+  for (int i = 0; i < 3; ++i) ps->t[i] = x[4 + i];
+  double R[9];
+  R[0] = 1.0 - 2.0 * (qy * qy + qz * qz); R[1] = 2.0 * (qx * qy - w * qz); R[2] = 2.0 * (qx * qz + w * qy);
+  R[3] = 2.0 * (qx * qy + w * qz); R[4] = 1.0 - 2.0 * (qx * qx + qz * qz); R[5] = 2.0 * (qy * qz - w * qx);
+  R[6] = 2.0 * (qx * qz - w * qy); R[7] = 2.0 * (qy * qz + w * qx); R[8] = 1.0 - 2.0 * (qx * qx + qy * qy);
+  const double dR[4][9] = {
+      {0, -2 * qz, 2 * qy, 2 * qz, 0, -2 * qx, -2 * qy, 2 * qx, 0},
+      {0, 2 * qy, 2 * qz, 2 * qy, -4 * qx, -2 * w, 2 * qz, 2 * w, -4 * qx},
+      {-4 * qy, 2 * qx, 2 * w, 2 * qx, 0, 2 * qz, -2 * w, 2 * qz, -4 * qy},
+      {-4 * qz, -2 * w, 2 * qx, 2 * w, -4 * qz, 2 * qy, 2 * qx, 2 * qy, 0}};
+  const double P[12] = {-qx, -qy, -qz, w, qz, -qy, -qz, w, qx, qy, -qx, w};
+  for (int j = 0; j < 3; ++j)
+    for (int e = 0; e < 9; ++e) {
+      double s = 0.0;
+      for (int i = 0; i < 4; ++i) s += dR[i][e] * P[3 * i + j];
+      ps->G[9 * j + e] = s;
+    }
+  for (int e = 0; e < 9; ++e) ps->R[e] = R[e];
+  if (rot_transposed) {  // ref: include/EAResidue.h:99-101 applies R^T
+    for (int a = 0; a < 3; ++a)
+      for (int b = a + 1; b < 3; ++b) {
+        double tmp = ps->R[3 * a + b];
+        ps->R[3 * a + b] = ps->R[3 * b + a];
+        ps->R[3 * b + a] = tmp;
+        for (int j = 0; j < 3; ++j) {
+          tmp = ps->G[9 * j + 3 * a + b];
+          ps->G[9 * j + 3 * a + b] = ps->G[9 * j + 3 * b + a];
+          ps->G[9 * j + 3 * b + a] = tmp;
+        }
+      }
+  }
+  const double n2 = w * w + qx * qx + qy * qy + qz * qz;
+  ps->unit_q = (fabs(n2 - 1.0) <= 1e-12 && !rot_transposed) ? 1 : 0;
+  ps->active = active;
+}
+
+// (A + diag(D^2)) y = g, 6x6 Cholesky.  Returns false when not positive definite / not finite.
+EA_HD inline bool solve_spd6(const double A[36], const double D[6], const double g[6], double y[6]) {
+  double L[36];
+  for (int i = 0; i < 36; ++i) L[i] = 0.0;
+  for (int i = 0; i < 6; ++i) {
+    for (int j = 0; j <= i; ++j) {
+      double s = A[6 * i + j] + (i == j ? D[i] * D[i] : 0.0);
+      for (int k = 0; k < j; ++k) s -= L[6 * i + k] * L[6 * j + k];
+      if (i == j) {
+        if (!(s > 0.0)) return false;
+        L[6 * i + i] = sqrt(s);
+      } else {
+        L[6 * i + j] = s / L[6 * j + j];
+      }
+    }
+  }
+  double z[6];
+  for (int i = 0; i < 6; ++i) {
+    double s = g[i];
+    for (int k = 0; k < i; ++k) s -= L[6 * i + k] * z[k];
+    z[i] = s / L[6 * i + i];
+  }
+  for (int i = 5; i >= 0; --i) {
+    double s = z[i];
+    for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * y[k];
+    y[i] = s / L[6 * i + i];
+  }
+  for (int i = 0; i < 6; ++i)
+    if (!(fabs(y[i]) <= DBL_MAX)) return false;
+  return true;
+}
+
+EA_HD inline void lm_trace(LMState *s, int it, double cost_change, double step_norm, double rel,
+                           int successful) {
+  if (it < kTrace) {
+    s->it_cost[it] = s->cost;
+    s->it_cost_change[it] = cost_change;
+    s->it_gradient_max_norm[it] = s->gradient_max_norm;
+    s->it_step_norm[it] = step_norm;
+    s->it_relative_decrease[it] = rel;
+    s->it_radius[it] = s->radius;
+    s->it_successful[it] = successful;
+  }
+}
+
+EA_HD inline void lm_finish(LMState *s, int termination, int why) {
+  s->running = 0;
+  s->termination = termination;
+  s->why = why;
+}
+
+EA_HD inline void lm_init(LMState *s, const LMOptions *o, const double q[4], const double t[3],
+                          int rot_transposed) {
+  for (int i = 0; i < 4; ++i) s->x[i] = q[i];
+  for (int i = 0; i < 3; ++i) s->x[4 + i] = t[i];
+  for (int i = 0; i < 7; ++i) s->cand[i] = s->x[i];
+  s->x_norm = norm_n(s->x, 7);
+  s->cost = 0.0;
+  for (int i = 0; i < 36; ++i) s->A[i] = 0.0;
+  for (int i = 0; i < 6; ++i) { s->g[i] = 0.0; s->S[i] = 1.0; s->diagonal[i] = 0.0; }
+  s->radius = o->initial_trust_region_radius;
+  s->decrease_factor = 2.0;
+  s->reuse_diagonal = 0;
+  s->mu = 1e-8; s->alpha = 0.0; s->dogleg_step_norm = 0.0; s->dl_reuse = 0;
+  s->model_cost_change = 0.0;
+  s->gradient_max_norm = 0.0;
+  s->iteration = 0;
+  s->running = 1;
+  s->termination = 1; s->why = 0;
+  s->num_successful = s->num_unsuccessful = s->num_consecutive_invalid = 0;
+  s->num_evals = 0;
+  s->rot_transposed = rot_transposed;
+}
+
+// load JtJ/Jtr from the accumulator slots into the state (the evaluation was made at s->x)
+EA_HD inline void lm_take_system(LMState *s, const double acc[kAccSlots]) {
+  int k = 0;
+  for (int a = 0; a < 6; ++a)
+    for (int b = a; b < 6; ++b) {
+      s->A[6 * a + b] = acc[kAccJtJ + k];
+      s->A[6 * b + a] = acc[kAccJtJ + k];
+      ++k;
+    }
+  for (int a = 0; a < 6; ++a) s->g[a] = acc[kAccJtr + a];
+  s->cost = acc[kAccCost];
+  // gradient_max_norm = || x - Plus(x, -gradient) ||_inf  (ambient space)
+  double neg[6], xp[7], m = 0.0;
+  for (int i = 0; i < 6; ++i) neg[i] = -s->g[i];
+  pose_plus(s->x, neg, xp);
+  for (int i = 0; i < 7; ++i) m = fmax(m, fabs(s->x[i] - xp[i]));
+  s->gradient_max_norm = m;
+}
+
+// scaled-space step from the current strategy; false = linear solve failed
+EA_HD inline bool lm_strategy_step(LMState *s, const LMOptions *o, const double As[36],
+                                   const double gs[6], double step[6]) {
+  if (o->strategy == 0) {
+    if (!s->reuse_diagonal)
+      for (int i = 0; i < 6; ++i)
+        s->diagonal[i] = fmin(fmax(As[6 * i + i], o->min_lm_diagonal), o->max_lm_diagonal);
+    double D[6], y[6];
+    for (int i = 0; i < 6; ++i) D[i] = sqrt(s->diagonal[i] / s->radius);
+    s->reuse_diagonal = 1;
+    if (!solve_spd6(As, D, gs, y)) return false;
+    for (int i = 0; i < 6; ++i) step[i] = -y[i];
+    return true;
+  }
+  // traditional dogleg
+  if (!s->dl_reuse) {
+    for (int i = 0; i < 6; ++i)
+      s->dl_diag[i] = sqrt(fmin(fmax(As[6 * i + i], o->min_lm_diagonal), o->max_lm_diagonal));
+    for (int i = 0; i < 6; ++i) s->dl_grad[i] = gs[i] / s->dl_diag[i];
+    double v[6], qf = 0.0, g2 = 0.0;
+    for (int i = 0; i < 6; ++i) v[i] = s->dl_grad[i] / s->dl_diag[i];
+    for (int a = 0; a < 6; ++a)
+      for (int b = 0; b < 6; ++b) qf += v[a] * As[6 * a + b] * v[b];
+    for (int i = 0; i < 6; ++i) g2 += s->dl_grad[i] * s->dl_grad[i];
+    s->alpha = g2 / qf;
+    bool ok = false;
+    while (s->mu < 1.0) {
+      double D[6], y[6];
+      for (int i = 0; i < 6; ++i) D[i] = s->dl_diag[i] * sqrt(s->mu);
+      ok = solve_spd6(As, D, gs, y);
+      if (ok) {
+        for (int i = 0; i < 6; ++i) s->dl_gn[i] = y[i];
+        break;
+      }
+      s->mu *= 10.0;
+    }
+    if (!ok) return false;
+    s->mu = fmax(1e-8, 2.0 * s->mu / 10.0);
+    for (int i = 0; i < 6; ++i) s->dl_gn[i] *= -s->dl_diag[i];
+  }
+  const double gn_norm = norm_n(s->dl_gn, 6);
+  if (gn_norm <= s->radius) {
+    for (int i = 0; i < 6; ++i) step[i] = s->dl_gn[i] / s->dl_diag[i];
+    s->dogleg_step_norm = gn_norm;
+    return true;
+  }
+  const double gradient_norm = norm_n(s->dl_grad, 6);
+  if (gradient_norm * s->alpha >= s->radius) {
+    for (int i = 0; i < 6; ++i)
+      step[i] = -(s->radius / gradient_norm) * s->dl_grad[i] / s->dl_diag[i];
+    s->dogleg_step_norm = s->radius;
+    return true;
+  }
+  double b_dot_a = 0.0;
+  for (int i = 0; i < 6; ++i) b_dot_a += -s->alpha * s->dl_grad[i] * s->dl_gn[i];
+  const double a_sq = (s->alpha * gradient_norm) * (s->alpha * gradient_norm);
+  const double bma_sq = a_sq - 2.0 * b_dot_a + gn_norm * gn_norm;
+  const double c = b_dot_a - a_sq;
+  const double d = sqrt(c * c + bma_sq * (s->radius * s->radius - a_sq));
+  const double beta = (c <= 0) ? (d - c) / bma_sq : (s->radius * s->radius - a_sq) / (d + c);
+  double dl[6];
+  for (int i = 0; i < 6; ++i) dl[i] = (-s->alpha * (1.0 - beta)) * s->dl_grad[i] + beta * s->dl_gn[i];
+  s->dogleg_step_norm = norm_n(dl, 6);
+  for (int i = 0; i < 6; ++i) step[i] = dl[i] / s->dl_diag[i];
+  return true;
+}
+
+// Top of TrustRegionMinimizer's loop: convergence checks, then a trust-region step and the
+// candidate pose.  Loops over invalid steps (they need no new evaluation).  On return either
+// s->running == 0 or s->cand holds the pose to evaluate next.
+EA_HD inline void lm_prepare_next(LMState *s, const LMOptions *o) {
+  for (;;) {
+    if (s->iteration >= o->max_num_iterations) { lm_finish(s, 1, 4); return; }
+    if (s->gradient_max_norm <= o->gradient_tolerance) { lm_finish(s, 0, 2); return; }
+    if (s->radius <= o->min_trust_region_radius) { lm_finish(s, 0, 5); return; }
+    s->iteration += 1;
+    double As[36], gs[6], step[6];
+    for (int a = 0; a < 6; ++a) {
+      gs[a] = s->g[a] * s->S[a];
+      for (int b = 0; b < 6; ++b) As[6 * a + b] = s->A[6 * a + b] * s->S[a] * s->S[b];
+    }
+    bool ok = lm_strategy_step(s, o, As, gs, step);
+    if (ok) {
+      // model_cost_change = -(Js s)^T (r + Js s / 2) = -(g^T s + s^T A s / 2)
+      double gts = 0.0, sAs = 0.0;
+      for (int a = 0; a < 6; ++a) {
+        gts += gs[a] * step[a];
+        for (int b = 0; b < 6; ++b) sAs += step[a] * As[6 * a + b] * step[b];
+      }
+      s->model_cost_change = -(gts + 0.5 * sAs);
+      if (!(s->model_cost_change > 0.0)) ok = false;
+    }
+    if (ok) {
+      double delta[6];
+      for (int i = 0; i < 6; ++i) delta[i] = step[i] * s->S[i];
+      pose_plus(s->x, delta, s->cand);
+      s->num_consecutive_invalid = 0;
+      return;
+    }
+    // HandleInvalidStep
+    s->num_unsuccessful += 1;
+    lm_trace(s, s->iteration, 0.0, 0.0, 0.0, 0);
+    if (++s->num_consecutive_invalid >= o->max_num_consecutive_invalid_steps) {
+      lm_finish(s, 2, 7);
+      return;
+    }
+    if (o->strategy == 0) { s->radius *= 0.5; s->reuse_diagonal = 1; }
+    else { s->mu *= 10.0; s->dl_reuse = 0; }
+  }
+}
+
+// after the evaluation at the initial pose
+EA_HD inline void lm_begin(LMState *s, const LMOptions *o, const double acc[kAccSlots]) {
+  s->num_evals += 1;
+  if (acc[kAccInvalid] > 0.0) { lm_finish(s, 2, 6); return; }
+  lm_take_system(s, acc);
+  if (o->jacobi_scaling)
+    for (int i = 0; i < 6; ++i) s->S[i] = 1.0 / (1.0 + sqrt(s->A[6 * i + i]));
+  lm_trace(s, 0, 0.0, 0.0, 0.0, 1);
+  lm_prepare_next(s, o);
+}
+
+// after the evaluation at s->cand
+EA_HD inline void lm_advance(LMState *s, const LMOptions *o, const double acc[kAccSlots]) {
+  s->num_evals += 1;
+  const bool eval_ok = !(acc[kAccInvalid] > 0.0);
+  const double cand_cost = eval_ok ? acc[kAccCost] : DBL_MAX;
+  double dx[7];
+  for (int i = 0; i < 7; ++i) dx[i] = s->x[i] - s->cand[i];
+  const double step_norm = norm_n(dx, 7);
+  if (step_norm <= o->parameter_tolerance * (s->x_norm + o->parameter_tolerance)) {
+    lm_trace(s, s->iteration, 0.0, step_norm, 0.0, 0);
+    lm_finish(s, 0, 3);
+    return;
+  }
+  const double cost_change = s->cost - cand_cost;
+  if (fabs(cost_change) <= o->function_tolerance * s->cost) {
+    lm_trace(s, s->iteration, cost_change, step_norm, 0.0, 0);
+    lm_finish(s, 0, 1);
+    return;
+  }
+  const double rel = cost_change / s->model_cost_change;
+  if (rel > o->min_relative_decrease) {
+    for (int i = 0; i < 7; ++i) s->x[i] = s->cand[i];
+    s->x_norm = norm_n(s->x, 7);
+    lm_take_system(s, acc);
+    s->num_successful += 1;
+    if (o->strategy == 0) {
+      const double f = 2.0 * rel - 1.0;
+      s->radius = s->radius / fmax(1.0 / 3.0, 1.0 - f * f * f);
+      s->radius = fmin(o->max_trust_region_radius, s->radius);
+      s->decrease_factor = 2.0;
+      s->reuse_diagonal = 0;
+    } else {
+      if (rel < 0.25) s->radius *= 0.5;
+      if (rel > 0.75) s->radius = fmax(s->radius, 3.0 * s->dogleg_step_norm);
+      s->radius = fmin(s->radius, o->max_trust_region_radius);
+      s->dl_reuse = 0;
+    }
+    lm_trace(s, s->iteration, cost_change, step_norm, rel, 1);
+  } else {
+    s->num_unsuccessful += 1;
+    if (o->strategy == 0) {
+      s->radius = s->radius / s->decrease_factor;
+      s->decrease_factor *= 2.0;
+      s->reuse_diagonal = 1;
+    } else {
+      s->radius *= 0.5;
+      s->dl_reuse = 1;
+    }
+    lm_trace(s, s->iteration, cost_change, step_norm, rel, 0);
+  }
+  lm_prepare_next(s, o);
+}
+
+}  // namespace ea

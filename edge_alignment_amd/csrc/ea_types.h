@@ -1,0 +1,68 @@
+// ea_types.h — structures shared by the host driver and the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define EA_HD __host__ __device__
+#else
+#define EA_HD
+#endif
+
+namespace ea {
+
+// accumulator slots of one fused evaluation (all fp64)
+//   0..20  JtJ upper triangle, row-major (a <= b)
+//  21..26  Jtr
+//  27      cost = 1/2 sum rho(r^2)
+//  28      number of blocks whose functor returned false
+//  29..31  spare (zero)
+constexpr int kAccJtJ = 0;
+constexpr int kAccJtr = 21;
+constexpr int kAccCost = 27;
+constexpr int kAccInvalid = 28;
+constexpr int kAccSlots = 32;
+
+constexpr int kImagePad = 3;      // replicated border texels on every side of the DT copy in HBM
+constexpr int kBlockThreads = 256;
+
+// One frame pair as the kernels see it.  Everything is in the problem dtype T (float/double).
+struct ProblemDesc {
+  const void *x, *y, *z;  // SoA edge points (frame A), n each
+  const void *dt;         // padded DT image: (H + 2*pad) rows x pitch, texel (v,u) at [(v+pad)*pitch + u+pad]
+  int32_t n;
+  int32_t W, H;           // u extent (Grid2D rows), v extent (Grid2D cols)
+  int32_t pitch;          // elements per padded row
+  double fx, fy, cx, cy;
+  double loss_a;
+  double z_guard, z_eps;
+  int32_t loss_kind;
+  int32_t rot_transposed;
+  int32_t tile_begin, tile_end;  // this problem's range in the tile list
+  int32_t pad_;
+};
+
+// A tile = a run of consecutive points of one problem handled by one workgroup.
+struct Tile {
+  int32_t problem;
+  int32_t start;  // first point
+  int32_t count;  // points in this tile
+  int32_t pad_;
+};
+
+// Pose-dependent constants, rebuilt whenever a pose changes (by the host for ea_eval, by the
+// device LM-step kernel inside ea_solve).  Uniform per problem -> scalar loads in the kernels.
+struct PoseState {
+  double q[4], t[3];
+  double R[9];       // rotation actually applied (already transposed for the ROS flavour)
+  double G[27];      // G[j] = d R / d delta_j, only read when unit_q == 0
+  int32_t unit_q;    // | |q|^2 - 1 | <= 1e-12  -> J_delta = 2 (R a) x g
+  int32_t active;    // 0: the problem's tiles return immediately (solve finished)
+};
+
+// Result of one reduced evaluation
+struct EvalOut {
+  double acc[kAccSlots];
+};
+
+}  // namespace ea

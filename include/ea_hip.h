@@ -1,0 +1,200 @@
+/*
+ * ea_hip.h — C-ABI of the MI355X-native edge-alignment hot path (libea_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of kuwt/edge_alignment: the per-edge-point
+ * EAResidue evaluation (SE(3) warp -> pinhole -> bicubic DT sample -> 1x6 Jacobian), the
+ * JtJ / Jtr / cost reduction, and the trust-region loop the reference hands to ceres::Solve.
+ * The reference has no FFI layer (it is a C++ source-level API on top of Ceres); each entry
+ * point below names the reference code it replaces (paths relative to the reference root).
+ * Host C++ shims that keep the reference's own spellings (EAResidue, SolveEA, a minimal
+ * ceres:: facade) sit on top of this header in edge_alignment_amd/include/.
+ *
+ * Conventions
+ *   - plain C types only; every function returns an ea_status (0 = ok, < 0 = error) and
+ *     never throws.  ea_last_error() gives a thread-local message for the last failure.
+ *   - poses are q = (w,x,y,z), t = (tx,ty,tz), b_T_a (maps frame-A points into frame B),
+ *     exactly the raw arrays of PoseManipUtils::eigenmat_to_raw
+ *     (standalone/PoseManipUtils.cpp:16-27); ea_solve updates them in place like ceres::Solve.
+ *   - host buffers handed to ea_problem_set_* are copied to HBM before the call returns and
+ *     may be freed afterwards (the reference's Grid2D merely borrows, utils.h:95).
+ *   - a handle is not thread-safe; use one handle per host thread / per GPU.
+ *   - there is NO CPU fallback: every compute entry point fails with EA_ERR_NO_DEVICE when
+ *     no gfx950 device is usable.
+ */
+#ifndef EA_HIP_H
+#define EA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  EA_OK = 0,
+  EA_ERR_INVALID_ARG = -1,
+  EA_ERR_HIP = -2,
+  EA_ERR_NO_DEVICE = -3,
+  EA_ERR_STATE = -4,
+  EA_ERR_ALLOC = -5
+} ea_status;
+
+/* arithmetic type of the per-point evaluation (reductions are always fp64) */
+typedef enum { EA_F64 = 0, EA_F32 = 1 } ea_dtype;
+
+/* ceres::TrivialLoss / CauchyLoss(a) / HuberLoss(a)
+ * (standalone_edge_align.cpp:272, :2604; src/SolveEA.cpp:144) */
+typedef enum { EA_LOSS_TRIVIAL = 0, EA_LOSS_CAUCHY = 1, EA_LOSS_HUBER = 2 } ea_loss_kind;
+
+/* ceres::TerminationType as far as this path can produce it */
+typedef enum { EA_CONVERGENCE = 0, EA_NO_CONVERGENCE = 1, EA_FAILURE = 2 } ea_termination;
+
+typedef enum {
+  EA_WHY_NONE = 0,
+  EA_WHY_FUNCTION_TOL = 1,
+  EA_WHY_GRADIENT_TOL = 2,
+  EA_WHY_PARAMETER_TOL = 3,
+  EA_WHY_MAX_ITERATIONS = 4,
+  EA_WHY_MIN_RADIUS = 5,
+  EA_WHY_INITIAL_EVAL_FAILED = 6,     /* a functor returned false at the start (utils.h:70-73) */
+  EA_WHY_TOO_MANY_INVALID_STEPS = 7,
+  EA_WHY_EVAL_FAILED = 8
+} ea_why;
+
+typedef enum { EA_STRATEGY_LM = 0, EA_STRATEGY_DOGLEG = 1 } ea_strategy;
+
+/* pinhole intrinsics, the four doubles every EAResidue carries (utils.h:41-44,96) */
+typedef struct {
+  double fx, fy, cx, cy;
+} ea_camera;
+
+/* the fields of ceres::Solver::Options the reference touches or relies on by default
+ * (standalone_edge_align.cpp:282-284, :2112-2116; src/SolveEA.cpp:184-192) */
+typedef struct {
+  int max_num_iterations;             /* 50 */
+  double function_tolerance;          /* 1e-6 */
+  double gradient_tolerance;          /* 1e-10 */
+  double parameter_tolerance;         /* 1e-8 */
+  double initial_trust_region_radius; /* 1e4 */
+  double max_trust_region_radius;     /* 1e16 */
+  double min_trust_region_radius;     /* 1e-32 */
+  double min_relative_decrease;       /* 1e-3 */
+  double min_lm_diagonal;             /* 1e-6 */
+  double max_lm_diagonal;             /* 1e32 */
+  int max_num_consecutive_invalid_steps; /* 5 */
+  int jacobi_scaling;                 /* 1 */
+  int strategy;                       /* EA_STRATEGY_LM (LEVENBERG_MARQUARDT) | EA_STRATEGY_DOGLEG */
+  int minimizer_progress_to_stdout;   /* 0 */
+  int iterations_per_sync;            /* device LM iterations enqueued between host checks; 0 = default */
+} ea_options;
+
+#define EA_MAX_TRACE 128
+
+/* what the drivers read back from ceres::Solver::Summary (FullReport(), :293) */
+typedef struct {
+  int termination;  /* ea_termination */
+  int why;          /* ea_why */
+  int num_iterations;          /* successful + unsuccessful steps (+1 if the last one ended the solve) */
+  int num_successful_steps;
+  int num_unsuccessful_steps;
+  double initial_cost, final_cost;
+  int64_t num_point_evals;     /* edge-point residual+Jacobian evaluations performed */
+  double total_time_ms;        /* host wall time of the call */
+  /* per-iteration trace, entries [0 .. min(num_iterations, EA_MAX_TRACE-1)] */
+  double it_cost[EA_MAX_TRACE];
+  double it_cost_change[EA_MAX_TRACE];
+  double it_gradient_max_norm[EA_MAX_TRACE];
+  double it_step_norm[EA_MAX_TRACE];
+  double it_relative_decrease[EA_MAX_TRACE];
+  double it_radius[EA_MAX_TRACE];
+  int it_successful[EA_MAX_TRACE];
+} ea_summary;
+
+typedef struct ea_problem ea_problem; /* one frame pair: edge points of A + DT image of B */
+typedef struct ea_batch ea_batch;     /* several problems evaluated / solved by the same launches */
+
+/* ---- library ------------------------------------------------------------------------- */
+const char *ea_last_error(void);
+const char *ea_version(void);
+int ea_device_count(int *count);            /* number of gfx950 devices visible */
+void ea_default_options(ea_options *opt);   /* ceres::Solver::Options() defaults used by test1 */
+
+/* ---- problem = ceres::Problem filled by the loop at standalone_edge_align.cpp:264-278 --- */
+int ea_problem_create(ea_problem **out, const ea_camera *cam, int dtype, int device);
+void ea_problem_destroy(ea_problem *p);
+
+/* Edge points, replacing the N `EAResidue::Create(fx,fy,cx,cy, X,Y,Z, interp)` +
+ * `AddResidualBlock` calls (standalone_edge_align.cpp:267-274; src/SolveEA.cpp:163-175).
+ * xyz: host, point i at xyz[i*stride_elems + {0,1,2}] — stride 4 for the 4xN column-major
+ * a_X of get_aX (utils.cpp:268-280) or 3 for list_edge_ref (SolveEA.cpp:55).  Converted once
+ * to SoA x[],y[],z[] of the problem dtype in HBM. */
+int ea_problem_set_points(ea_problem *p, const double *xyz, int64_t n, int64_t stride_elems);
+/* same, from SoA arrays of the problem's dtype already resident in HBM (borrowed, must
+ * outlive the problem) */
+int ea_problem_set_points_device(ea_problem *p, const void *x, const void *y, const void *z,
+                                 int64_t n);
+
+/* Distance-transform image, replacing
+ *   ceres::Grid2D<double,1> grid(data, 0, grid_rows, 0, grid_cols);
+ *   ceres::BiCubicInterpolator<...> interp(grid);        (standalone_edge_align.cpp:258-259)
+ * data: host, row-major, value(r,c) = data[r*grid_cols + c]; the functor samples it at
+ * (r = u, c = v) (utils.h:77), so grid_rows is the u extent (image width) and grid_cols the
+ * v extent (image height) exactly as the reference passes e_disTrans.cols()/rows(). */
+int ea_problem_set_dt(ea_problem *p, const double *data, int grid_rows, int grid_cols);
+/* same, from an image already in HBM: row-major [height][width] (u contiguous) of the problem's
+ * dtype; copied into the library's padded layout by a device kernel */
+int ea_problem_set_dt_image_device(ea_problem *p, const void *image, int height, int width);
+
+/* loss_function argument of AddResidualBlock (:272 `new CauchyLoss(1.)`) */
+int ea_problem_set_loss(ea_problem *p, int loss_kind, double a);
+/* functor flavour: standalone (utils.h:48-80) = {z_guard 0.01, z_eps 0, rot_transposed 0}
+ * [default]; ROS flavour (include/EAResidue.h:86-118) = {0, 0.001, 1} */
+int ea_problem_set_flavour(ea_problem *p, double z_guard, double z_eps, int rot_transposed);
+int64_t ea_problem_num_points(const ea_problem *p);
+
+/* One evaluation of the whole problem at pose (q,t) — what ceres' evaluator computes from the
+ * N AutoDiffCostFunction<EAResidue,1,4,3> blocks + QuaternionParameterization + loss:
+ *   cost = 1/2 sum rho(r_i^2);  JtJ (6x6 row-major) and Jtr (6) of the loss-corrected 1x6 rows
+ *   in the tangent ordering [delta(3) | t(3)];  n_invalid = blocks whose functor returned false
+ *   (sums then cover the valid blocks only).  Any output pointer may be NULL. */
+int ea_eval(ea_problem *p, const double q[4], const double t[3], double *cost, double JtJ[36],
+            double Jtr[6], int64_t *n_invalid);
+/* per-point outputs (host, n and n*6 row-major; NaN for failed blocks).  corrected != 0:
+ * sqrt(rho') r and sqrt(rho') J as handed to the minimiser; 0: raw r_i and raw row. */
+int ea_eval_points(ea_problem *p, const double q[4], const double t[3], double *r, double *J,
+                   int corrected);
+/* residual-only evaluation (the candidate-cost evaluation inside the trust-region loop) */
+int ea_cost(ea_problem *p, const double q[4], const double t[3], double *cost,
+            int64_t *n_invalid);
+
+/* ceres::Solve(options, &problem, &summary) (standalone_edge_align.cpp:286; SolveEA.cpp:198).
+ * q,t in/out.  The whole trust-region loop runs on the device. */
+int ea_solve(ea_problem *p, const ea_options *opt, double q[4], double t[3], ea_summary *summary);
+
+/* ---- batches of independent frame pairs (one launch sequence for all of them) --------- */
+int ea_batch_create(ea_batch **out, ea_problem *const *problems, int count);
+void ea_batch_destroy(ea_batch *b);
+int ea_batch_count(const ea_batch *b);
+/* q: count x 4, t: count x 3, cost: count, JtJ: count x 36, Jtr: count x 6, n_invalid: count */
+int ea_batch_eval(ea_batch *b, const double *q, const double *t, double *cost, double *JtJ,
+                  double *Jtr, int64_t *n_invalid);
+int ea_batch_solve(ea_batch *b, const ea_options *opt, double *q, double *t,
+                   ea_summary *summaries);
+
+/* ---- measurement hooks (used by bench.py; timing is done with HIP events on the stream the
+ * kernels are launched on) ------------------------------------------------------------- */
+/* Upload the poses once, run `warmup` untimed then `steps` timed fused evaluations
+ * (residual + Jacobian + JtJ/Jtr/cost reduction) back to back with the inputs resident in HBM.
+ * ms_total: event time over the timed region; ms_eval_kernel: average duration of the
+ * dominant per-point kernel alone (events around each launch in a second pass). */
+int ea_batch_bench_eval(ea_batch *b, const double *q, const double *t, int warmup, int steps,
+                        double *ms_total, double *ms_eval_kernel);
+/* tuning knobs: key in {"lds_bytes", "points_per_thread", "use_lds", "xcd_remap"}; value < 0
+ * restores the default */
+int ea_batch_set_tuning(ea_batch *b, const char *key, int value);
+int ea_batch_get_info(const ea_batch *b, const char *key, int64_t *value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EA_HIP_H */

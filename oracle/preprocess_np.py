@@ -1,0 +1,155 @@
+"""numpy restatement of the reference's CPU pre-processing that PRODUCES the hot path's inputs.
+
+TEST INFRASTRUCTURE ONLY — PARITY UNPINNED except for one number: `get_aX` on the bundled frame 1
+yields 44 457 edge points, i.e. ceil(44457/30) = 1482 residual blocks, the count in the
+reference's only recorded log (standalone/README.md:34).  tests/test_preprocess_oracle.py holds
+that check.
+
+Follows (ref = /root/reference):
+  get_aX                  ref: standalone/utils.cpp:201-281
+  get_distance_transform  ref: standalone/utils.cpp:38-83
+and the published OpenCV 3 algorithms those call (OpenCV is absent from this image):
+  GaussianBlur 3x3 sigma=0 on 8-bit  -> [1 2 1]x[1 2 1]/16, fixed point, round-half-up, reflect-101
+  cvtColor CV_RGB2GRAY on 8-bit      -> (4899*c0 + 9617*c1 + 1868*c2 + 8192) >> 14  (c0 is really
+                                        blue: imread returns BGR, the code says RGB — utils.cpp:51,216)
+  Laplacian CV_16S ksize=3           -> [[2,0,2],[0,-8,0],[2,0,2]], reflect-101
+  convertScaleAbs                    -> min(|x|, 255)
+  medianBlur 3                       -> 3x3 median, replicate border
+  distanceTransform(DIST_L2, 3)      -> two-pass 3x3 chamfer, a=0.955 b=1.3693 in 16.16 fixed point
+  normalize(NORM_MINMAX, 0, 1)       -> float32  src*scale + shift
+"""
+import numpy as np
+
+
+def load_rgb_as_bgr(path):
+    """cv::imread(path) equivalent for an 8-bit colour PNG: HxWx3 uint8 in B,G,R order."""
+    from PIL import Image
+    im = np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8)
+    return im[:, :, ::-1].copy()
+
+
+def load_depth_u16(path):
+    """cv::imread(path, CV_LOAD_IMAGE_ANYDEPTH) for the TUM 16-bit depth PNG."""
+    from PIL import Image
+    im = Image.open(path)
+    a = np.asarray(im)
+    return a.astype(np.uint16)
+
+
+def _pad_reflect101(a, n=1):
+    return np.pad(a, ((n, n), (n, n)) + ((0, 0),) * (a.ndim - 2), mode="reflect")
+
+
+def gaussian_blur3_u8(img):
+    """cv::GaussianBlur(img, Size(3,3), 0, 0, BORDER_DEFAULT) on CV_8UC3 / CV_8UC1."""
+    a = _pad_reflect101(img.astype(np.int32))
+    h = a[:, :-2] + 2 * a[:, 1:-1] + a[:, 2:]
+    v = h[:-2] + 2 * h[1:-1] + h[2:]
+    return ((v + 8) >> 4).astype(np.uint8)
+
+
+def rgb2gray_u8(img3):
+    """cv::cvtColor(img, CV_RGB2GRAY) applied to whatever is in channels 0,1,2."""
+    c = img3.astype(np.int64)
+    return ((4899 * c[:, :, 0] + 9617 * c[:, :, 1] + 1868 * c[:, :, 2] + 8192) >> 14).astype(np.uint8)
+
+
+def laplacian3_abs_u8(gray):
+    """cv::Laplacian(gray, CV_16S, 3, 1, 0, BORDER_DEFAULT) then cv::convertScaleAbs."""
+    a = _pad_reflect101(gray.astype(np.int32))
+    lap = 2 * (a[:-2, :-2] + a[:-2, 2:] + a[2:, :-2] + a[2:, 2:]) - 8 * a[1:-1, 1:-1]
+    return np.minimum(np.abs(lap), 255).astype(np.uint8)
+
+
+def edge_strength(img_bgr):
+    """The gradient map both get_aX and get_distance_transform threshold at > 35."""
+    return laplacian3_abs_u8(rgb2gray_u8(gaussian_blur3_u8(img_bgr)))
+
+
+def get_aX(img_bgr, depth_u16, fx, fy, cx, cy, z_scaling=5000.0, threshold=35):
+    """ref: utils.cpp:201-281.  Returns (a_X 4xN float64 in raster order, (v,u) index arrays)."""
+    grad = edge_strength(img_bgr)
+    H, W = grad.shape
+    Z = depth_u16.astype(np.float64) / float(z_scaling)
+    u = np.arange(W, dtype=np.float64)[None, :]
+    v = np.arange(H, dtype=np.float64)[:, None]
+    X = (u - cx) * Z / fx
+    Y = (v - cy) * Z / fy
+    keep = (grad.astype(np.float64) > threshold) & (Z > 0)
+    vv, uu = np.nonzero(keep)  # raster order: v outer, u inner
+    a_X = np.stack([X[vv, uu], Y[vv, uu], Z[vv, uu], np.ones(vv.size)], axis=0)
+    return a_X, (vv, uu)
+
+
+def median_blur3_u8(img):
+    """cv::medianBlur(img, 3) on CV_8UC1 (replicate border)."""
+    a = np.pad(img, 1, mode="edge")
+    H, W = img.shape
+    stack = np.stack([a[i:i + H, j:j + W] for i in range(3) for j in range(3)], axis=0)
+    return np.sort(stack, axis=0)[4].astype(np.uint8)
+
+
+HV_DIST = int(round(0.955 * 65536))     # CV_FLT_TO_FIX(0.955f, 16)
+DIAG_DIST = int(round(1.3693 * 65536))  # CV_FLT_TO_FIX(1.3693f, 16)
+_DIST_MAX = (1 << 31) // 2 - 1          # INT_MAX >> 1 scale guard
+
+
+def _row_scan(c, step, reverse=False):
+    """t[j] = min(c[j], t[j-1] + step) along the last axis (min-plus scan), vectorised."""
+    if reverse:
+        return _row_scan(c[..., ::-1], step)[..., ::-1]
+    k = np.arange(c.shape[-1], dtype=np.int64) * step
+    return np.minimum.accumulate(c - k, axis=-1) + k
+
+
+def chamfer3x3_fixed(zero_mask):
+    """cv::distanceTransform(src, DIST_L2, 3) core: src==0 pixels are sources.
+    Returns int64 distances in 16.16 fixed point."""
+    H, W = zero_mask.shape
+    BIG = np.int64(_DIST_MAX)
+    t = np.full((H + 2, W + 2), BIG, dtype=np.int64)
+    # forward pass
+    for i in range(1, H + 1):
+        up = t[i - 1]
+        c = np.minimum(np.minimum(up[:-2] + DIAG_DIST, up[1:-1] + HV_DIST), up[2:] + DIAG_DIST)
+        c = np.where(zero_mask[i - 1], 0, c)
+        # the left neighbour of column 1 is the border (BIG): the scan starts from c
+        row = _row_scan(c, HV_DIST)
+        row = np.where(zero_mask[i - 1], 0, row)
+        t[i, 1:-1] = np.minimum(row, BIG)
+    # backward pass
+    for i in range(H, 0, -1):
+        dn = t[i + 1]
+        c = np.minimum(np.minimum(dn[2:] + DIAG_DIST, dn[1:-1] + HV_DIST), dn[:-2] + DIAG_DIST)
+        c = np.minimum(c, t[i, 1:-1])
+        row = _row_scan(c, HV_DIST, reverse=True)
+        t[i, 1:-1] = np.minimum(row, BIG)
+    return t[1:-1, 1:-1]
+
+
+def distance_transform_l2_3(src_u8):
+    d = chamfer3x3_fixed(src_u8 == 0)
+    return (d.astype(np.float64) * (1.0 / 65536.0)).astype(np.float32)
+
+
+def normalize_minmax_f32(dist, lo=0.0, hi=1.0):
+    smin, smax = float(dist.min()), float(dist.max())
+    scale = (hi - lo) * (1.0 / (smax - smin) if (smax - smin) > np.finfo(np.float64).eps else 0.0)
+    shift = lo - smin * scale
+    return (dist * np.float32(scale) + np.float32(shift)).astype(np.float32)
+
+
+def get_distance_transform(img_bgr, threshold=35, normalize=True):
+    """ref: utils.cpp:38-83.  Returns HxW float32 in [0,1]."""
+    lap = edge_strength(img_bgr)
+    B = np.where(lap > threshold, 0, 255).astype(np.uint8)
+    Bf = median_blur3_u8(B)
+    dist = distance_transform_l2_3(Bf)
+    return normalize_minmax_f32(dist) if normalize else dist
+
+
+def grid_view_of_image(dt_hw):
+    """What `ceres::Grid2D<double,1> grid(e.data(), 0, e.cols(), 0, e.rows())` sees after
+    cv::cv2eigen into a column-major Eigen::MatrixXd (standalone_edge_align.cpp:205-206,258):
+    a row-major array with num_rows = W (u), num_cols = H (v), value(r,c) = DT[v=c, u=r]."""
+    return np.ascontiguousarray(dt_hw.astype(np.float64).T)
