@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — edge-point residual+Jacobian evaluations per second on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one frame pair's edge cloud with the inputs already
+resident in HBM: the fused per-point kernel (SE(3) warp, pinhole, bicubic DT sample, analytic 1x6
+row, IRLS weight, JtJ/Jtr/cost partials) plus the fixed-order fold of the partials — exactly what
+one evaluation inside the trust-region loop costs.  Default workload = BASELINE.json configs[1]
+(C2): single 640x480 frame pair, 5e4 edge points, fp64.  With N GPUs every rank evaluates its own
+independent frame pair (weak scaling, no data-path collective); the one collective is the pose
+all-gather (RCCL) after the per-rank LM solves, reported separately.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_workload(name, seed_offset):
+    from edge_alignment_amd import capi, synth
+    if name == "c2":
+        cfg = synth.config_c2_twin(seed=2 + seed_offset, n_points=50000)
+        dtype, tag, loss = capi.EA_F64, "f64", (capi.LOSS_CAUCHY, 1.0)
+        desc = "c2: single 640x480 frame pair, 50000 edge points, fp64, CauchyLoss(1)"
+    elif name == "c5":
+        cfg = synth.config_c5(seed=5 + seed_offset, n_points=1000000)
+        dtype, tag, loss = capi.EA_F32, "f32", (capi.LOSS_TRIVIAL, 1.0)
+        desc = "c5: 1e6-point edge cloud into a 2048x1536 DT image, fp32 (fp64 accumulation)"
+    elif name == "lm1e5":
+        cfg = synth.config_c2_twin(seed=7 + seed_offset, n_points=100000)
+        dtype, tag, loss = capi.EA_F64, "f64", (capi.LOSS_CAUCHY, 1.0)
+        desc = "lm1e5: 640x480 frame pair, 1e5 edge points, fp64"
+    else:
+        raise ValueError(name)
+    return cfg, dtype, tag, loss, desc
+
+
+def algorithmic_bytes(n_points, H, W, esize):
+    """Fused mode: 3*s per point + the DT image once per launch."""
+    return 3 * esize * n_points + H * W * esize
+
+
+def cpu_baseline(cfg, loss, budget_s=12.0):
+    """The oracle's Ceres-style path (Jet<7> autodiff of the functor + local parameterisation +
+    loss correction + normal-equation accumulation) on ONE host core, on a bounded sample of the
+    same workload."""
+    from oracle import ea_oracle as eo
+    O = eo.OracleProblem(cfg["grid"], *cfg["K"], loss=loss[0], loss_a=loss[1])
+    n = min(cfg["xyz"].shape[0], 50000)
+    X = np.ascontiguousarray(cfg["xyz"][:n])
+    q, t = np.array([1.0, 0, 0, 0]), np.zeros(3)
+    O.eval(X, q, t, eo.JAC_JET)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        O.eval(X, q, t, eo.JAC_JET)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s:
+            break
+    return {"value": n * reps / el, "unit": "evals/s", "cores": 1, "kind": "port",
+            "sample": "%d passes over the first %d points of the same cloud, Jet<7> autodiff (Ceres-style) "
+                      "fp64, %.1f s" % (reps, n, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c5"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+
+    import torch  # plumbing only: process group (RCCL), barriers, device sync
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+
+    from edge_alignment_amd import capi
+    from edge_alignment_amd import dist as ead
+    if capi.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X (gfx950): " + capi.load().ea_last_error().decode())
+
+    def barrier_sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    cfg, dtype, tag, loss, desc = build_workload(args.workload, rank)
+    P = capi.Problem(*cfg["K"], dtype=dtype, device=local_rank)
+    P.set_points(cfg["xyz"])
+    P.set_dt_grid(cfg["grid"])
+    P.set_loss(*loss)
+    B = capi.Batch([P])
+    n_pts = P.num_points
+    H, W = cfg["image"].shape
+    esize = 8 if dtype == capi.EA_F64 else 4
+    q0, t0 = np.array([1.0, 0, 0, 0]), np.zeros(3)
+
+    # warm-up (untimed), then EXACTLY K timed steps between barrier+sync brackets
+    if args.warmup > 0:
+        B.bench_eval(q0, t0, 0, args.warmup, kernel_pass=False)
+    barrier_sync()
+    t_start = time.perf_counter()
+    B.bench_eval(q0, t0, 0, args.steps, kernel_pass=False)  # K x (fused eval + fold), then stream sync
+    barrier_sync()
+    elapsed = time.perf_counter() - t_start
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    value = world * n_pts * args.steps / elapsed
+
+    # per-launch duration of the dominant kernel (HIP events on the library's stream)
+    _, ms_kernel = B.bench_eval(q0, t0, 2, min(args.steps, 64))
+    bytes_launch = algorithmic_bytes(n_pts, H, W, esize)
+    achieved = bytes_launch / (ms_kernel * 1e-3) / 1e9
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get(args.workload, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "ea_eval_fused_kernel<%s>" % ("double" if esize == 8 else "float"),
+                "kernel_ms": ms_kernel, "algorithmic_bytes_per_launch": bytes_launch}
+
+    extras = {}
+    if not args.no_extras:
+        # LM iterations/s at 1e5 points (second headline of BASELINE.json), device-resident loop
+        cfg2, dt2, _, loss2, _ = build_workload("lm1e5", rank)
+        P2 = capi.Problem(*cfg2["K"], dtype=dt2, device=local_rank)
+        P2.set_points(cfg2["xyz"]); P2.set_dt_grid(cfg2["grid"]); P2.set_loss(*loss2)
+        P2.solve(q0, t0)
+        barrier_sync()
+        ts = time.perf_counter()
+        reps, its = 5, 0
+        for _ in range(reps):
+            q, t, s = P2.solve(q0, t0)
+            its += s["num_iterations"]
+        torch.cuda.synchronize()
+        el = time.perf_counter() - ts
+        lm_local = its / el
+        # the one collective: all-gather of the solved poses (7 doubles + status per problem)
+        tg = time.perf_counter()
+        qa, ta, st = ead.gather_poses([q], [t], [s["termination"]], world, rank, world,
+                                      device="cuda" if world > 1 else "cpu")
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        if dist is not None:
+            tt = torch.tensor([lm_local], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            lm_total = float(tt.item())
+        else:
+            lm_total = lm_local
+        from edge_alignment_amd import synth
+        err_rot = synth.rotation_angle_between(q, cfg2["q_true"])
+        err_t = float(np.linalg.norm(t - cfg2["t_true"]))
+        extras = {"lm_iters_per_s_at_1e5_pts": lm_total, "lm_iterations_per_solve": its / reps,
+                  "lm_solve_ms": el / reps * 1e3, "pose_gather_ms": gather_ms,
+                  "lm_pose_err_vs_planted": {"rad": err_rot, "m": err_t}}
+        P2.close()
+
+    out = None
+    if rank == 0:
+        out = {"metric": "edge-point residual+Jacobian evals/sec", "value": value, "unit": "evals/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": tag, "data": "synthetic",
+               "config": {"workload": desc, "points_per_gpu": int(n_pts), "dt_image": "%dx%d" % (W, H),
+                          "parallelism": "independent frame pairs, one per GPU; single RCCL pose all-gather",
+                          "tiles": B.info("num_tiles"), "points_per_thread": B.info("points_per_thread"),
+                          "lds_bytes": B.info("lds_bytes")},
+               "roofline": roofline}
+        out.update(extras)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, loss)
+        else:
+            out["cpu_baseline"] = None
+    B.close()
+    P.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -281,12 +281,13 @@ class Batch:
         _check(load().ea_batch_solve(self._h, C.byref(o), _dp(q), _dp(t), s))
         return q, t, [summary_to_dict(x) for x in s]
 
-    def bench_eval(self, q, t, warmup, steps):
+    def bench_eval(self, q, t, warmup, steps, kernel_pass=True):
+        """(ms over `steps` fused evaluations, mean ms of the per-point kernel alone | None)"""
         q, t = _f64(q).reshape(-1, 4), _f64(t).reshape(-1, 3)
         ms_total, ms_kernel = C.c_double(), C.c_double()
-        _check(load().ea_batch_bench_eval(self._h, _dp(q), _dp(t), warmup, steps,
-                                          C.byref(ms_total), C.byref(ms_kernel)))
-        return ms_total.value, ms_kernel.value
+        _check(load().ea_batch_bench_eval(self._h, _dp(q), _dp(t), warmup, steps, C.byref(ms_total),
+                                          C.byref(ms_kernel) if kernel_pass else None))
+        return ms_total.value, (ms_kernel.value if kernel_pass else None)
 
     def set_tuning(self, key, value):
         _check(load().ea_batch_set_tuning(self._h, key.encode(), int(value)))

@@ -16,15 +16,16 @@
 #include "ea_types.h"
 
 namespace ea {
-hipError_t launch_eval_fused(int dtype, int ppt, const ProblemDesc *probs, const Tile *tiles, int ntiles,
-                             int xcd_remap, const PoseState *poses, double *partials, int lds_bytes,
-                             hipStream_t stream);
+hipError_t launch_eval_fused(int dtype, int ppt, int nt, const ProblemDesc *probs, int count, int chunk,
+                             int max_chunks, int xcd_remap, const PoseState *poses, double *partials,
+                             int lds_bytes, hipStream_t stream);
 hipError_t launch_eval_points(int dtype, const ProblemDesc *probs, int problem, int n, const PoseState *poses,
                               double *r_out, double *J_out, int corrected, hipStream_t stream);
 hipError_t launch_reduce(const ProblemDesc *probs, int count, const double *partials, EvalOut *out,
                          hipStream_t stream);
 hipError_t launch_lm_step(const ProblemDesc *probs, int count, const double *partials, PoseState *poses,
-                          LMState *states, const LMOptions &opt, int *running_flags, hipStream_t stream);
+                          LMState *states, LMTrace *traces, const LMOptions &opt, int *running_flags,
+                          hipStream_t stream);
 hipError_t launch_pad_image(int dtype, const void *src, int H, int W, void *dst, int pitch, hipStream_t stream);
 }  // namespace ea
 
@@ -71,21 +72,23 @@ struct ea_batch {
   bool own_stream = false;
   // device
   ProblemDesc *d_probs = nullptr;
-  Tile *d_tiles = nullptr;
-  int ntiles = 0, tiles_cap = 0;
+  int ntiles = 0, tiles_cap = 0;  // rows of the partial-sum array (one per workgroup with work)
+  int chunk = 256, max_chunks = 0; // points per workgroup; largest per-problem workgroup count
   PoseState *d_poses = nullptr;
   double *d_partials = nullptr;
   EvalOut *d_out = nullptr;
   LMState *d_states = nullptr;
+  LMTrace *d_traces = nullptr;
   int *d_running = nullptr;
   // pinned host mirrors
   PoseState *h_poses = nullptr;
   EvalOut *h_out = nullptr;
   LMState *h_states = nullptr;
+  LMTrace *h_traces = nullptr;
   int *h_running = nullptr;
   // tuning (-1 = heuristic)
-  int t_lds_bytes = -1, t_ppt = -1, t_use_lds = -1, t_xcd = -1;
-  int ppt = 1, lds_bytes = 0, xcd_remap = 1;
+  int t_lds_bytes = -1, t_ppt = -1, t_use_lds = -1, t_xcd = -1, t_nt = -1;
+  int ppt = 1, nt = 256, lds_bytes = 0, xcd_remap = 1;
   bool built = false;
 };
 
@@ -287,12 +290,13 @@ extern "C" int ea_problem_set_flavour(ea_problem *p, double z_guard, double z_ep
 // ---- batch --------------------------------------------------------------------------------------
 
 static void batch_free_device(ea_batch *b) {
-  (void)hipFree(b->d_probs); (void)hipFree(b->d_tiles); (void)hipFree(b->d_poses);
+  (void)hipFree(b->d_probs); (void)hipFree(b->d_poses); (void)hipFree(b->d_traces);
   (void)hipFree(b->d_partials); (void)hipFree(b->d_out); (void)hipFree(b->d_states); (void)hipFree(b->d_running);
-  (void)hipHostFree(b->h_poses); (void)hipHostFree(b->h_out); (void)hipHostFree(b->h_states); (void)hipHostFree(b->h_running);
-  b->d_probs = nullptr; b->d_tiles = nullptr; b->d_poses = nullptr; b->d_partials = nullptr;
+  (void)hipHostFree(b->h_poses); (void)hipHostFree(b->h_out); (void)hipHostFree(b->h_states);
+  (void)hipHostFree(b->h_traces); (void)hipHostFree(b->h_running);
+  b->d_probs = nullptr; b->d_poses = nullptr; b->d_partials = nullptr; b->d_traces = nullptr;
   b->d_out = nullptr; b->d_states = nullptr; b->d_running = nullptr;
-  b->h_poses = nullptr; b->h_out = nullptr; b->h_states = nullptr; b->h_running = nullptr;
+  b->h_poses = nullptr; b->h_out = nullptr; b->h_states = nullptr; b->h_traces = nullptr; b->h_running = nullptr;
 }
 
 extern "C" int ea_batch_create(ea_batch **out, ea_problem *const *problems, int count) {
@@ -317,10 +321,12 @@ extern "C" int ea_batch_create(ea_batch **out, ea_problem *const *problems, int 
   if (e == hipSuccess) e = hipMalloc(&b->d_poses, c * sizeof(PoseState));
   if (e == hipSuccess) e = hipMalloc(&b->d_out, c * sizeof(EvalOut));
   if (e == hipSuccess) e = hipMalloc(&b->d_states, c * sizeof(LMState));
+  if (e == hipSuccess) e = hipMalloc(&b->d_traces, c * sizeof(LMTrace));
   if (e == hipSuccess) e = hipMalloc(&b->d_running, c * sizeof(int));
   if (e == hipSuccess) e = hipHostMalloc(&b->h_poses, c * sizeof(PoseState));
   if (e == hipSuccess) e = hipHostMalloc(&b->h_out, c * sizeof(EvalOut));
   if (e == hipSuccess) e = hipHostMalloc(&b->h_states, c * sizeof(LMState));
+  if (e == hipSuccess) e = hipHostMalloc(&b->h_traces, c * sizeof(LMTrace));
   if (e == hipSuccess) e = hipHostMalloc(&b->h_running, c * sizeof(int));
   if (e != hipSuccess) {
     batch_free_device(b);
@@ -358,16 +364,28 @@ static int batch_build(ea_batch *b) {
     if (p->n > 0 && !p->d_x) return fail(EA_ERR_STATE, "edge points not set (ea_problem_set_points)");
     total += p->n;
   }
-  // points per thread: keep >= ~1024 workgroups (4 per CU) in flight when the batch is large enough
+  // Workgroup sizing.  nt = threads per workgroup (256, or 1024 = one workgroup per CU), ppt =
+  // points per lane; a workgroup owns chunk = nt*ppt consecutive points and emits one partial row.
+  // Small problems are latency-bound: one point per lane and as many waves as possible.  Large
+  // ones take 1024-thread workgroups so that the partial rows to fold stay in the hundreds.
+  // (measured on MI355X, profiles/r01_sweep.txt): fp32 single problems >= 2.5e5 points take
+  // 1024-thread workgroups with two points per lane (fewer partial rows to fold); fp64 and batches of
+  // mid-size problems take 256-thread workgroups, two points per lane once the batch is large.
+  int64_t max_n = 0;
+  for (ea_problem *p : b->probs) max_n = std::max<int64_t>(max_n, p->n);
+  const bool big_f32 = b->dtype == EA_F32 && max_n >= 250000;
+  int nt = (b->t_nt == 1024 || b->t_nt == 256) ? b->t_nt : (big_f32 ? 1024 : 256);
   int ppt = b->t_ppt;
-  if (ppt != 1 && ppt != 2 && ppt != 4) {
-    const int64_t per = total / ((int64_t)kBlockThreads * 1024);
-    ppt = per >= 4 ? 4 : (per >= 2 ? 2 : 1);
-  }
+  if (ppt != 1 && ppt != 2 && ppt != 4)
+    ppt = b->dtype == EA_F32 ? ((big_f32 || total >= 1000000) ? 2 : 1) : (total >= 300000 ? 2 : 1);
+  if (nt == 1024) ppt = b->dtype == EA_F32 ? std::min(ppt, 2) : 1;  // 128-VGPR budget at 16 waves/CU
+  if (b->dtype == EA_F64 && ppt > 2) ppt = 2;
   b->ppt = ppt;
-  const int chunk = kBlockThreads * ppt;
+  b->nt = nt;
+  const int64_t chunk = (int64_t)nt * ppt;
+  b->chunk = (int)chunk;
   std::vector<ProblemDesc> descs(b->probs.size());
-  std::vector<Tile> tiles;
+  int rows = 0, max_chunks = 0;
   for (size_t i = 0; i < b->probs.size(); ++i) {
     ea_problem *p = b->probs[i];
     ProblemDesc &d = descs[i];
@@ -376,30 +394,28 @@ static int batch_build(ea_batch *b) {
     d.n = (int32_t)p->n; d.W = p->W; d.H = p->H; d.pitch = p->pitch;
     d.fx = p->cam.fx; d.fy = p->cam.fy; d.cx = p->cam.cx; d.cy = p->cam.cy;
     d.loss_a = p->loss_a; d.z_guard = p->z_guard; d.z_eps = p->z_eps;
+    d.fxf = (float)d.fx; d.fyf = (float)d.fy; d.cxf = (float)d.cx; d.cyf = (float)d.cy;
+    d.loss_af = (float)d.loss_a; d.z_guardf = (float)d.z_guard; d.z_epsf = (float)d.z_eps;
     d.loss_kind = p->loss_kind; d.rot_transposed = p->rot_transposed;
-    d.tile_begin = (int32_t)tiles.size();
-    for (int64_t s = 0; s < p->n; s += chunk) {
-      Tile t;
-      t.problem = (int32_t)i; t.start = (int32_t)s;
-      t.count = (int32_t)std::min<int64_t>(chunk, p->n - s);
-      t.pad_ = 0;
-      tiles.push_back(t);
-    }
-    d.tile_end = (int32_t)tiles.size();
+    const int nchunks = (int)((p->n + chunk - 1) / chunk);
+    d.tile_begin = rows;
+    rows += nchunks;
+    d.tile_end = rows;
+    max_chunks = std::max(max_chunks, nchunks);
     b->versions[i] = p->version;
   }
-  b->ntiles = (int)tiles.size();
+  b->ntiles = rows;
+  b->max_chunks = max_chunks;
   if (b->ntiles > b->tiles_cap) {
-    (void)hipFree(b->d_tiles); (void)hipFree(b->d_partials);
-    b->d_tiles = nullptr; b->d_partials = nullptr;
+    (void)hipFree(b->d_partials);
+    b->d_partials = nullptr;
     b->tiles_cap = b->ntiles + b->ntiles / 4 + 16;
-    HIPCHK(hipMalloc(&b->d_tiles, (size_t)b->tiles_cap * sizeof(Tile)));
     HIPCHK(hipMalloc(&b->d_partials, (size_t)b->tiles_cap * kAccSlots * sizeof(double)));
   }
   HIPCHK(hipMemcpy(b->d_probs, descs.data(), descs.size() * sizeof(ProblemDesc), hipMemcpyHostToDevice));
-  if (b->ntiles)
-    HIPCHK(hipMemcpy(b->d_tiles, tiles.data(), tiles.size() * sizeof(Tile), hipMemcpyHostToDevice));
-  int use_lds = b->t_use_lds < 0 ? 1 : b->t_use_lds;
+  // LDS staging of the DT footprint is available but off by default: on MI355X the unaligned 16-byte
+  // row loads served by the XCD's L2 beat it at every size measured
+  int use_lds = b->t_use_lds < 0 ? 0 : b->t_use_lds;
   int lds = b->t_lds_bytes >= 0 ? b->t_lds_bytes : (b->dtype == EA_F32 ? 32768 : 49152);
   if (lds > 61440) lds = 61440;
   b->lds_bytes = use_lds ? lds : 0;
@@ -414,8 +430,8 @@ static void host_pose_state(const ea_problem *p, const double *q, const double *
 }
 
 static int batch_launch_eval(ea_batch *b) {
-  HIPCHK(launch_eval_fused(b->dtype, b->ppt, b->d_probs, b->d_tiles, b->ntiles, b->xcd_remap, b->d_poses,
-                           b->d_partials, b->lds_bytes, b->stream));
+  HIPCHK(launch_eval_fused(b->dtype, b->ppt, b->nt, b->d_probs, (int)b->probs.size(), b->chunk, b->max_chunks,
+                           b->xcd_remap, b->d_poses, b->d_partials, b->lds_bytes, b->stream));
   return EA_OK;
 }
 
@@ -457,26 +473,26 @@ extern "C" int ea_batch_eval(ea_batch *b, const double *q, const double *t, doub
   return EA_OK;
 }
 
-static void fill_summary(const LMState &s, int64_t npts, double ms, ea_summary *out) {
+static void fill_summary(const LMState &s, const LMTrace &tr, int64_t npts, double ms, ea_summary *out) {
   std::memset(out, 0, sizeof(*out));
   out->termination = s.termination;
   out->why = s.why;
   out->num_iterations = s.iteration;
   out->num_successful_steps = s.num_successful;
   out->num_unsuccessful_steps = s.num_unsuccessful;
-  out->initial_cost = s.it_cost[0];
+  out->initial_cost = tr.it_cost[0];
   out->final_cost = s.cost;
   out->num_point_evals = (int64_t)s.num_evals * npts;
   out->total_time_ms = ms;
   const int ni = std::min(s.iteration + 1, (int)EA_MAX_TRACE);
   for (int i = 0; i < ni; ++i) {
-    out->it_cost[i] = s.it_cost[i];
-    out->it_cost_change[i] = s.it_cost_change[i];
-    out->it_gradient_max_norm[i] = s.it_gradient_max_norm[i];
-    out->it_step_norm[i] = s.it_step_norm[i];
-    out->it_relative_decrease[i] = s.it_relative_decrease[i];
-    out->it_radius[i] = s.it_radius[i];
-    out->it_successful[i] = s.it_successful[i];
+    out->it_cost[i] = tr.it_cost[i];
+    out->it_cost_change[i] = tr.it_cost_change[i];
+    out->it_gradient_max_norm[i] = tr.it_gradient_max_norm[i];
+    out->it_step_norm[i] = tr.it_step_norm[i];
+    out->it_relative_decrease[i] = tr.it_relative_decrease[i];
+    out->it_radius[i] = tr.it_radius[i];
+    out->it_successful[i] = tr.it_successful[i];
   }
 }
 
@@ -522,7 +538,8 @@ extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, 
     for (int k = 0; k < m; ++k) {
       rc = batch_launch_eval(b);
       if (rc != EA_OK) return rc;
-      HIPCHK(launch_lm_step(b->d_probs, count, b->d_partials, b->d_poses, b->d_states, lo, b->d_running, b->stream));
+      HIPCHK(launch_lm_step(b->d_probs, count, b->d_partials, b->d_poses, b->d_states, b->d_traces, lo,
+                            b->d_running, b->stream));
     }
     budget -= m;
     HIPCHK(hipMemcpyAsync(b->h_running, b->d_running, count * sizeof(int), hipMemcpyDeviceToHost, b->stream));
@@ -532,19 +549,22 @@ extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, 
     if (!any) break;
   }
   HIPCHK(hipMemcpyAsync(b->h_states, b->d_states, count * sizeof(LMState), hipMemcpyDeviceToHost, b->stream));
+  if (summaries || o.minimizer_progress_to_stdout)
+    HIPCHK(hipMemcpyAsync(b->h_traces, b->d_traces, count * sizeof(LMTrace), hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   for (int i = 0; i < count; ++i) {
     const LMState &s = b->h_states[i];
     for (int k = 0; k < 4; ++k) q[4 * i + k] = s.x[k];
     for (int k = 0; k < 3; ++k) t[3 * i + k] = s.x[4 + k];
-    if (summaries) fill_summary(s, b->probs[i]->n, ms, &summaries[i]);
+    const LMTrace &tr = b->h_traces[i];
+    if (summaries) fill_summary(s, tr, b->probs[i]->n, ms, &summaries[i]);
     if (o.minimizer_progress_to_stdout) {
       std::printf("problem %d\niter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n", i);
       const int ni = std::min(s.iteration + 1, (int)kTrace);
       for (int it = 0; it < ni; ++it)
-        std::printf("%4d  %.6e  % .2e    %.2e   %.2e  % .2e  %.2e\n", it, s.it_cost[it], s.it_cost_change[it],
-                    s.it_gradient_max_norm[it], s.it_step_norm[it], s.it_relative_decrease[it], s.it_radius[it]);
+        std::printf("%4d  %.6e  % .2e    %.2e   %.2e  % .2e  %.2e\n", it, tr.it_cost[it], tr.it_cost_change[it],
+                    tr.it_gradient_max_norm[it], tr.it_step_norm[it], tr.it_relative_decrease[it], tr.it_radius[it]);
     }
   }
   return EA_OK;
@@ -609,6 +629,7 @@ extern "C" int ea_batch_set_tuning(ea_batch *b, const char *key, int value) {
   else if (k == "points_per_thread") b->t_ppt = value;
   else if (k == "use_lds") b->t_use_lds = value;
   else if (k == "xcd_remap") b->t_xcd = value;
+  else if (k == "threads") b->t_nt = value;
   else return fail(EA_ERR_INVALID_ARG, "unknown tuning key: " + k);
   b->built = false;
   return EA_OK;
@@ -621,6 +642,8 @@ extern "C" int ea_batch_get_info(const ea_batch *b, const char *key, int64_t *va
   else if (k == "points_per_thread") *value = b->ppt;
   else if (k == "lds_bytes") *value = b->lds_bytes;
   else if (k == "xcd_remap") *value = b->xcd_remap;
+  else if (k == "chunk") *value = b->chunk;
+  else if (k == "threads") *value = b->nt;
   else if (k == "num_points") { int64_t s = 0; for (auto *p : b->probs) s += p->n; *value = s; }
   else return fail(EA_ERR_INVALID_ARG, "unknown info key: " + k);
   return EA_OK;

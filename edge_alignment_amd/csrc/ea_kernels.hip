@@ -12,7 +12,8 @@
 // image row-major [v][u] with a 3-texel replicated border so that Grid2D's clamp-to-edge
 // addressing needs no per-tap clamps; per-tile partial sums as 32 doubles (256 B) per tile.
 // A workgroup handles a tile = run of consecutive points; their projected footprint (+halo) is
-// staged through LDS when it fits, otherwise the taps come from L2 directly.
+// staged through LDS when it fits, otherwise the taps come from L2 directly (four unaligned
+// 16-byte row loads per point).
 //
 // No MFMA: pointwise arithmetic plus a 28-value reduction.
 
@@ -56,66 +57,90 @@ __device__ __forceinline__ void cr_weights(T x, T w[4], T d[4]) {
   d[3] = x * t_fma<T>(T(1.5), x, T(-1));
 }
 
+// uniform (per-problem / per-pose) values in the kernel's arithmetic type
+template <typename T> struct Uni;
+template <> struct Uni<double> {
+  static __device__ __forceinline__ const double *R(const PoseState &ps) { return ps.R; }
+  static __device__ __forceinline__ const double *t(const PoseState &ps) { return ps.t; }
+  static __device__ __forceinline__ const double *G(const PoseState &ps) { return ps.G; }
+  static __device__ __forceinline__ double fx(const ProblemDesc &pd) { return pd.fx; }
+  static __device__ __forceinline__ double fy(const ProblemDesc &pd) { return pd.fy; }
+  static __device__ __forceinline__ double cx(const ProblemDesc &pd) { return pd.cx; }
+  static __device__ __forceinline__ double cy(const ProblemDesc &pd) { return pd.cy; }
+  static __device__ __forceinline__ double loss_a(const ProblemDesc &pd) { return pd.loss_a; }
+  static __device__ __forceinline__ double z_guard(const ProblemDesc &pd) { return pd.z_guard; }
+  static __device__ __forceinline__ double z_eps(const ProblemDesc &pd) { return pd.z_eps; }
+};
+template <> struct Uni<float> {
+  static __device__ __forceinline__ const float *R(const PoseState &ps) { return ps.Rf; }
+  static __device__ __forceinline__ const float *t(const PoseState &ps) { return ps.tf; }
+  static __device__ __forceinline__ const float *G(const PoseState &ps) { return ps.Gf; }
+  static __device__ __forceinline__ float fx(const ProblemDesc &pd) { return pd.fxf; }
+  static __device__ __forceinline__ float fy(const ProblemDesc &pd) { return pd.fyf; }
+  static __device__ __forceinline__ float cx(const ProblemDesc &pd) { return pd.cxf; }
+  static __device__ __forceinline__ float cy(const ProblemDesc &pd) { return pd.cyf; }
+  static __device__ __forceinline__ float loss_a(const ProblemDesc &pd) { return pd.loss_af; }
+  static __device__ __forceinline__ float z_guard(const ProblemDesc &pd) { return pd.z_guardf; }
+  static __device__ __forceinline__ float z_eps(const ProblemDesc &pd) { return pd.z_epsf; }
+};
+
 // per-point state carried from the projection phase to the sampling phase
 template <typename T>
 struct Proj {
-  T bx, by, iz;   // warped point (x, y) and 1 / (b_z + z_eps)
+  T bx, by, iz;    // warped point (x, y) and 1 / (b_z + z_eps)
   T cx_, cy_, cz_; // R a  (= b - t), for the unit-quaternion Jacobian
-  T fu, fv;       // fractional parts of (u, v)
-  int iu, iv;     // floor(u), floor(v), clamped to [-2, W] / [-2, H]
-  int state;      // 0 = lane has no point, 1 = valid, 2 = functor returned false
+  T fu, fv;        // fractional parts of (u, v)
+  int iu, iv;      // floor(u), floor(v), saturated to [-2, W] / [-2, H]
+  int state;       // 0 = lane has no point, 1 = valid, 2 = functor returned false
 };
 
 template <typename T>
-struct PoseT {
-  T R[9], t[3];
-};
-
-template <typename T>
-__device__ __forceinline__ void load_pose(const PoseState &ps, PoseT<T> &p) {
-#pragma unroll
-  for (int i = 0; i < 9; ++i) p.R[i] = (T)ps.R[i];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) p.t[i] = (T)ps.t[i];
-}
-
-template <typename T>
-__device__ __forceinline__ void project_point(const ProblemDesc &pd, const PoseT<T> &pose, T x, T y,
-                                              T z, Proj<T> &o) {
-  const T cxr = t_fma<T>(pose.R[2], z, t_fma<T>(pose.R[1], y, pose.R[0] * x));
-  const T cyr = t_fma<T>(pose.R[5], z, t_fma<T>(pose.R[4], y, pose.R[3] * x));
-  const T czr = t_fma<T>(pose.R[8], z, t_fma<T>(pose.R[7], y, pose.R[6] * x));
-  const T bx = cxr + pose.t[0], by = cyr + pose.t[1], bz = czr + pose.t[2];
-  const T zg = (T)pd.z_guard;
+__device__ __forceinline__ void project_point(const ProblemDesc &pd, const PoseState &ps, T x, T y, T z,
+                                              Proj<T> &o) {
+  const T *R = Uni<T>::R(ps);
+  const T *t = Uni<T>::t(ps);
+  const T cxr = t_fma<T>(R[2], z, t_fma<T>(R[1], y, R[0] * x));
+  const T cyr = t_fma<T>(R[5], z, t_fma<T>(R[4], y, R[3] * x));
+  const T czr = t_fma<T>(R[8], z, t_fma<T>(R[7], y, R[6] * x));
+  const T bx = cxr + t[0], by = cyr + t[1], bz = czr + t[2];
+  const T zg = Uni<T>::z_guard(pd);
   // ref: utils.h:70-73 — `return false` inside (-0.01, 0.01)
   const bool bad = (zg > T(0)) && (bz < zg) && (bz > -zg);
-  const T iz = t_rcp<T>(bz + (T)pd.z_eps);
-  const T u = t_fma<T>((T)pd.fx * bx, iz, (T)pd.cx);
-  const T v = t_fma<T>((T)pd.fy * by, iz, (T)pd.cy);
-  // floor with saturation: beyond [-2, W] x [-2, H] every tap is the replicated border texel
-  const T uf = floor(fmin(fmax(u, T(-2)), (T)pd.W));
-  const T vf = floor(fmin(fmax(v, T(-2)), (T)pd.H));
+  const T iz = t_rcp<T>(bz + Uni<T>::z_eps(pd));
+  const T u = t_fma<T>(Uni<T>::fx(pd) * bx, iz, Uni<T>::cx(pd));
+  const T v = t_fma<T>(Uni<T>::fy(pd) * by, iz, Uni<T>::cy(pd));
+  // Texel index saturates: beyond [-2, W] x [-2, H] every tap is the replicated border texel.
+  // The fraction stays the true one (Ceres: r - int(floor(r))): with equal taps the spline is
+  // constant only while the weights stay O(1).
+  const T uf = floor(u), vf = floor(v);
   o.bx = bx; o.by = by; o.iz = iz;
   o.cx_ = cxr; o.cy_ = cyr; o.cz_ = czr;
-  o.fu = u - uf;  // for saturated coordinates the taps are all equal and the fraction is irrelevant
+  o.fu = u - uf;
   o.fv = v - vf;
-  o.iu = (int)uf;
-  o.iv = (int)vf;
+  o.iu = (int)fmin(fmax(uf, T(-2)), (T)pd.W);
+  o.iv = (int)fmin(fmax(vf, T(-2)), (T)pd.H);
   o.state = bad ? 2 : 1;
 }
 
-// 16 taps -> value and gradient.  taps(l, k) = DT(v = iv-1+l, u = iu-1+k)
-template <typename T, typename TapFn>
-__device__ __forceinline__ void bicubic(T fu, T fv, TapFn tap, T &f, T &Fu, T &Fv) {
+// four consecutive texels of one image row; 4/8-byte aligned only (the hardware's unaligned
+// access mode turns this into one or two dwordx4 loads instead of four scalar ones)
+template <typename T>
+struct __attribute__((packed, aligned(sizeof(T)))) Row4 {
+  T p0, p1, p2, p3;
+};
+
+// 16 taps -> value and gradient.  row(l) = DT(v = iv-1+l, u = iu-1 .. iu+2)
+template <typename T, typename RowFn>
+__device__ __forceinline__ void bicubic(T fu, T fv, RowFn row, T &f, T &Fu, T &Fv) {
   T wu[4], du[4], wv[4], dv[4];
   cr_weights<T>(fu, wu, du);
   cr_weights<T>(fv, wv, dv);
   f = T(0); Fu = T(0); Fv = T(0);
 #pragma unroll
   for (int l = 0; l < 4; ++l) {
-    const T p0 = tap(l, 0), p1 = tap(l, 1), p2 = tap(l, 2), p3 = tap(l, 3);
-    const T rs = t_fma<T>(wu[3], p3, t_fma<T>(wu[2], p2, t_fma<T>(wu[1], p1, wu[0] * p0)));
-    const T rd = t_fma<T>(du[3], p3, t_fma<T>(du[2], p2, t_fma<T>(du[1], p1, du[0] * p0)));
+    const Row4<T> r = row(l);
+    const T rs = t_fma<T>(wu[3], r.p3, t_fma<T>(wu[2], r.p2, t_fma<T>(wu[1], r.p1, wu[0] * r.p0)));
+    const T rd = t_fma<T>(du[3], r.p3, t_fma<T>(du[2], r.p2, t_fma<T>(du[1], r.p1, du[0] * r.p0)));
     f = t_fma<T>(wv[l], rs, f);
     Fv = t_fma<T>(dv[l], rs, Fv);
     Fu = t_fma<T>(wv[l], rd, Fu);
@@ -144,12 +169,12 @@ __device__ __forceinline__ void loss_eval(int kind, T a, T s, T &rho, T &w) {
   }
 }
 
-// residual and raw 1x6 row of one point from its sample
+// raw 1x6 row of one point from its sample gradient
 template <typename T>
 __device__ __forceinline__ void jacobian_row(const ProblemDesc &pd, const PoseState &ps,
                                              const Proj<T> &pr, T x, T y, T z, T Fu, T Fv, T J[6]) {
-  const T gx = Fu * (T)pd.fx * pr.iz;
-  const T gy = Fv * (T)pd.fy * pr.iz;
+  const T gx = Fu * Uni<T>::fx(pd) * pr.iz;
+  const T gy = Fv * Uni<T>::fy(pd) * pr.iz;
   const T gz = -t_fma<T>(gx, pr.bx, gy * pr.by) * pr.iz;
   if (ps.unit_q) {
     // d b / d delta = -2 [R a]x  =>  J_delta = 2 (R a) x g
@@ -159,10 +184,10 @@ __device__ __forceinline__ void jacobian_row(const ProblemDesc &pd, const PoseSt
   } else {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const double *G = ps.G + 9 * j;
-      const T d0 = t_fma<T>((T)G[2], z, t_fma<T>((T)G[1], y, (T)G[0] * x));
-      const T d1 = t_fma<T>((T)G[5], z, t_fma<T>((T)G[4], y, (T)G[3] * x));
-      const T d2 = t_fma<T>((T)G[8], z, t_fma<T>((T)G[7], y, (T)G[6] * x));
+      const T *G = Uni<T>::G(ps) + 9 * j;
+      const T d0 = t_fma<T>(G[2], z, t_fma<T>(G[1], y, G[0] * x));
+      const T d1 = t_fma<T>(G[5], z, t_fma<T>(G[4], y, G[3] * x));
+      const T d2 = t_fma<T>(G[8], z, t_fma<T>(G[7], y, G[6] * x));
       J[j] = t_fma<T>(gz, d2, t_fma<T>(gy, d1, gx * d0));
     }
   }
@@ -170,32 +195,68 @@ __device__ __forceinline__ void jacobian_row(const ProblemDesc &pd, const PoseSt
 }
 
 // ------------------------------------------------------------------------------------------------
-// wavefront reduction of 32 values per lane: transposing butterfly.
-// After the call lane L (0..63) holds in v[0] the wave total of slot
-//   id(L) = 16*b0 + 8*b1 + 4*b2 + 2*b3 + b4   (b_k = bit k of L); lanes L and L^32 hold the same.
-// 31 shuffles + 1 instead of 32*6.
+// wavefront reduction of 32 values per lane: transposing butterfly on DPP.
+//
+// Each step pairs lanes, lets the pair split its values in two halves, and adds the partner's
+// copy of the kept half — so the number of live values halves while the number of lanes summed
+// doubles: 16+8+4+2+1 exchanges instead of 32*6.  The lane pairings are the ones DPP offers for
+// free inside a 16-lane row (row_mirror = xor 15, row_half_mirror = xor 7, quad_perm = xor 2 and
+// xor 1), ordered so that a partner always agrees on every selection bit used before; the two
+// cross-row steps (xor 16, xor 32) move one value each.
+// After the call lane L holds in v[0] the wave total of slot
+//   id(L) = 16*b3 + 8*b2 + 4*b1 + 2*b0 + b4   (b_k = bit k of L); lanes L and L^32 hold the same.
 
 __device__ __forceinline__ int butterfly_slot(int lane) {
-  return ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
+  return ((lane & 8) << 1) | ((lane & 4) << 1) | ((lane & 2) << 1) | ((lane & 1) << 1) | ((lane & 16) >> 4);
 }
 
-template <int M, int C>
-__device__ __forceinline__ void butterfly_step(double (&v)[32], int lane) {
-  const bool upper = (lane & M) != 0;
+constexpr int kDppRowMirror = 0x140, kDppRowHalfMirror = 0x141, kDppQuadXor2 = 0x4E, kDppQuadXor1 = 0xB1;
+
+template <int CTRL>
+__device__ __forceinline__ float lane_xchg(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double lane_xchg(double x) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, false);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+// xor 16 inside each half-wave: ds_swizzle bit-mask mode (and 0x1f, or 0, xor 0x10); no LDS memory
+__device__ __forceinline__ float lane_xor16(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));
+}
+__device__ __forceinline__ double lane_xor16(double x) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const int lo = __builtin_amdgcn_ds_swizzle((int)(unsigned)u, 0x401F);
+  const int hi = __builtin_amdgcn_ds_swizzle((int)(unsigned)(u >> 32), 0x401F);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+template <int CTRL, int BIT, int C, typename A>
+__device__ __forceinline__ void butterfly_step(A (&v)[32], int lane) {
+  const bool upper = (lane & BIT) != 0;
 #pragma unroll
   for (int i = 0; i < C; ++i) {
-    const double send = upper ? v[i] : v[i + C];
-    const double keep = upper ? v[i + C] : v[i];
-    v[i] = keep + __shfl_xor(send, M, 64);
+    const A send = upper ? v[i] : v[i + C];
+    const A keep = upper ? v[i + C] : v[i];
+    v[i] = keep + lane_xchg<CTRL>(send);
   }
 }
 
-__device__ __forceinline__ void wave_reduce32(double (&v)[32], int lane) {
-  butterfly_step<1, 16>(v, lane);
-  butterfly_step<2, 8>(v, lane);
-  butterfly_step<4, 4>(v, lane);
-  butterfly_step<8, 2>(v, lane);
-  butterfly_step<16, 1>(v, lane);
+template <typename A>
+__device__ __forceinline__ void wave_reduce32(A (&v)[32], int lane) {
+  butterfly_step<kDppRowMirror, 8, 16>(v, lane);
+  butterfly_step<kDppRowHalfMirror, 4, 8>(v, lane);
+  butterfly_step<kDppQuadXor2, 2, 4>(v, lane);
+  butterfly_step<kDppQuadXor1, 1, 2>(v, lane);
+  {
+    const bool upper = (lane & 16) != 0;
+    const A send = upper ? v[0] : v[1];
+    const A keep = upper ? v[1] : v[0];
+    v[0] = keep + lane_xor16(send);
+  }
   v[0] += __shfl_xor(v[0], 32, 64);
 }
 
@@ -211,64 +272,75 @@ __device__ __forceinline__ int wave_max_i32(int x) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// fused evaluation kernel: residual + Jacobian + loss + JtJ/Jtr/cost partials per tile
+// fused evaluation kernel: residual + Jacobian + loss + JtJ/Jtr/cost partials, one row per workgroup
+//
+// grid = (8 * ceil(chunks/8), problems).  Workgroup (c, p) owns points [c*chunk, (c+1)*chunk) of
+// problem p, chunk = NT*PPT: every lane takes PPT points (strided by NT so loads coalesce), one
+// wavefront butterfly per wave and one cross-wave fold per workgroup -> one partial row.
 
-constexpr int kRedBytes = 4 * kAccSlots * 8;  // cross-wave scratch: 4 waves x 32 doubles
-constexpr int kHdrBytes = kRedBytes + 64;     // + bbox words, keeps the tile 16-byte aligned
+constexpr int kMaxWaves = 16;
+constexpr int kRedBytes = kMaxWaves * kAccSlots * 8;  // cross-wave scratch: up to 16 waves x 32 doubles
+constexpr int kHdrBytes = kRedBytes + kMaxWaves * 16;  // + bbox words, keeps the tile 16-byte aligned
 
-template <typename T, int PPT>
-__global__ __launch_bounds__(kBlockThreads) void ea_eval_fused_kernel(
-    const ProblemDesc *__restrict__ probs, const Tile *__restrict__ tiles, int ntiles,
-    int tiles_per_xcd, int xcd_remap, const PoseState *__restrict__ poses,
-    double *__restrict__ partials, int lds_texels) {
+// NT = workgroup size (256 or 1024).  1024 = one workgroup per CU: four times fewer partial rows
+// to fold afterwards at the same points-per-lane latency.
+template <typename T, int PPT, bool USE_LDS, int NT>
+__global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
+    const ProblemDesc *__restrict__ probs, const PoseState *__restrict__ poses,
+    double *__restrict__ partials, int chunk, int chunks_per_xcd, int xcd_remap, int lds_texels) {
   extern __shared__ __align__(16) unsigned char smem[];
   double *s_red = reinterpret_cast<double *>(smem);
   int *s_box = reinterpret_cast<int *>(smem + kRedBytes);
   T *s_tile = reinterpret_cast<T *>(smem + kHdrBytes);
 
-  // XCD-aware tile assignment: workgroups are dealt round-robin over the 8 XCDs, so give each
-  // XCD a contiguous run of tiles (neighbouring tiles read neighbouring image rows -> one L2).
-  const int bid = blockIdx.x;
-  const int tile_id = xcd_remap ? (bid & 7) * tiles_per_xcd + (bid >> 3) : bid;
-  if (tile_id >= ntiles) return;
-  const Tile tile = tiles[tile_id];
-  const ProblemDesc &pd = probs[tile.problem];
-  const PoseState &ps = poses[tile.problem];
-  if (!ps.active) return;
+  // XCD-aware chunk assignment: workgroups are dealt round-robin over the 8 XCDs, so give each
+  // XCD a contiguous run of chunks (neighbouring chunks read neighbouring image rows -> one L2).
+  const int bx = blockIdx.x;
+  const int c = xcd_remap ? (bx & 7) * chunks_per_xcd + (bx >> 3) : bx;
+  const ProblemDesc &pd = probs[blockIdx.y];
+  const PoseState &ps = poses[blockIdx.y];
+  const long long start = (long long)c * chunk;
+  if (start >= pd.n || !ps.active) return;
+  const int count = min(chunk, (int)(pd.n - start));
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
 
-  PoseT<T> pose;
-  load_pose<T>(ps, pose);
-  const T *__restrict__ px = static_cast<const T *>(pd.x);
-  const T *__restrict__ py = static_cast<const T *>(pd.y);
-  const T *__restrict__ pz = static_cast<const T *>(pd.z);
+  const T *__restrict__ px = static_cast<const T *>(pd.x) + start;
+  const T *__restrict__ py = static_cast<const T *>(pd.y) + start;
+  const T *__restrict__ pz = static_cast<const T *>(pd.z) + start;
+  const int pitch = pd.pitch;
+  const T *__restrict__ gimg = static_cast<const T *>(pd.dt) + (size_t)kImagePad * (size_t)pitch + kImagePad;
+  const int loss_kind = pd.loss_kind;
+  const T loss_a = Uni<T>::loss_a(pd);
 
   // ---- phase 1: coalesced point loads, warp + projection
   Proj<T> pr[PPT];
   T X[PPT], Y[PPT], Z[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int j = tid + k * NT;
+    pr[k].state = 0;
+    if (j < count) { X[k] = px[j]; Y[k] = py[j]; Z[k] = pz[j]; }
+  }
   int bb_u0 = 0x7fffffff, bb_u1 = -0x7fffffff, bb_v0 = 0x7fffffff, bb_v1 = -0x7fffffff;
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
-    const int j = tid + k * kBlockThreads;
-    pr[k].state = 0;
-    if (j < tile.count) {
-      const int i = tile.start + j;
-      X[k] = px[i]; Y[k] = py[i]; Z[k] = pz[i];
-      project_point<T>(pd, pose, X[k], Y[k], Z[k], pr[k]);
-      if (pr[k].state == 1) {
+    const int j = tid + k * NT;
+    if (j < count) {
+      project_point<T>(pd, ps, X[k], Y[k], Z[k], pr[k]);
+      if (USE_LDS && pr[k].state == 1) {
         bb_u0 = min(bb_u0, pr[k].iu); bb_u1 = max(bb_u1, pr[k].iu);
         bb_v0 = min(bb_v0, pr[k].iv); bb_v1 = max(bb_v1, pr[k].iv);
       }
     }
   }
 
-  // ---- phase 2: footprint of the tile, staged through LDS when it fits
-  bool use_lds = false;
+  // ---- phase 2: footprint of the sub-chunk, staged through LDS when it fits
+  bool in_lds = false;
   int u0 = 0, v0 = 0, tw = 0;
-  if (lds_texels > 0) {
+  if (USE_LDS) {
     bb_u0 = wave_min_i32(bb_u0); bb_u1 = wave_max_i32(bb_u1);
     bb_v0 = wave_min_i32(bb_v0); bb_v1 = wave_max_i32(bb_v1);
     if (lane == 0) {
@@ -278,7 +350,7 @@ __global__ __launch_bounds__(kBlockThreads) void ea_eval_fused_kernel(
     __syncthreads();
     int U0 = s_box[0], U1 = s_box[1], V0 = s_box[2], V1 = s_box[3];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
+    for (int w = 1; w < NT / 64; ++w) {
       U0 = min(U0, s_box[4 * w + 0]); U1 = max(U1, s_box[4 * w + 1]);
       V0 = min(V0, s_box[4 * w + 2]); V1 = max(V1, s_box[4 * w + 3]);
     }
@@ -288,16 +360,15 @@ __global__ __launch_bounds__(kBlockThreads) void ea_eval_fused_kernel(
       const int th = V1 - V0 + 4;
       const long long area = (long long)tw * (long long)th;
       if (area <= (long long)lds_texels) {
-        use_lds = true;
-        const T *__restrict__ img = static_cast<const T *>(pd.dt) +
-                                    (size_t)(v0 + kImagePad) * (size_t)pd.pitch + (u0 + kImagePad);
+        in_lds = true;
+        const T *__restrict__ img = gimg + (ptrdiff_t)v0 * pitch + u0;
         const float inv_tw = 1.0f / (float)tw;
-        for (int idx = tid; idx < (int)area; idx += kBlockThreads) {
+        for (int idx = tid; idx < (int)area; idx += NT) {
           int row = (int)((float)idx * inv_tw);
           int col = idx - row * tw;
           if (col < 0) { row -= 1; col += tw; }
           if (col >= tw) { row += 1; col -= tw; }
-          s_tile[idx] = img[(size_t)row * (size_t)pd.pitch + col];
+          s_tile[idx] = img[(ptrdiff_t)row * pitch + col];
         }
         __syncthreads();
       }
@@ -309,25 +380,25 @@ __global__ __launch_bounds__(kBlockThreads) void ea_eval_fused_kernel(
 #pragma unroll
   for (int i = 0; i < 28; ++i) acc[i] = T(0);
   int n_bad = 0;
-  const T *__restrict__ gimg = static_cast<const T *>(pd.dt) + (size_t)kImagePad * (size_t)pd.pitch + kImagePad;
-  const int pitch = pd.pitch;
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
     if (pr[k].state == 2) n_bad += 1;
     if (pr[k].state != 1) continue;
     T f, Fu, Fv;
-    if (use_lds) {
+    if (USE_LDS && in_lds) {
       const T *base = s_tile + (pr[k].iv - 1 - v0) * tw + (pr[k].iu - 1 - u0);
       const int stride = tw;
-      bicubic<T>(pr[k].fu, pr[k].fv, [&](int l, int c) { return base[l * stride + c]; }, f, Fu, Fv);
+      bicubic<T>(pr[k].fu, pr[k].fv,
+                 [&](int l) { return *reinterpret_cast<const Row4<T> *>(base + l * stride); }, f, Fu, Fv);
     } else {
       const T *base = gimg + (ptrdiff_t)(pr[k].iv - 1) * pitch + (pr[k].iu - 1);
-      bicubic<T>(pr[k].fu, pr[k].fv, [&](int l, int c) { return base[(ptrdiff_t)l * pitch + c]; }, f, Fu, Fv);
+      bicubic<T>(pr[k].fu, pr[k].fv,
+                 [&](int l) { return *reinterpret_cast<const Row4<T> *>(base + (ptrdiff_t)l * pitch); }, f, Fu, Fv);
     }
     T J[6];
     jacobian_row<T>(pd, ps, pr[k], X[k], Y[k], Z[k], Fu, Fv, J);
     T rho, w;
-    loss_eval<T>(pd.loss_kind, (T)pd.loss_a, f * f, rho, w);
+    loss_eval<T>(loss_kind, loss_a, f * f, rho, w);
     const T wr = w * f;
     int s = 0;
 #pragma unroll
@@ -340,18 +411,22 @@ __global__ __launch_bounds__(kBlockThreads) void ea_eval_fused_kernel(
     acc[kAccCost] = t_fma<T>(T(0.5), rho, acc[kAccCost]);
   }
 
-  // ---- phase 4: wavefront butterfly, then fixed-order cross-wave sum
-  double v[32];
+  // ---- phase 4: wavefront butterfly in the kernel's arithmetic type (a lane's accumulators and
+  // a wavefront's 64-lane sums are T; everything above a wavefront is fp64), then the
+  // fixed-order cross-wave sum
+  T v[32];
 #pragma unroll
-  for (int i = 0; i < 28; ++i) v[i] = (double)acc[i];
-  v[28] = (double)n_bad; v[29] = 0.0; v[30] = 0.0; v[31] = 0.0;
-  wave_reduce32(v, lane);
-  __syncthreads();  // s_tile / s_box readers are done; s_red is a separate region but keep phases ordered
-  if (lane < 32) s_red[wave * kAccSlots + butterfly_slot(lane)] = v[0];
+  for (int i = 0; i < 28; ++i) v[i] = acc[i];
+  v[28] = (T)n_bad; v[29] = T(0); v[30] = T(0); v[31] = T(0);
+  wave_reduce32<T>(v, lane);
+  if (USE_LDS) __syncthreads();  // tile readers done before the scratch rows are written
+  if (lane < 32) s_red[wave * kAccSlots + butterfly_slot(lane)] = (double)v[0];
   __syncthreads();
   if (tid < kAccSlots) {
-    const double sum = ((s_red[tid] + s_red[kAccSlots + tid]) + s_red[2 * kAccSlots + tid]) + s_red[3 * kAccSlots + tid];
-    partials[(size_t)tile_id * kAccSlots + tid] = sum;
+    double sum = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) sum += s_red[w * kAccSlots + tid];
+    partials[(size_t)(pd.tile_begin + c) * kAccSlots + tid] = sum;
   }
 }
 
@@ -366,11 +441,9 @@ __global__ __launch_bounds__(kBlockThreads) void ea_eval_points_kernel(
   const PoseState &ps = poses[problem];
   const int i = blockIdx.x * kBlockThreads + threadIdx.x;
   if (i >= pd.n) return;
-  PoseT<T> pose;
-  load_pose<T>(ps, pose);
   const T x = static_cast<const T *>(pd.x)[i], y = static_cast<const T *>(pd.y)[i], z = static_cast<const T *>(pd.z)[i];
   Proj<T> pr;
-  project_point<T>(pd, pose, x, y, z, pr);
+  project_point<T>(pd, ps, x, y, z, pr);
   const double nan = __builtin_nan("");
   if (pr.state != 1) {
     if (r_out) r_out[i] = nan;
@@ -378,17 +451,17 @@ __global__ __launch_bounds__(kBlockThreads) void ea_eval_points_kernel(
       for (int a = 0; a < 6; ++a) J_out[(size_t)i * 6 + a] = nan;
     return;
   }
-  const T *base = static_cast<const T *>(pd.dt) + (size_t)kImagePad * (size_t)pd.pitch + kImagePad +
-                  (ptrdiff_t)(pr.iv - 1) * pd.pitch + (pr.iu - 1);
   const int pitch = pd.pitch;
+  const T *base = static_cast<const T *>(pd.dt) + (size_t)kImagePad * (size_t)pitch + kImagePad +
+                  (ptrdiff_t)(pr.iv - 1) * pitch + (pr.iu - 1);
   T f, Fu, Fv;
-  bicubic<T>(pr.fu, pr.fv, [&](int l, int c) { return base[(ptrdiff_t)l * pitch + c]; }, f, Fu, Fv);
+  bicubic<T>(pr.fu, pr.fv, [&](int l) { return *reinterpret_cast<const Row4<T> *>(base + (ptrdiff_t)l * pitch); }, f, Fu, Fv);
   T J[6];
   jacobian_row<T>(pd, ps, pr, x, y, z, Fu, Fv, J);
   T sc = T(1);
   if (corrected) {
     T rho, w;
-    loss_eval<T>(pd.loss_kind, (T)pd.loss_a, f * f, rho, w);
+    loss_eval<T>(pd.loss_kind, Uni<T>::loss_a(pd), f * f, rho, w);
     sc = t_sqrt<T>(w);
   }
   if (r_out) r_out[i] = (double)(sc * f);
@@ -399,53 +472,82 @@ __global__ __launch_bounds__(kBlockThreads) void ea_eval_points_kernel(
 // ------------------------------------------------------------------------------------------------
 // fixed-order reduction of a problem's tile partials -> 32 accumulators
 
+constexpr int kFoldThreads = 1024;  // plain fold: 32 slots x 32 strided groups
+constexpr int kLmThreads = 512;     // fold + scalar LM code (8 waves leave it 256 VGPRs)
+
+template <int NTHREADS>
 __device__ __forceinline__ void reduce_tiles(const double *__restrict__ partials, int tile_begin,
-                                             int tile_end, double *s_part /* 8 x 32 */,
-                                             double *out /* 32, lanes 0..31 write */) {
+                                             int tile_end, double *s_part /* (NTHREADS/32) x 32 */,
+                                             double *out /* 32, threads 0..31 write */) {
+  constexpr int kRedGroups = NTHREADS / 32;
   const int tid = threadIdx.x;
-  const int id = tid & 31, j = tid >> 5;  // 8 strided partial sums per slot
-  double s = 0.0;
-  for (int tI = tile_begin + j; tI < tile_end; tI += 8) s += partials[(size_t)tI * kAccSlots + id];
-  s_part[j * kAccSlots + id] = s;
+  const int id = tid & 31, j = tid >> 5;
+  // fixed summation order for a given tile count; 8 independent loads in flight per thread
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
+  int tI = tile_begin + j;
+  constexpr int G = kRedGroups;
+  for (; tI + 7 * G < tile_end; tI += 8 * G) {
+    const double *p = partials + (size_t)tI * kAccSlots + id;
+    s0 += p[0 * G * kAccSlots]; s1 += p[1 * G * kAccSlots]; s2 += p[2 * G * kAccSlots]; s3 += p[3 * G * kAccSlots];
+    s4 += p[4 * G * kAccSlots]; s5 += p[5 * G * kAccSlots]; s6 += p[6 * G * kAccSlots]; s7 += p[7 * G * kAccSlots];
+  }
+  for (; tI < tile_end; tI += G) s0 += partials[(size_t)tI * kAccSlots + id];
+  s_part[j * kAccSlots + id] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
   __syncthreads();
   if (tid < kAccSlots) {
     double tot = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) tot += s_part[k * kAccSlots + tid];
+    for (int k = 0; k < G; ++k) tot += s_part[k * kAccSlots + tid];
     out[tid] = tot;
   }
 }
 
-__global__ __launch_bounds__(kBlockThreads) void ea_reduce_kernel(const ProblemDesc *__restrict__ probs,
+__global__ __launch_bounds__(kFoldThreads) void ea_reduce_kernel(const ProblemDesc *__restrict__ probs,
                                                                   const double *__restrict__ partials,
                                                                   EvalOut *__restrict__ out) {
-  __shared__ double s_part[8 * kAccSlots];
+  __shared__ double s_part[(kFoldThreads / 32) * kAccSlots];
   const ProblemDesc &pd = probs[blockIdx.x];
-  reduce_tiles(partials, pd.tile_begin, pd.tile_end, s_part, out[blockIdx.x].acc);
+  reduce_tiles<kFoldThreads>(partials, pd.tile_begin, pd.tile_end, s_part, out[blockIdx.x].acc);
 }
 
-// LM step: reduce this problem's partials, advance the trust-region state machine, publish the
-// next pose to evaluate.  One workgroup per problem; the state machine itself is scalar work on
-// lane 0 (6x6 algebra in fp64).
-__global__ __launch_bounds__(kBlockThreads) void ea_lm_step_kernel(
+// LM step: fold this problem's partial rows, advance the trust-region state machine, publish the
+// next pose to evaluate.  One workgroup per problem.  The state machine is scalar fp64 work on
+// lane 0; its state is staged in LDS so the dependent field accesses cost LDS, not HBM, latency.
+__global__ __launch_bounds__(kLmThreads) void ea_lm_step_kernel(
     const ProblemDesc *__restrict__ probs, const double *__restrict__ partials,
-    PoseState *__restrict__ poses, LMState *__restrict__ states, LMOptions opt,
-    int *__restrict__ running_flags) {
-  __shared__ double s_part[8 * kAccSlots];
+    PoseState *__restrict__ poses, LMState *__restrict__ states, LMTrace *__restrict__ traces,
+    LMOptions opt, int *__restrict__ running_flags) {
+  __shared__ double s_part[(kLmThreads / 32) * kAccSlots];
   __shared__ double s_acc[kAccSlots];
+  __shared__ LMState s_st;
+  __shared__ PoseState s_ps;
+  static_assert(sizeof(LMState) % 8 == 0 && sizeof(PoseState) % 8 == 0, "8-byte copy granules");
   const int p = blockIdx.x;
-  LMState *st = states + p;
-  if (!st->running) return;  // uniform
+  if (!states[p].running) return;  // uniform
+  {
+    const double *src = reinterpret_cast<const double *>(states + p);
+    double *dst = reinterpret_cast<double *>(&s_st);
+    for (int i = threadIdx.x; i < (int)(sizeof(LMState) / 8); i += kLmThreads) dst[i] = src[i];
+  }
   const ProblemDesc &pd = probs[p];
-  reduce_tiles(partials, pd.tile_begin, pd.tile_end, s_part, s_acc);
+  reduce_tiles<kLmThreads>(partials, pd.tile_begin, pd.tile_end, s_part, s_acc);
   __syncthreads();
   if (threadIdx.x == 0) {
     double acc[kAccSlots];
     for (int i = 0; i < kAccSlots; ++i) acc[i] = s_acc[i];
-    if (st->num_evals == 0) lm_begin(st, &opt, acc);
-    else lm_advance(st, &opt, acc);
-    make_pose_state(st->cand, st->rot_transposed, st->running, poses + p);
-    running_flags[p] = st->running;
+    if (s_st.num_evals == 0) lm_begin(&s_st, traces + p, &opt, acc);
+    else lm_advance(&s_st, traces + p, &opt, acc);
+    make_pose_state(s_st.cand, s_st.rot_transposed, s_st.running, &s_ps);
+    running_flags[p] = s_st.running;
+  }
+  __syncthreads();
+  {
+    const double *src = reinterpret_cast<const double *>(&s_st);
+    double *dst = reinterpret_cast<double *>(states + p);
+    for (int i = threadIdx.x; i < (int)(sizeof(LMState) / 8); i += kLmThreads) dst[i] = src[i];
+    const double *ps = reinterpret_cast<const double *>(&s_ps);
+    double *pd2 = reinterpret_cast<double *>(poses + p);
+    for (int i = threadIdx.x; i < (int)(sizeof(PoseState) / 8); i += kLmThreads) pd2[i] = ps[i];
   }
 }
 
@@ -463,27 +565,33 @@ __global__ void ea_pad_image_kernel(const T *__restrict__ src, int H, int W, T *
 // ------------------------------------------------------------------------------------------------
 // launchers (called from ea_capi.cpp)
 
-hipError_t launch_eval_fused(int dtype, int ppt, const ProblemDesc *probs, const Tile *tiles, int ntiles,
-                             int xcd_remap, const PoseState *poses, double *partials, int lds_bytes,
-                             hipStream_t stream) {
-  if (ntiles <= 0) return hipSuccess;
-  const int tiles_per_xcd = (ntiles + 7) / 8;
-  const int grid = xcd_remap ? tiles_per_xcd * 8 : ntiles;
+hipError_t launch_eval_fused(int dtype, int ppt, int nt, const ProblemDesc *probs, int count, int chunk,
+                             int max_chunks, int xcd_remap, const PoseState *poses, double *partials,
+                             int lds_bytes, hipStream_t stream) {
+  if (count <= 0 || max_chunks <= 0) return hipSuccess;
+  const int chunks_per_xcd = (max_chunks + 7) / 8;
+  const dim3 grid(xcd_remap ? chunks_per_xcd * 8 : max_chunks, count);
   const int esz = dtype == 1 ? 4 : 8;
   const int lds_texels = lds_bytes > 0 ? lds_bytes / esz : 0;
   const size_t shmem = (size_t)kHdrBytes + (size_t)lds_texels * esz;
-#define EA_LAUNCH(T, P)                                                                         \
-  hipLaunchKernelGGL((ea_eval_fused_kernel<T, P>), dim3(grid), dim3(kBlockThreads), shmem, stream, probs, \
-                     tiles, ntiles, tiles_per_xcd, xcd_remap, poses, partials, lds_texels)
+#define EA_LAUNCH(T, P, L, N)                                                                \
+  hipLaunchKernelGGL((ea_eval_fused_kernel<T, P, L, N>), grid, dim3(N), shmem, stream, probs, \
+                     poses, partials, chunk, chunks_per_xcd, xcd_remap, lds_texels)
+#define EA_LAUNCH_L(T, P, N)                                          \
+  do {                                                                \
+    if (lds_texels > 0) EA_LAUNCH(T, P, true, N); else EA_LAUNCH(T, P, false, N); \
+  } while (0)
   if (dtype == 1) {
-    if (ppt == 1) EA_LAUNCH(float, 1);
-    else if (ppt == 2) EA_LAUNCH(float, 2);
-    else EA_LAUNCH(float, 4);
+    if (nt == 1024) { if (ppt == 1) EA_LAUNCH_L(float, 1, 1024); else EA_LAUNCH_L(float, 2, 1024); }
+    else if (ppt == 1) EA_LAUNCH_L(float, 1, 256);
+    else if (ppt == 2) EA_LAUNCH_L(float, 2, 256);
+    else EA_LAUNCH_L(float, 4, 256);
   } else {
-    if (ppt == 1) EA_LAUNCH(double, 1);
-    else if (ppt == 2) EA_LAUNCH(double, 2);
-    else EA_LAUNCH(double, 4);
+    if (nt == 1024) EA_LAUNCH_L(double, 1, 1024);
+    else if (ppt == 1) EA_LAUNCH_L(double, 1, 256);
+    else EA_LAUNCH_L(double, 2, 256);
   }
+#undef EA_LAUNCH_L
 #undef EA_LAUNCH
   return hipGetLastError();
 }
@@ -504,15 +612,16 @@ hipError_t launch_eval_points(int dtype, const ProblemDesc *probs, int problem, 
 hipError_t launch_reduce(const ProblemDesc *probs, int count, const double *partials, EvalOut *out,
                          hipStream_t stream) {
   if (count <= 0) return hipSuccess;
-  hipLaunchKernelGGL(ea_reduce_kernel, dim3(count), dim3(kBlockThreads), 0, stream, probs, partials, out);
+  hipLaunchKernelGGL(ea_reduce_kernel, dim3(count), dim3(kFoldThreads), 0, stream, probs, partials, out);
   return hipGetLastError();
 }
 
 hipError_t launch_lm_step(const ProblemDesc *probs, int count, const double *partials, PoseState *poses,
-                          LMState *states, const LMOptions &opt, int *running_flags, hipStream_t stream) {
+                          LMState *states, LMTrace *traces, const LMOptions &opt, int *running_flags,
+                          hipStream_t stream) {
   if (count <= 0) return hipSuccess;
-  hipLaunchKernelGGL(ea_lm_step_kernel, dim3(count), dim3(kBlockThreads), 0, stream, probs, partials, poses,
-                     states, opt, running_flags);
+  hipLaunchKernelGGL(ea_lm_step_kernel, dim3(count), dim3(kLmThreads), 0, stream, probs, partials, poses,
+                     states, traces, opt, running_flags);
   return hipGetLastError();
 }
 

@@ -50,7 +50,12 @@ struct LMState {
   int num_successful, num_unsuccessful, num_consecutive_invalid;
   int num_evals;    // whole-problem evaluations performed
   int rot_transposed;
-  // trace
+  int pad_;
+};
+
+// per-iteration trace (what minimizer_progress_to_stdout would print); written once per
+// iteration, never read back by the state machine
+struct LMTrace {
   double it_cost[kTrace], it_cost_change[kTrace], it_gradient_max_norm[kTrace];
   double it_step_norm[kTrace], it_relative_decrease[kTrace], it_radius[kTrace];
   int it_successful[kTrace];
@@ -123,6 +128,9 @@ EA_HD inline void make_pose_state(const double x[7], int rot_transposed, int act
         }
       }
   }
+  for (int e = 0; e < 9; ++e) ps->Rf[e] = (float)ps->R[e];
+  for (int e = 0; e < 27; ++e) ps->Gf[e] = (float)ps->G[e];
+  for (int e = 0; e < 3; ++e) ps->tf[e] = (float)ps->t[e];
   const double n2 = w * w + qx * qx + qy * qy + qz * qz;
   ps->unit_q = (fabs(n2 - 1.0) <= 1e-12 && !rot_transposed) ? 1 : 0;
   ps->active = active;
@@ -160,16 +168,16 @@ EA_HD inline bool solve_spd6(const double A[36], const double D[6], const double
   return true;
 }
 
-EA_HD inline void lm_trace(LMState *s, int it, double cost_change, double step_norm, double rel,
-                           int successful) {
-  if (it < kTrace) {
-    s->it_cost[it] = s->cost;
-    s->it_cost_change[it] = cost_change;
-    s->it_gradient_max_norm[it] = s->gradient_max_norm;
-    s->it_step_norm[it] = step_norm;
-    s->it_relative_decrease[it] = rel;
-    s->it_radius[it] = s->radius;
-    s->it_successful[it] = successful;
+EA_HD inline void lm_trace(const LMState *s, LMTrace *tr, int it, double cost_change, double step_norm,
+                           double rel, int successful) {
+  if (tr && it < kTrace) {
+    tr->it_cost[it] = s->cost;
+    tr->it_cost_change[it] = cost_change;
+    tr->it_gradient_max_norm[it] = s->gradient_max_norm;
+    tr->it_step_norm[it] = step_norm;
+    tr->it_relative_decrease[it] = rel;
+    tr->it_radius[it] = s->radius;
+    tr->it_successful[it] = successful;
   }
 }
 
@@ -291,7 +299,7 @@ EA_HD inline bool lm_strategy_step(LMState *s, const LMOptions *o, const double 
 // Top of TrustRegionMinimizer's loop: convergence checks, then a trust-region step and the
 // candidate pose.  Loops over invalid steps (they need no new evaluation).  On return either
 // s->running == 0 or s->cand holds the pose to evaluate next.
-EA_HD inline void lm_prepare_next(LMState *s, const LMOptions *o) {
+EA_HD inline void lm_prepare_next(LMState *s, LMTrace *tr, const LMOptions *o) {
   for (;;) {
     if (s->iteration >= o->max_num_iterations) { lm_finish(s, 1, 4); return; }
     if (s->gradient_max_norm <= o->gradient_tolerance) { lm_finish(s, 0, 2); return; }
@@ -322,7 +330,7 @@ EA_HD inline void lm_prepare_next(LMState *s, const LMOptions *o) {
     }
     // HandleInvalidStep
     s->num_unsuccessful += 1;
-    lm_trace(s, s->iteration, 0.0, 0.0, 0.0, 0);
+    lm_trace(s, tr, s->iteration, 0.0, 0.0, 0.0, 0);
     if (++s->num_consecutive_invalid >= o->max_num_consecutive_invalid_steps) {
       lm_finish(s, 2, 7);
       return;
@@ -333,18 +341,18 @@ EA_HD inline void lm_prepare_next(LMState *s, const LMOptions *o) {
 }
 
 // after the evaluation at the initial pose
-EA_HD inline void lm_begin(LMState *s, const LMOptions *o, const double acc[kAccSlots]) {
+EA_HD inline void lm_begin(LMState *s, LMTrace *tr, const LMOptions *o, const double acc[kAccSlots]) {
   s->num_evals += 1;
   if (acc[kAccInvalid] > 0.0) { lm_finish(s, 2, 6); return; }
   lm_take_system(s, acc);
   if (o->jacobi_scaling)
     for (int i = 0; i < 6; ++i) s->S[i] = 1.0 / (1.0 + sqrt(s->A[6 * i + i]));
-  lm_trace(s, 0, 0.0, 0.0, 0.0, 1);
-  lm_prepare_next(s, o);
+  lm_trace(s, tr, 0, 0.0, 0.0, 0.0, 1);
+  lm_prepare_next(s, tr, o);
 }
 
 // after the evaluation at s->cand
-EA_HD inline void lm_advance(LMState *s, const LMOptions *o, const double acc[kAccSlots]) {
+EA_HD inline void lm_advance(LMState *s, LMTrace *tr, const LMOptions *o, const double acc[kAccSlots]) {
   s->num_evals += 1;
   const bool eval_ok = !(acc[kAccInvalid] > 0.0);
   const double cand_cost = eval_ok ? acc[kAccCost] : DBL_MAX;
@@ -352,13 +360,13 @@ EA_HD inline void lm_advance(LMState *s, const LMOptions *o, const double acc[kA
   for (int i = 0; i < 7; ++i) dx[i] = s->x[i] - s->cand[i];
   const double step_norm = norm_n(dx, 7);
   if (step_norm <= o->parameter_tolerance * (s->x_norm + o->parameter_tolerance)) {
-    lm_trace(s, s->iteration, 0.0, step_norm, 0.0, 0);
+    lm_trace(s, tr, s->iteration, 0.0, step_norm, 0.0, 0);
     lm_finish(s, 0, 3);
     return;
   }
   const double cost_change = s->cost - cand_cost;
   if (fabs(cost_change) <= o->function_tolerance * s->cost) {
-    lm_trace(s, s->iteration, cost_change, step_norm, 0.0, 0);
+    lm_trace(s, tr, s->iteration, cost_change, step_norm, 0.0, 0);
     lm_finish(s, 0, 1);
     return;
   }
@@ -380,7 +388,7 @@ EA_HD inline void lm_advance(LMState *s, const LMOptions *o, const double acc[kA
       s->radius = fmin(s->radius, o->max_trust_region_radius);
       s->dl_reuse = 0;
     }
-    lm_trace(s, s->iteration, cost_change, step_norm, rel, 1);
+    lm_trace(s, tr, s->iteration, cost_change, step_norm, rel, 1);
   } else {
     s->num_unsuccessful += 1;
     if (o->strategy == 0) {
@@ -391,9 +399,9 @@ EA_HD inline void lm_advance(LMState *s, const LMOptions *o, const double acc[kA
       s->radius *= 0.5;
       s->dl_reuse = 1;
     }
-    lm_trace(s, s->iteration, cost_change, step_norm, rel, 0);
+    lm_trace(s, tr, s->iteration, cost_change, step_norm, rel, 0);
   }
-  lm_prepare_next(s, o);
+  lm_prepare_next(s, tr, o);
 }
 
 }  // namespace ea

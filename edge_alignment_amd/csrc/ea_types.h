@@ -26,7 +26,8 @@ constexpr int kAccSlots = 32;
 constexpr int kImagePad = 3;      // replicated border texels on every side of the DT copy in HBM
 constexpr int kBlockThreads = 256;
 
-// One frame pair as the kernels see it.  Everything is in the problem dtype T (float/double).
+// One frame pair as the kernels see it.  Arrays are in the problem dtype T (float/double).
+// Scalars are kept in both precisions so the fp32 kernels never convert uniform values per point.
 struct ProblemDesc {
   const void *x, *y, *z;  // SoA edge points (frame A), n each
   const void *dt;         // padded DT image: (H + 2*pad) rows x pitch, texel (v,u) at [(v+pad)*pitch + u+pad]
@@ -34,19 +35,12 @@ struct ProblemDesc {
   int32_t W, H;           // u extent (Grid2D rows), v extent (Grid2D cols)
   int32_t pitch;          // elements per padded row
   double fx, fy, cx, cy;
-  double loss_a;
-  double z_guard, z_eps;
+  double loss_a, z_guard, z_eps;
+  float fxf, fyf, cxf, cyf;
+  float loss_af, z_guardf, z_epsf;
   int32_t loss_kind;
   int32_t rot_transposed;
-  int32_t tile_begin, tile_end;  // this problem's range in the tile list
-  int32_t pad_;
-};
-
-// A tile = a run of consecutive points of one problem handled by one workgroup.
-struct Tile {
-  int32_t problem;
-  int32_t start;  // first point
-  int32_t count;  // points in this tile
+  int32_t tile_begin, tile_end;  // this problem's rows in the partial-sum array (one per workgroup)
   int32_t pad_;
 };
 
@@ -56,8 +50,10 @@ struct PoseState {
   double q[4], t[3];
   double R[9];       // rotation actually applied (already transposed for the ROS flavour)
   double G[27];      // G[j] = d R / d delta_j, only read when unit_q == 0
+  float Rf[9], tf[3], Gf[27];
   int32_t unit_q;    // | |q|^2 - 1 | <= 1e-12  -> J_delta = 2 (R a) x g
-  int32_t active;    // 0: the problem's tiles return immediately (solve finished)
+  int32_t active;    // 0: the problem's workgroups return immediately (solve finished)
+  int32_t pad_[2];
 };
 
 // Result of one reduced evaluation

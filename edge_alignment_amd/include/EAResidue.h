@@ -1,0 +1,58 @@
+// EAResidue.h — drop-in for the cost functor of standalone/utils.h:38-99 (kuwt/edge_alignment).
+//
+// Same class name, constructor and static Create(...) as the reference, so the loop at
+// standalone/standalone_edge_align.cpp:267-274 compiles unchanged:
+//     ceres::CostFunction* cost = EAResidue::Create(fx,fy,cx,cy, X,Y,Z, interpolated_imb_disTrans);
+//     problem.AddResidualBlock(cost, new CauchyLoss(1.), b_quat_a, b_t_a);
+// The functor no longer computes anything per call through dual numbers: it carries the block's
+// constants, and ceres::Solve (facade, ceres/ceres.h) evaluates all blocks at once in the gfx950
+// kernels behind include/ea_hip.h.  operator()<double> is kept for host-side spot checks and
+// follows the reference text line by line (utils.h:48-80).
+#pragma once
+#include "ceres/ceres.h"
+
+class EAResidue {
+ public:
+  typedef ceres::BiCubicInterpolator<ceres::Grid2D<double, 1>> Interpolator;
+
+  EAResidue(const double fx, const double fy, const double cx, const double cy, const double a_Xx,
+            const double a_Xy, const double a_Xz, const Interpolator &__interpolated_a)
+      : interp_a(__interpolated_a), fx(fx), fy(fy), cx(cx), cy(cy), a_Xx(a_Xx), a_Xy(a_Xy), a_Xz(a_Xz) {}
+
+  // scalar evaluation (no derivatives) — host-side probe only
+  bool operator()(const double *const quat, const double *const t, double *residue) const {
+    const double w = quat[0], x = quat[1], y = quat[2], z = quat[3];
+    const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                         2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                         2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
+    const double bx = R[0] * a_Xx + R[1] * a_Xy + R[2] * a_Xz + t[0];
+    const double by = R[3] * a_Xx + R[4] * a_Xy + R[5] * a_Xz + t[1];
+    const double bz = R[6] * a_Xx + R[7] * a_Xy + R[8] * a_Xz + t[2];
+    if (bz < 0.01 && bz > -0.01) return false;
+    interp_a.Evaluate(fx * bx / bz + cx, fy * by / bz + cy, &residue[0]);
+    return true;
+  }
+
+  static ceres::CostFunction *Create(const double fx, const double fy, const double cx, const double cy,
+                                     const double a_Xx, const double a_Xy, const double a_Xz,
+                                     const Interpolator &__interpolated_a) {
+    return (new ceres::AutoDiffCostFunction<EAResidue, 1, 4, 3>(
+        new EAResidue(fx, fy, cx, cy, a_Xx, a_Xy, a_Xz, __interpolated_a)));
+  }
+
+  // read by the ceres:: facade when the problem is handed to the GPU
+  bool ea_describe(ceres::EABlockInfo *b) const {
+    b->fx = fx; b->fy = fy; b->cx = cx; b->cy = cy;
+    b->X = a_Xx; b->Y = a_Xy; b->Z = a_Xz;
+    b->grid_data = interp_a.grid().data();
+    b->grid_rows = interp_a.grid().num_rows();
+    b->grid_cols = interp_a.grid().num_cols();
+    b->z_guard = 0.01; b->z_eps = 0.0; b->rot_transposed = 0;  // utils.h:70-75
+    return true;
+  }
+
+ private:
+  const Interpolator &interp_a;
+  double fx, fy, cx, cy;
+  double a_Xx, a_Xy, a_Xz;
+};

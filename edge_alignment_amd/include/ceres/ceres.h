@@ -1,0 +1,296 @@
+// ceres/ceres.h — the slice of the ceres:: API that kuwt/edge_alignment touches on its hot path,
+// re-hosted on the MI355X C-ABI (include/ea_hip.h).  NOT Ceres Solver and not a general solver:
+// a source-compatibility facade so that the reference's "Setup non-linear Least Squares" blocks
+// (standalone/standalone_edge_align.cpp:256-293, src/SolveEA.cpp:124-216) compile and run
+// unchanged against libea_hip.so.
+//
+// What it understands: residual blocks created by EAResidue::Create(...) /
+// AutoDiffCostFunction<EAResidue,1,4,3> over ONE interpolator and ONE (q,t) pair, an optional
+// CauchyLoss / HuberLoss / TrivialLoss (NULL = trivial), QuaternionParameterization on q, and the
+// Solver::Options fields the reference sets.  Anything else is reported through
+// Summary::termination_type = FAILURE with a message; nothing is evaluated on the CPU.
+#pragma once
+
+#include <cmath>
+#include <cstdio>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "../../../include/ea_hip.h"
+#include "cubic_interpolation.h"
+#include "loss_function.h"
+
+namespace ceres {
+
+enum LinearSolverType { DENSE_NORMAL_CHOLESKY, DENSE_QR, SPARSE_NORMAL_CHOLESKY, DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR, CGNR };
+enum MinimizerType { LINE_SEARCH, TRUST_REGION };
+enum TrustRegionStrategyType { LEVENBERG_MARQUARDT, DOGLEG };
+enum DoglegType { TRADITIONAL_DOGLEG, SUBSPACE_DOGLEG };
+enum TerminationType { CONVERGENCE, NO_CONVERGENCE, FAILURE, USER_SUCCESS, USER_FAILURE };
+enum Ownership { DO_NOT_TAKE_OWNERSHIP, TAKE_OWNERSHIP };
+
+// ---- cost functions ------------------------------------------------------------------------
+// The facade never differentiates anything: a cost function is only a carrier of the per-block
+// constants (3-D point, intrinsics, interpolator) that the GPU kernels consume.
+struct EABlockInfo {
+  double fx, fy, cx, cy;
+  double X, Y, Z;
+  const double *grid_data;  // Grid2D view the functor samples at (r = u, c = v)
+  int grid_rows, grid_cols;
+  double z_guard, z_eps;    // functor flavour (standalone: 0.01, 0; ROS: 0, 0.001)
+  int rot_transposed;
+};
+
+class CostFunction {
+ public:
+  virtual ~CostFunction() {}
+  // true if this block is an edge-alignment block; fills info
+  virtual bool DescribeEdgeAlignmentBlock(EABlockInfo *) const { return false; }
+};
+
+// AutoDiffCostFunction<Functor, 1, 4, 3>: owns the functor like Ceres does.  The functor must
+// expose `bool ea_describe(ceres::EABlockInfo*) const` (edge_alignment_amd/include/EAResidue.h does).
+template <typename Functor, int kNumResiduals, int N0 = 0, int N1 = 0, int N2 = 0>
+class AutoDiffCostFunction : public CostFunction {
+ public:
+  explicit AutoDiffCostFunction(Functor *functor) : functor_(functor) {}
+  bool DescribeEdgeAlignmentBlock(EABlockInfo *info) const override {
+    if (kNumResiduals != 1 || N0 != 4 || N1 != 3 || N2 != 0) return false;
+    return functor_->ea_describe(info);
+  }
+  const Functor *functor() const { return functor_.get(); }
+
+ private:
+  std::unique_ptr<Functor> functor_;
+};
+
+// ---- local parameterisation -----------------------------------------------------------------
+class LocalParameterization {
+ public:
+  virtual ~LocalParameterization() {}
+  virtual bool IsQuaternion() const { return false; }
+};
+// q+ = [cos|d|, sin|d|/|d| d] (x) q  — applied on the device by the LM-step kernel
+class QuaternionParameterization : public LocalParameterization {
+ public:
+  bool IsQuaternion() const override { return true; }
+};
+
+// ---- problem --------------------------------------------------------------------------------
+class Problem {
+ public:
+  Problem() {}
+  ~Problem() {
+    for (auto *c : costs_) delete c;
+    for (auto *l : losses_) delete l;
+    for (auto *p : params_) delete p;
+  }
+  Problem(const Problem &) = delete;
+  Problem &operator=(const Problem &) = delete;
+
+  // standalone_edge_align.cpp:272  problem.AddResidualBlock(cost, new CauchyLoss(1.), q, t)
+  void AddResidualBlock(CostFunction *cost, LossFunction *loss, double *q, double *t) {
+    costs_.push_back(cost);
+    if (loss) losses_.insert(loss);  // one `new CauchyLoss(1.)` per block in the reference; shared ones are fine too
+    Block b;
+    b.ok = cost->DescribeEdgeAlignmentBlock(&b.info);
+    b.loss = loss;
+    b.q = q;
+    b.t = t;
+    blocks_.push_back(b);
+  }
+  // standalone_edge_align.cpp:277-278
+  void SetParameterization(double *values, LocalParameterization *p) {
+    params_.push_back(p);
+    if (p && p->IsQuaternion()) quat_param_on_ = values;
+  }
+  int NumResidualBlocks() const { return (int)blocks_.size(); }
+  int NumResiduals() const { return (int)blocks_.size(); }
+
+ private:
+  struct Block {
+    EABlockInfo info;
+    bool ok;
+    LossFunction *loss;
+    double *q, *t;
+  };
+  std::vector<Block> blocks_;
+  std::vector<CostFunction *> costs_;
+  std::unordered_set<LossFunction *> losses_;
+  std::vector<LocalParameterization *> params_;
+  double *quat_param_on_ = nullptr;
+  friend class ProblemAccess;
+};
+
+// ---- solver ---------------------------------------------------------------------------------
+struct Solver {
+  struct Options {
+    MinimizerType minimizer_type = TRUST_REGION;
+    TrustRegionStrategyType trust_region_strategy_type = LEVENBERG_MARQUARDT;
+    DoglegType dogleg_type = TRADITIONAL_DOGLEG;
+    LinearSolverType linear_solver_type = DENSE_QR;  // accepted; the 6x6 system is solved on the device
+    int max_num_iterations = 50;
+    double max_solver_time_in_seconds = 1e9;
+    int num_threads = 1;
+    double initial_trust_region_radius = 1e4;
+    double max_trust_region_radius = 1e16;
+    double min_trust_region_radius = 1e-32;
+    double min_relative_decrease = 1e-3;
+    double min_lm_diagonal = 1e-6;
+    double max_lm_diagonal = 1e32;
+    int max_num_consecutive_invalid_steps = 5;
+    double function_tolerance = 1e-6;
+    double gradient_tolerance = 1e-10;
+    double parameter_tolerance = 1e-8;
+    bool jacobi_scaling = true;
+    bool minimizer_progress_to_stdout = false;
+    // not part of Ceres: arithmetic type of the per-point evaluation and the GPU to use
+    int ea_dtype = EA_F64;
+    int ea_device = 0;
+  };
+  struct Summary {
+    TerminationType termination_type = FAILURE;
+    std::string message = "ceres::Solve was not called.";
+    double initial_cost = -1, final_cost = -1;
+    int num_successful_steps = -1, num_unsuccessful_steps = -1;
+    int num_residual_blocks = 0, num_residuals = 0;
+    int num_parameter_blocks = 2, num_parameters = 7, num_effective_parameters = 6;
+    double total_time_in_seconds = -1;
+    ea_summary detail{};
+
+    bool IsSolutionUsable() const { return termination_type == CONVERGENCE || termination_type == NO_CONVERGENCE; }
+    std::string BriefReport() const {
+      std::ostringstream o;
+      o << "edge_alignment_amd Report: Iterations: " << (num_successful_steps + num_unsuccessful_steps)
+        << ", Initial cost: " << initial_cost << ", Final cost: " << final_cost
+        << ", Termination: " << TermName();
+      return o.str();
+    }
+    std::string FullReport() const {
+      char buf[2048];
+      std::snprintf(buf, sizeof(buf),
+                    "\nSolver Summary (edge_alignment_amd, MI355X gfx950; ceres:: facade)\n\n"
+                    "Parameter blocks %26d\nParameters %32d\nEffective parameters %22d\n"
+                    "Residual blocks %27d\nResidual %34d\n\n"
+                    "Minimizer                        TRUST_REGION\n"
+                    "Linear solver          6x6 normal equations (device)\n\n"
+                    "Cost:\nInitial %35.6e\nFinal %37.6e\nChange %36.6e\n\n"
+                    "Minimizer iterations %22d\nSuccessful steps %26d\nUnsuccessful steps %24d\n\n"
+                    "Time (in seconds):\nTotal %37.4f\n\nTermination: %28s (%s)\n",
+                    num_parameter_blocks, num_parameters, num_effective_parameters, num_residual_blocks,
+                    num_residuals, initial_cost, final_cost, initial_cost - final_cost,
+                    num_successful_steps + num_unsuccessful_steps, num_successful_steps, num_unsuccessful_steps,
+                    total_time_in_seconds, TermName(), message.c_str());
+      return std::string(buf);
+    }
+    const char *TermName() const {
+      switch (termination_type) {
+        case CONVERGENCE: return "CONVERGENCE";
+        case NO_CONVERGENCE: return "NO_CONVERGENCE";
+        case FAILURE: return "FAILURE";
+        default: return "USER";
+      }
+    }
+  };
+};
+
+namespace internal {
+inline const char *WhyMessage(int why) {
+  switch (why) {
+    case EA_WHY_FUNCTION_TOL: return "Function tolerance reached.";
+    case EA_WHY_GRADIENT_TOL: return "Gradient tolerance reached.";
+    case EA_WHY_PARAMETER_TOL: return "Parameter tolerance reached.";
+    case EA_WHY_MAX_ITERATIONS: return "Maximum number of iterations reached.";
+    case EA_WHY_MIN_RADIUS: return "Minimum trust region radius reached.";
+    case EA_WHY_INITIAL_EVAL_FAILED: return "Initial residual and Jacobian evaluation failed.";
+    case EA_WHY_TOO_MANY_INVALID_STEPS: return "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps.";
+    case EA_WHY_EVAL_FAILED: return "Residual and Jacobian evaluation failed.";
+    default: return "";
+  }
+}
+}  // namespace internal
+
+// standalone_edge_align.cpp:286  ceres::Solve(options, &problem, &summary)
+inline void Solve(const Solver::Options &options, Problem *problem, Solver::Summary *summary);
+
+class ProblemAccess {  // keeps Problem's internals private to user code
+ public:
+  static void Run(const Solver::Options &options, Problem *problem, Solver::Summary *summary) {
+    Solver::Summary &s = *summary;
+    s = Solver::Summary();
+    const auto &blocks = problem->blocks_;
+    s.num_residual_blocks = s.num_residuals = (int)blocks.size();
+    auto fail = [&](const std::string &m) { s.termination_type = FAILURE; s.message = m; };
+    if (options.minimizer_type != TRUST_REGION) return fail("only TRUST_REGION is supported");
+    if (blocks.empty()) { s.termination_type = CONVERGENCE; s.message = "No residual blocks."; s.initial_cost = s.final_cost = 0; s.num_successful_steps = s.num_unsuccessful_steps = 0; return; }
+    const auto &b0 = blocks[0];
+    std::vector<double> xyz(3 * blocks.size());
+    for (size_t i = 0; i < blocks.size(); ++i) {
+      const auto &b = blocks[i];
+      if (!b.ok) return fail("residual block is not an EAResidue block (this facade only hosts the edge-alignment hot path)");
+      if (b.q != b0.q || b.t != b0.t) return fail("all residual blocks must share one (quaternion, translation) pair");
+      if (b.info.grid_data != b0.info.grid_data || b.info.grid_rows != b0.info.grid_rows || b.info.grid_cols != b0.info.grid_cols)
+        return fail("all residual blocks must sample the same interpolator");
+      if (b.info.fx != b0.info.fx || b.info.fy != b0.info.fy || b.info.cx != b0.info.cx || b.info.cy != b0.info.cy)
+        return fail("all residual blocks must share the camera intrinsics");
+      if (!SameLoss(b.loss, b0.loss)) return fail("all residual blocks must use the same loss function");
+      xyz[3 * i + 0] = b.info.X; xyz[3 * i + 1] = b.info.Y; xyz[3 * i + 2] = b.info.Z;
+    }
+    if (problem->quat_param_on_ != b0.q)
+      return fail("the quaternion block needs QuaternionParameterization (problem.SetParameterization)");
+    ea_camera cam = {b0.info.fx, b0.info.fy, b0.info.cx, b0.info.cy};
+    ea_problem *p = nullptr;
+    int rc = ea_problem_create(&p, &cam, options.ea_dtype, options.ea_device);
+    if (rc == EA_OK) rc = ea_problem_set_points(p, xyz.data(), (int64_t)blocks.size(), 3);
+    if (rc == EA_OK) rc = ea_problem_set_dt(p, b0.info.grid_data, b0.info.grid_rows, b0.info.grid_cols);
+    if (rc == EA_OK) rc = ea_problem_set_flavour(p, b0.info.z_guard, b0.info.z_eps, b0.info.rot_transposed);
+    if (rc == EA_OK) {
+      int kind = EA_LOSS_TRIVIAL; double a = 1.0;
+      if (b0.loss) { kind = b0.loss->ea_kind(); a = b0.loss->ea_scale(); }
+      rc = ea_problem_set_loss(p, kind, a);
+    }
+    ea_options o;
+    ea_default_options(&o);
+    o.max_num_iterations = options.max_num_iterations;
+    o.function_tolerance = options.function_tolerance;
+    o.gradient_tolerance = options.gradient_tolerance;
+    o.parameter_tolerance = options.parameter_tolerance;
+    o.initial_trust_region_radius = options.initial_trust_region_radius;
+    o.max_trust_region_radius = options.max_trust_region_radius;
+    o.min_trust_region_radius = options.min_trust_region_radius;
+    o.min_relative_decrease = options.min_relative_decrease;
+    o.min_lm_diagonal = options.min_lm_diagonal;
+    o.max_lm_diagonal = options.max_lm_diagonal;
+    o.max_num_consecutive_invalid_steps = options.max_num_consecutive_invalid_steps;
+    o.jacobi_scaling = options.jacobi_scaling ? 1 : 0;
+    o.strategy = options.trust_region_strategy_type == DOGLEG ? EA_STRATEGY_DOGLEG : EA_STRATEGY_LM;
+    o.minimizer_progress_to_stdout = options.minimizer_progress_to_stdout ? 1 : 0;
+    if (rc == EA_OK) rc = ea_solve(p, &o, b0.q, b0.t, &s.detail);  // q, t updated in place, like Ceres
+    if (p) ea_problem_destroy(p);
+    if (rc != EA_OK) return fail(std::string("libea_hip: ") + ea_last_error());
+    s.termination_type = s.detail.termination == EA_CONVERGENCE ? CONVERGENCE : (s.detail.termination == EA_NO_CONVERGENCE ? NO_CONVERGENCE : FAILURE);
+    s.message = internal::WhyMessage(s.detail.why);
+    s.initial_cost = s.detail.initial_cost;
+    s.final_cost = s.detail.final_cost;
+    s.num_successful_steps = s.detail.num_successful_steps;
+    s.num_unsuccessful_steps = s.detail.num_unsuccessful_steps;
+    s.total_time_in_seconds = s.detail.total_time_ms * 1e-3;
+  }
+
+ private:
+  static bool SameLoss(const LossFunction *a, const LossFunction *b) {
+    const int ka = a ? a->ea_kind() : EA_LOSS_TRIVIAL, kb = b ? b->ea_kind() : EA_LOSS_TRIVIAL;
+    if (ka != kb) return false;
+    if (ka == EA_LOSS_TRIVIAL) return true;
+    return a->ea_scale() == b->ea_scale();
+  }
+};
+
+inline void Solve(const Solver::Options &options, Problem *problem, Solver::Summary *summary) {
+  ProblemAccess::Run(options, problem, summary);
+}
+
+}  // namespace ceres

@@ -1,0 +1,43 @@
+// ros/EAResidue.h — drop-in for include/EAResidue.h:69-126 of kuwt/edge_alignment (ROS flavour).
+//
+// Keeps the constructor `EAResidue(lx,ly,lz, BiCubicInterpolator<Grid2D<double,2>>&, Matrix3d& K)`.
+// K is any type indexable as K(i,j) (Eigen::Matrix3d upstream).  The upstream functor is
+// numerically broken (it reads a single-channel image through a 2-channel grid
+// and writes two values into a 1-slot residual); this drop-in keeps its *intended* semantics as
+// kernel knobs — R applied transposed (:99-101), divisor z + 0.001 (:104-105), no z guard — and
+// samples channel 0 of the grid it is given.  It is an API surface, not a parity target.
+#pragma once
+#include "../ceres/ceres.h"
+
+class EAResidue {
+ public:
+  typedef ceres::BiCubicInterpolator<ceres::Grid2D<double, 2>> Interpolator2;
+  typedef ceres::BiCubicInterpolator<ceres::Grid2D<double, 1>> Interpolator1;
+
+  template <typename Mat3>
+  EAResidue(double lx, double ly, double lz, Interpolator2 &interpolated_a, Mat3 &K)
+      : lx(lx), ly(ly), lz(lz), data_(interpolated_a.grid().data()), rows_(interpolated_a.grid().num_rows()),
+        cols_(interpolated_a.grid().num_cols()) {
+    fx = K(0, 0); fy = K(1, 1); cx = K(0, 2); cy = K(1, 2);
+  }
+  template <typename Mat3>
+  EAResidue(double lx, double ly, double lz, Interpolator1 &interpolated_a, Mat3 &K)
+      : lx(lx), ly(ly), lz(lz), data_(interpolated_a.grid().data()), rows_(interpolated_a.grid().num_rows()),
+        cols_(interpolated_a.grid().num_cols()) {
+    fx = K(0, 0); fy = K(1, 1); cx = K(0, 2); cy = K(1, 2);
+  }
+
+  bool ea_describe(ceres::EABlockInfo *b) const {
+    b->fx = fx; b->fy = fy; b->cx = cx; b->cy = cy;
+    b->X = lx; b->Y = ly; b->Z = lz;
+    b->grid_data = data_; b->grid_rows = rows_; b->grid_cols = cols_;
+    b->z_guard = 0.0; b->z_eps = 0.001; b->rot_transposed = 1;
+    return true;
+  }
+
+ private:
+  double lx, ly, lz;
+  double fx, fy, cx, cy;
+  const double *data_;
+  int rows_, cols_;
+};

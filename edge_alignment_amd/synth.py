@@ -39,6 +39,7 @@ def rotation_angle_between(q1, q2):
 
 def random_segments(H, W, n_segments, rng, min_len=40.0, max_len=None):
     max_len = max_len or 0.35 * min(H, W)
+    min_len = min(min_len, 0.5 * max_len)
     p0 = np.stack([rng.uniform(8, W - 9, n_segments), rng.uniform(8, H - 9, n_segments)], axis=1)
     ang = rng.uniform(0, 2 * np.pi, n_segments)
     ln = rng.uniform(min_len, max_len, n_segments)

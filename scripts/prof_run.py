@@ -1,0 +1,22 @@
+"""Workload for rocprofv3 runs: a few fused evaluations + LM solves on C2, LM-1e5 and C5."""
+import sys, numpy as np
+sys.path.insert(0, '.')
+from edge_alignment_amd import capi, synth
+q0 = np.array([1.,0,0,0]); t0 = np.zeros(3)
+which = sys.argv[1] if len(sys.argv) > 1 else 'all'
+def run(cfg, dtype, loss, steps, solve=True, tune=None):
+    P = capi.Problem(*cfg['K'], dtype=dtype); P.set_points(cfg['xyz']); P.set_dt_grid(cfg['grid']); P.set_loss(*loss)
+    B = capi.Batch([P])
+    for k, v in (tune or {}).items(): B.set_tuning(k, v)
+    ms, _ = B.bench_eval(q0, t0, 5, steps, kernel_pass=False)
+    print('ms/step', ms/steps, 'tiles', B.info('num_tiles'), 'ppt', B.info('points_per_thread'))
+    if solve:
+        q, t, s = P.solve(q0, t0)
+        print('solve', s['why'], s['num_iterations'], s['total_time_ms'])
+    B.close(); P.close()
+if which in ('all', 'c2'):
+    run(synth.config_c2_twin(), capi.EA_F64, (capi.LOSS_CAUCHY, 1.0), 50)
+if which in ('all', 'lm'):
+    run(synth.config_c2_twin(seed=7, n_points=100000), capi.EA_F64, (capi.LOSS_CAUCHY, 1.0), 50)
+if which in ('all', 'c5'):
+    run(synth.config_c5(), capi.EA_F32, (capi.LOSS_TRIVIAL, 1.0), 50)

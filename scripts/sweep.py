@@ -1,0 +1,31 @@
+"""Tuning sweep of the fused evaluation kernel (timing via the C-ABI measurement hook)."""
+import sys, itertools, numpy as np
+sys.path.insert(0, '.')
+from edge_alignment_amd import capi, synth
+q0 = np.array([1.,0,0,0]); t0 = np.zeros(3)
+def sweep(name, cfgs, dtype, loss, grid, steps=100):
+    Ps = []
+    for cfg in cfgs:
+        P = capi.Problem(*cfg['K'], dtype=dtype); P.set_points(cfg['xyz']); P.set_dt_grid(cfg['grid']); P.set_loss(*loss); Ps.append(P)
+    B = capi.Batch(Ps); n = sum(P.num_points for P in Ps); m = len(Ps)
+    Q = np.tile(q0, (m, 1)); T = np.zeros((m, 3))
+    for use_lds, ppt, nt in grid:
+        B.set_tuning('use_lds', use_lds); B.set_tuning('points_per_thread', ppt); B.set_tuning('threads', nt)
+        ms, msk = B.bench_eval(Q, T, 10, steps)
+        print('%s lds %d ppt %d nt %4d -> rows %5d | step %.2f us kernel(ev) %.2f us | %.3e evals/s' % (
+            name, use_lds, B.info('points_per_thread'), B.info('threads'), B.info('num_tiles'), ms/steps*1e3, msk*1e3, n/(ms/steps*1e-3)), flush=True)
+    B.set_tuning('use_lds', 0); B.set_tuning('points_per_thread', -1); B.set_tuning('threads', -1)
+    q, t, s = B.solve(Q, T)
+    print('   solve(default tuning)', s[0]['why'], s[0]['num_iterations'], 'ms %.3f' % s[0]['total_time_ms'], 'us/iter %.1f' % (s[0]['total_time_ms']*1e3/max(1,s[0]['num_iterations'])))
+    B.close()
+    for P in Ps: P.close()
+g = list(itertools.product((0,1), (1,2), (256, 1024)))
+sweep('c2 f64', [synth.config_c2_twin()], capi.EA_F64, (capi.LOSS_CAUCHY,1.0), g)
+sweep('lm1e5 f64', [synth.config_c2_twin(seed=7, n_points=100000)], capi.EA_F64, (capi.LOSS_CAUCHY,1.0), g)
+c5 = synth.config_c5()
+g5 = list(itertools.product((0,1), (1,2,4), (256, 1024)))
+sweep('c5 f32', [c5], capi.EA_F32, (capi.LOSS_TRIVIAL,1.0), g5)
+sweep('c5 f64', [c5], capi.EA_F64, (capi.LOSS_TRIVIAL,1.0), g)
+c2s = [synth.config_c2_twin(seed=100+i) for i in range(32)]
+sweep('c4-like 32x50k f64', c2s, capi.EA_F64, (capi.LOSS_CAUCHY,1.0), g)
+sweep('c4-like 32x50k f32', c2s, capi.EA_F32, (capi.LOSS_CAUCHY,1.0), g5)

@@ -1,0 +1,52 @@
+// Host build of the product's trust-region state machine (edge_alignment_amd/csrc/ea_lm.h),
+// driven by an evaluator callback.  Test-only: lets the CPU suite compare the shipped LM logic
+// with the oracle's LM without a GPU.
+#include <cstring>
+
+#include "ea_lm.h"
+
+extern "C" {
+
+typedef void (*ea_eval_cb)(const double pose[7], double acc[32], void *user);
+
+struct ShimOut {
+  double x[7];
+  int iteration, termination, why, num_successful, num_unsuccessful, num_evals;
+  double final_cost;
+  double it_cost[ea::kTrace];
+  double it_radius[ea::kTrace];
+  int it_successful[ea::kTrace];
+};
+
+int ea_lm_host_solve(const ea::LMOptions *o, const double q[4], const double t[3], int rot_transposed,
+                     ea_eval_cb cb, void *user, ShimOut *out) {
+  ea::LMState s;
+  ea::LMTrace tr;
+  std::memset(&tr, 0, sizeof(tr));
+  ea::lm_init(&s, o, q, t, rot_transposed);
+  double acc[ea::kAccSlots];
+  int guard = o->max_num_iterations + 4;
+  while (s.running && guard-- > 0) {
+    cb(s.num_evals == 0 ? s.x : s.cand, acc, user);
+    if (s.num_evals == 0) ea::lm_begin(&s, &tr, o, acc);
+    else ea::lm_advance(&s, &tr, o, acc);
+  }
+  std::memcpy(out->x, s.x, sizeof(out->x));
+  out->iteration = s.iteration; out->termination = s.termination; out->why = s.why;
+  out->num_successful = s.num_successful; out->num_unsuccessful = s.num_unsuccessful;
+  out->num_evals = s.num_evals; out->final_cost = s.cost;
+  std::memcpy(out->it_cost, tr.it_cost, sizeof(out->it_cost));
+  std::memcpy(out->it_radius, tr.it_radius, sizeof(out->it_radius));
+  std::memcpy(out->it_successful, tr.it_successful, sizeof(out->it_successful));
+  return s.running ? -1 : 0;
+}
+
+void ea_lm_host_pose_state(const double x[7], int rot_transposed, double R[9], double G[27], int *unit_q) {
+  ea::PoseState ps;
+  ea::make_pose_state(x, rot_transposed, 1, &ps);
+  std::memcpy(R, ps.R, sizeof(ps.R));
+  std::memcpy(G, ps.G, sizeof(ps.G));
+  *unit_q = ps.unit_q;
+}
+
+}  // extern "C"

@@ -1,0 +1,116 @@
+"""The SHIPPED trust-region state machine (edge_alignment_amd/csrc/ea_lm.h, the code the
+device LM-step kernel runs) compiled for the host and driven by the oracle's evaluator:
+its iterates must coincide with the oracle's own LM restatement."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from edge_alignment_amd import synth
+
+
+class LMOptions(C.Structure):
+    _fields_ = [("max_num_iterations", C.c_int),
+                ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+                ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double), ("min_trust_region_radius", C.c_double),
+                ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+                ("max_num_consecutive_invalid_steps", C.c_int), ("jacobi_scaling", C.c_int), ("strategy", C.c_int)]
+
+
+KT = 128
+
+
+class ShimOut(C.Structure):
+    _fields_ = [("x", C.c_double * 7), ("iteration", C.c_int), ("termination", C.c_int), ("why", C.c_int),
+                ("num_successful", C.c_int), ("num_unsuccessful", C.c_int), ("num_evals", C.c_int),
+                ("final_cost", C.c_double), ("it_cost", C.c_double * KT), ("it_radius", C.c_double * KT),
+                ("it_successful", C.c_int * KT)]
+
+
+CB = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+
+
+def _opts(**kw):
+    o = LMOptions(50, 1e-6, 1e-10, 1e-8, 1e4, 1e16, 1e-32, 1e-3, 1e-6, 1e32, 5, 1, 0)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def _run(shim, P, oracle, X, q0, t0, **kw):
+    def cb(pose, acc, _):
+        x = np.array([pose[i] for i in range(7)])
+        e = P.eval(X, x[:4], x[4:])
+        k = 0
+        for a in range(6):
+            for b in range(a, 6):
+                acc[k] = e["JtJ"][a, b]; k += 1
+        for a in range(6):
+            acc[21 + a] = e["Jtr"][a]
+        acc[27] = e["cost"]
+        acc[28] = float(e["n_invalid"])
+        for i in range(29, 32):
+            acc[i] = 0.0
+    out = ShimOut()
+    o = _opts(**kw)
+    q0 = np.asarray(q0, dtype=np.float64); t0 = np.asarray(t0, dtype=np.float64)
+    shim.ea_lm_host_solve.argtypes = [C.POINTER(LMOptions), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, CB, C.c_void_p, C.POINTER(ShimOut)]
+    rc = shim.ea_lm_host_solve(C.byref(o), q0.ctypes.data_as(C.POINTER(C.c_double)), t0.ctypes.data_as(C.POINTER(C.c_double)), 0, CB(cb), None, C.byref(out))
+    assert rc == 0
+    return out
+
+
+@pytest.mark.parametrize("strategy", [0, 1])
+def test_shipped_lm_follows_oracle_iterates_on_bundled_pair(lm_host_shim, oracle, bundled_pair, strategy):
+    P = oracle.OracleProblem(bundled_pair["grids"][3], *bundled_pair["K"])
+    X = bundled_pair["aX"][:3, ::30].T.copy()
+    out = _run(lm_host_shim, P, oracle, X, [1, 0, 0, 0], [0, 0, 0], strategy=strategy)
+    q, t, s = P.solve(X, [1, 0, 0, 0], [0, 0, 0], strategy=strategy)
+    assert out.iteration == s["num_iterations"]
+    assert oracle.WHY[out.why] == s["why"] and out.termination == s["termination"]
+    assert out.num_successful == s["num_successful_steps"] and out.num_unsuccessful == s["num_unsuccessful_steps"]
+    x = np.array(out.x[:])
+    assert np.abs(x[:4] - q).max() < 1e-12 and np.abs(x[4:] - t).max() < 1e-12
+    n = s["num_iterations"] + 1
+    assert np.array(out.it_cost[:n]) == pytest.approx(s["it_cost"], rel=1e-12)
+    assert np.array(out.it_radius[:n]) == pytest.approx(s["it_radius"], rel=1e-12)
+    assert list(out.it_successful[:n]) == list(s["it_successful"])
+
+
+def test_shipped_lm_failure_and_limits(lm_host_shim, oracle):
+    pr = synth.make_problem(120, 160, 600, 40, 21, 130.0, 130.0, 79.5, 59.5,
+                            planted_q=synth.quat_from_axis_angle([1, 2, 3], np.deg2rad(1.0)), planted_t=(0.01, -0.005, 0.02), normalize=True)
+    P = oracle.OracleProblem(pr["grid"], *pr["K"])
+    X = pr["xyz"].copy()
+    out = _run(lm_host_shim, P, oracle, X, [1, 0, 0, 0], [0, 0, 0], max_num_iterations=3)
+    q, t, s = P.solve(X, [1, 0, 0, 0], [0, 0, 0], max_num_iterations=3)
+    assert oracle.WHY[out.why] == s["why"] == "max_iterations" and out.iteration == 3
+    assert np.abs(np.array(out.x[:4]) - q).max() < 1e-13
+    X[5] = [0.0, 0.0, 0.001]  # functor returns false -> FAILURE at iteration 0, pose untouched
+    out = _run(lm_host_shim, P, oracle, X, [1, 0, 0, 0], [0, 0, 0])
+    assert out.termination == 2 and oracle.WHY[out.why] == "initial_eval_failed" and out.num_evals == 1
+    assert list(out.x[:]) == [1, 0, 0, 0, 0, 0, 0]
+
+
+def test_pose_state_general_derivative_matches_jet(lm_host_shim, oracle):
+    # G_j of make_pose_state (used by the kernels for |q| != 1) against Jet autodiff
+    rng = np.random.default_rng(5)
+    g = rng.random((64, 48))
+    P = oracle.OracleProblem(g, 50.0, 55.0, 31.5, 23.5, loss=oracle.LOSS_TRIVIAL)
+    q = np.array([0.7, 0.3, -0.4, 0.2]) * 1.2
+    t = np.array([0.02, -0.01, 0.03])
+    x = np.concatenate([q, t])
+    R = np.zeros(9); G = np.zeros(27); u = C.c_int()
+    dp = C.POINTER(C.c_double)
+    lm_host_shim.ea_lm_host_pose_state(x.ctypes.data_as(dp), 0, R.ctypes.data_as(dp), G.ctypes.data_as(dp), C.byref(u))
+    assert u.value == 0
+    X = np.array([0.3, -0.2, 2.0])
+    ok, r, jq, jt = P.block_jet(q, t, X)
+    Pm = oracle.quat_plus_jacobian(q)
+    j_delta = jq @ Pm
+    G = G.reshape(3, 3, 3)
+    got = np.array([jt @ (G[j] @ X) for j in range(3)])
+    assert got == pytest.approx(j_delta, rel=1e-12, abs=1e-12)
+    x[:4] = q / np.linalg.norm(q)
+    lm_host_shim.ea_lm_host_pose_state(x.ctypes.data_as(dp), 0, R.ctypes.data_as(dp), G.ctypes.data_as(dp), C.byref(u))
+    assert u.value == 1

@@ -1,0 +1,237 @@
+"""Pins the CPU oracle with closed-form known answers and mutual agreement of independent
+derivations.  The reference has no tests and no golden vectors at this boundary:
+parity with Ceres itself is UNPINNED; these checks are what stands in for it."""
+import numpy as np
+import pytest
+
+from oracle import ea_numpy as en
+
+
+def _poly_grid(rows, cols, fn):
+    r = np.arange(rows, dtype=np.float64)[:, None]
+    c = np.arange(cols, dtype=np.float64)[None, :]
+    return np.ascontiguousarray(fn(r, c) + 0.0 * r * c)
+
+
+def test_bicubic_reproduces_quadratics_and_gradients(oracle):
+    # Catmull-Rom with central-difference tangents is exact for polynomials of degree <= 2
+    fn = lambda r, c: 0.3 + 0.7 * r - 0.2 * c + 0.05 * r * r - 0.03 * c * c + 0.011 * r * c
+    P = oracle.OracleProblem(_poly_grid(40, 30, fn), 1, 1, 0, 0)
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        r, c = rng.uniform(2, 36), rng.uniform(2, 26)
+        f, dr, dc = P.bicubic(r, c)
+        assert f == pytest.approx(fn(r, c), rel=1e-13, abs=1e-13)
+        assert dr == pytest.approx(0.7 + 0.1 * r + 0.011 * c, rel=1e-12, abs=1e-12)
+        assert dc == pytest.approx(-0.2 - 0.06 * c + 0.011 * r, rel=1e-12, abs=1e-12)
+
+
+def test_bicubic_returns_texel_at_integer_coordinates(oracle):
+    rng = np.random.default_rng(1)
+    g = rng.random((17, 23))
+    P = oracle.OracleProblem(g, 1, 1, 0, 0)
+    for r in range(17):
+        for c in range(23):
+            assert P.bicubic(float(r), float(c))[0] == g[r, c]
+
+
+def test_bicubic_clamps_to_edge_like_grid2d(oracle):
+    rng = np.random.default_rng(2)
+    g = rng.random((9, 11))
+    P = oracle.OracleProblem(g, 1, 1, 0, 0)
+    # far outside: every tap is the same border texel -> constant value, zero gradient
+    for (r, c, ri, ci) in [(-50.3, -7.7, 0, 0), (100.2, 300.9, 8, 10), (-9.0, 55.5, 0, 10), (1e12, -1e12, 8, 0)]:
+        f, dr, dc = P.bicubic(r, c)
+        # equal taps: the spline coefficients vanish up to one rounding of 3*p
+        assert f == pytest.approx(g[ri, ci], abs=1e-15) and abs(dr) < 1e-15 and abs(dc) < 1e-15
+    # straddling the border: equals interpolation on an explicitly edge-padded grid
+    gp = np.pad(g, 4, mode="edge")
+    Pp = oracle.OracleProblem(gp, 1, 1, 0, 0)
+    for (r, c) in [(-0.4, 3.3), (8.6, 10.2), (0.2, -0.9), (7.9, 10.99), (-1.5, -1.5), (9.7, 4.0)]:
+        a = P.bicubic(r, c)
+        b = Pp.bicubic(r + 4, c + 4)
+        assert a == pytest.approx(b, rel=0, abs=1e-15)
+
+
+def test_bicubic_matches_weight_form_numpy(oracle):
+    rng = np.random.default_rng(3)
+    g = rng.random((31, 29))
+    P = oracle.OracleProblem(g, 1, 1, 0, 0)
+    r = rng.uniform(-3, 33, 500)
+    c = rng.uniform(-3, 31, 500)
+    f, dr, dc = en.bicubic(g, r, c)
+    for i in range(500):
+        a = P.bicubic(r[i], c[i])
+        assert a == pytest.approx((f[i], dr[i], dc[i]), rel=0, abs=5e-14)
+
+
+def _random_problem(oracle, seed, loss=None, n=300):
+    rng = np.random.default_rng(seed)
+    g = rng.random((64, 48))
+    kw = {} if loss is None else dict(loss=loss[0], loss_a=loss[1])
+    P = oracle.OracleProblem(g, 50.0, 55.0, 31.5, 23.5, **kw)
+    X = np.c_[rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), rng.uniform(1, 4, n)]
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    q = np.array([0.95, 0.1, -0.2, 0.15])
+    q /= np.linalg.norm(q)
+    t = np.array([0.02, -0.01, 0.03])
+    return P, g, X, q, t
+
+
+def test_jet_autodiff_equals_analytic_row(oracle):
+    P, g, X, q, t = _random_problem(oracle, 4)
+    a = P.eval(X, q, t, oracle.JAC_ANALYTIC, materialize=True)
+    j = P.eval(X, q, t, oracle.JAC_JET, materialize=True)
+    scale = np.abs(a["raw_J"]).max()
+    assert np.abs(a["raw_r"] - j["raw_r"]).max() < 1e-14
+    assert np.abs(a["raw_J"] - j["raw_J"]).max() < 1e-13 * scale
+    assert np.abs(a["JtJ"] - j["JtJ"]).max() < 1e-12 * np.abs(a["JtJ"]).max()
+    assert a["cost"] == pytest.approx(j["cost"], rel=1e-14)
+
+
+def test_jet_equals_analytic_for_non_unit_quaternion(oracle):
+    # Ceres never normalises q; dR/dq * P(q) must hold for |q| != 1 too
+    P, g, X, q, t = _random_problem(oracle, 5)
+    q = q * 1.37
+    a = P.eval(X, q, t, oracle.JAC_ANALYTIC, materialize=True)
+    j = P.eval(X, q, t, oracle.JAC_JET, materialize=True)
+    assert np.abs(a["raw_J"] - j["raw_J"]).max() < 1e-13 * np.abs(a["raw_J"]).max()
+
+
+def test_numpy_unit_quaternion_identity_matches(oracle):
+    # independent derivation: d b / d delta = -2 [R a]x
+    for loss in [(oracle.LOSS_TRIVIAL, 1.0), (oracle.LOSS_CAUCHY, 1.0), (oracle.LOSS_CAUCHY, 0.3), (oracle.LOSS_HUBER, 0.4)]:
+        P, g, X, q, t = _random_problem(oracle, 6, loss=loss)
+        a = P.eval(X, q, t, oracle.JAC_ANALYTIC, materialize=True)
+        n = en.evaluate(g, (50.0, 55.0, 31.5, 23.5), X, q, t, loss_kind=loss[0], loss_a=loss[1])
+        assert np.abs(a["raw_J"] - n["raw_J"]).max() < 1e-12 * np.abs(a["raw_J"]).max()
+        assert np.abs(a["J"] - n["J"]).max() < 1e-12 * np.abs(a["J"]).max()
+        assert np.abs(a["r"] - n["r"]).max() < 1e-13
+        assert a["cost"] == pytest.approx(n["cost"], rel=1e-13)
+        assert np.abs(a["JtJ"] - n["JtJ"]).max() < 1e-12 * np.abs(a["JtJ"]).max()
+        assert np.abs(a["Jtr"] - n["Jtr"]).max() < 1e-12 * np.abs(a["Jtr"]).max()
+
+
+def test_analytic_row_matches_finite_differences_in_the_tangent_space(oracle):
+    # smooth grid so that central differences are accurate
+    fn = lambda r, c: np.sin(0.11 * r) * np.cos(0.07 * c) + 0.002 * r * c
+    P = oracle.OracleProblem(_poly_grid(64, 48, fn), 50.0, 55.0, 31.5, 23.5)
+    rng = np.random.default_rng(7)
+    q = np.array([0.97, 0.05, -0.1, 0.08]); q /= np.linalg.norm(q)
+    t = np.array([0.01, 0.02, -0.03])
+    h = 1e-6
+    for _ in range(20):
+        X = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.4, 0.4), rng.uniform(1.5, 3)])
+        ok, r0, j6 = P.block_analytic(q, t, X)
+        assert ok
+        for k in range(6):
+            d = np.zeros(6); d[k] = h
+            rp = P.block_analytic(oracle.quat_plus(q, d[:3]), t + d[3:], X)[1]
+            rm = P.block_analytic(oracle.quat_plus(q, -d[:3]), t - d[3:], X)[1]
+            assert (rp - rm) / (2 * h) == pytest.approx(j6[k], rel=2e-6, abs=2e-7)
+
+
+def test_quaternion_plus_and_its_jacobian(oracle):
+    q = np.array([0.9, 0.1, -0.3, 0.2]); q /= np.linalg.norm(q)
+    assert np.array_equal(oracle.quat_plus(q, np.zeros(3)), q)
+    d = np.array([0.01, -0.02, 0.03])
+    qp = oracle.quat_plus(q, d)
+    assert np.linalg.norm(qp) == pytest.approx(1.0, abs=1e-15)
+    # left update by a rotation of angle 2|d| about d
+    assert en.quat_to_R(qp) == pytest.approx(_axis_angle_R(d / np.linalg.norm(d), 2 * np.linalg.norm(d)) @ en.quat_to_R(q), abs=1e-14)
+    P = oracle.quat_plus_jacobian(q)
+    h = 1e-7
+    for k in range(3):
+        e = np.zeros(3); e[k] = h
+        fd = (oracle.quat_plus(q, e) - oracle.quat_plus(q, -e)) / (2 * h)
+        assert fd == pytest.approx(P[:, k], abs=1e-9)
+
+
+def _axis_angle_R(axis, ang):
+    x, y, z = axis
+    Kx = np.array([[0, -z, y], [z, 0, -x], [-y, x, 0]])
+    return np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+
+
+def test_functor_failure_inside_z_guard(oracle):
+    # ref: utils.h:70-73 — `return false` when -0.01 < b_z < 0.01
+    P, g, X, q, t = _random_problem(oracle, 8, n=10)
+    X[3] = [0.1, 0.1, 0.005]
+    X[7] = [0.1, 0.1, -0.0099]
+    e = P.eval(X, [1, 0, 0, 0], [0, 0, 0], oracle.JAC_JET, materialize=True)
+    assert e["n_invalid"] == 2 and np.isnan(e["r"][3]) and np.isnan(e["r"][7])
+    ok, _, _ = P.block_analytic([1, 0, 0, 0], [0, 0, 0], [0.1, 0.1, 0.01])
+    assert ok  # boundary value itself evaluates (strict inequalities)
+    q1, t1, s = P.solve(X, [1, 0, 0, 0], [0, 0, 0])
+    assert s["termination"] == oracle.FAILURE and s["why"] == "initial_eval_failed"
+    assert np.array_equal(q1, [1, 0, 0, 0]) and np.array_equal(t1, [0, 0, 0])
+
+
+def test_ros_flavour_knobs(oracle):
+    # include/EAResidue.h:86-118: R^T, divisor z + 0.001, no guard
+    rng = np.random.default_rng(9)
+    g = rng.random((64, 48))
+    P = oracle.OracleProblem(g, 50.0, 55.0, 31.5, 23.5, loss=oracle.LOSS_TRIVIAL, z_guard=0.0, z_eps=0.001, rot_transposed=True)
+    q = np.array([0.95, 0.1, -0.2, 0.15]); q /= np.linalg.norm(q)
+    t = np.array([0.02, -0.01, 0.03])
+    X = np.c_[rng.uniform(-1, 1, 50), rng.uniform(-1, 1, 50), rng.uniform(1, 4, 50)]
+    a = P.eval(X, q, t, oracle.JAC_ANALYTIC, materialize=True)
+    j = P.eval(X, q, t, oracle.JAC_JET, materialize=True)
+    assert np.abs(a["raw_J"] - j["raw_J"]).max() < 1e-13 * np.abs(a["raw_J"]).max()
+    b = X @ en.quat_to_R(q) + t  # R^T a + t
+    u = 50.0 * b[:, 0] / (b[:, 2] + 0.001) + 31.5
+    v = 55.0 * b[:, 1] / (b[:, 2] + 0.001) + 23.5
+    f, _, _ = en.bicubic(g, u, v)
+    assert np.abs(f - a["raw_r"]).max() < 1e-13
+
+
+def _planted(seed=11, n=4000, normalize=True):
+    from edge_alignment_amd import synth
+    q = synth.quat_from_axis_angle([1, 2, 3], np.deg2rad(1.0))
+    return synth.make_problem(120, 160, n, 40, seed, 130.0, 130.0, 79.5, 59.5, planted_q=q,
+                              planted_t=(0.01, -0.005, 0.02), normalize=normalize)
+
+
+def test_lm_recovers_planted_pose(oracle):
+    from edge_alignment_amd import synth
+    pr = _planted()
+    P = oracle.OracleProblem(pr["grid"], *pr["K"])
+    q, t, s = P.solve(pr["xyz"], [1, 0, 0, 0], [0, 0, 0])
+    assert s["termination"] == oracle.CONVERGENCE
+    assert synth.rotation_angle_between(q, pr["q_true"]) < 1e-6
+    assert np.linalg.norm(t - pr["t_true"]) < 1e-6
+    # monotone cost on successful steps
+    c = s["it_cost"]
+    assert np.all(np.diff(c) <= 1e-15)
+
+
+def test_lm_dense_qr_and_jet_follow_the_same_iterates(oracle):
+    # the Ceres-faithful configuration (Jet autodiff + DENSE_QR on the stacked system) and the
+    # normal-equation configuration are the same algorithm up to rounding
+    pr = _planted(seed=12, n=1500)
+    P = oracle.OracleProblem(pr["grid"], *pr["K"])
+    qa, ta, sa = P.solve(pr["xyz"], [1, 0, 0, 0], [0, 0, 0])
+    qb, tb, sb = P.solve(pr["xyz"], [1, 0, 0, 0], [0, 0, 0], jacobian_mode=oracle.JAC_JET, linear_solver=oracle.LIN_DENSE_QR)
+    assert sa["num_iterations"] == sb["num_iterations"] and sa["why"] == sb["why"]
+    assert np.abs(qa - qb).max() < 1e-10 and np.abs(ta - tb).max() < 1e-10
+
+
+def test_dogleg_strategy_converges_to_the_same_minimum(oracle):
+    # src/SolveEA.cpp:191-192 uses DOGLEG, 25 iterations
+    from edge_alignment_amd import synth
+    pr = _planted(seed=13, n=1500)
+    P = oracle.OracleProblem(pr["grid"], *pr["K"])
+    q, t, s = P.solve(pr["xyz"], [1, 0, 0, 0], [0, 0, 0], strategy=oracle.STRATEGY_DOGLEG, max_num_iterations=25)
+    assert s["termination"] == oracle.CONVERGENCE
+    assert synth.rotation_angle_between(q, pr["q_true"]) < 1e-5
+    assert np.linalg.norm(t - pr["t_true"]) < 1e-5
+
+
+def test_max_iterations_and_empty_problem(oracle):
+    pr = _planted(seed=14, n=800)
+    P = oracle.OracleProblem(pr["grid"], *pr["K"])
+    q, t, s = P.solve(pr["xyz"], [1, 0, 0, 0], [0, 0, 0], max_num_iterations=2)
+    assert s["why"] == "max_iterations" and s["termination"] == oracle.NO_CONVERGENCE and s["num_iterations"] == 2
+    q, t, s = P.solve(np.zeros((0, 3)), [1, 0, 0, 0], [0, 0, 0])
+    assert s["why"] == "gradient_tolerance" and s["num_iterations"] == 0 and s["initial_cost"] == 0.0
