@@ -187,6 +187,36 @@ def main():
                   "lm_pose_err_vs_planted": {"rad": err_rot, "m": err_t}}
         P2.close()
 
+    # Throughput-regime context for the same kernel (not the headline value): the C5 roofline-stress
+    # cloud and a C4-style batch of 32 C2-shaped frame pairs evaluated by one launch.
+    others = {}
+    if not args.no_extras and rank == 0 and world == 1:
+        from edge_alignment_amd import synth
+        def measure(problems, dtype, esz, loss):
+            Ps = []
+            for cfgx in problems:
+                Px = capi.Problem(*cfgx["K"], dtype=dtype, device=local_rank)
+                Px.set_points(cfgx["xyz"]); Px.set_dt_grid(cfgx["grid"]); Px.set_loss(*loss)
+                Ps.append(Px)
+            Bx = capi.Batch(Ps)
+            m = len(Ps)
+            Q = np.tile(q0, (m, 1)); T = np.zeros((m, 3))
+            ms, msk = Bx.bench_eval(Q, T, 10, 100)
+            npts = sum(Px.num_points for Px in Ps)
+            by = sum(algorithmic_bytes(Px.num_points, cfgx["image"].shape[0], cfgx["image"].shape[1], esz)
+                     for Px, cfgx in zip(Ps, problems))
+            res = {"evals_per_s": npts / (ms / 100 * 1e-3), "us_per_step": ms / 100 * 1e3, "kernel_us": msk * 1e3,
+                   "roofline_frac": by / (msk * 1e-3) / 1e9 / HBM_PEAK_GBS, "points": int(npts)}
+            Bx.close()
+            for Px in Ps:
+                Px.close()
+            return res
+        if args.workload != "c5":
+            others["c5_fp32_1e6pts_2048x1536"] = measure([synth.config_c5()], capi.EA_F32, 4, (capi.LOSS_TRIVIAL, 1.0))
+        batch = [synth.config_c2_twin(seed=100 + i) for i in range(32)]
+        others["batch32_c2_fp64"] = measure(batch, capi.EA_F64, 8, (capi.LOSS_CAUCHY, 1.0))
+        others["batch32_c2_fp32"] = measure(batch, capi.EA_F32, 4, (capi.LOSS_CAUCHY, 1.0))
+
     out = None
     if rank == 0:
         out = {"metric": "edge-point residual+Jacobian evals/sec", "value": value, "unit": "evals/s",
@@ -199,6 +229,8 @@ def main():
                           "lds_bytes": B.info("lds_bytes")},
                "roofline": roofline}
         out.update(extras)
+        if others:
+            out["other_workloads"] = others
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, loss)
         else:

@@ -28,7 +28,7 @@ EXPORTED = [
     "ea_problem_set_loss", "ea_problem_set_flavour", "ea_problem_num_points",
     "ea_eval", "ea_eval_points", "ea_cost", "ea_solve",
     "ea_batch_create", "ea_batch_destroy", "ea_batch_count", "ea_batch_eval", "ea_batch_solve",
-    "ea_batch_bench_eval", "ea_batch_set_tuning", "ea_batch_get_info",
+    "ea_batch_bench_eval", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
 ]
 
 
@@ -110,6 +110,7 @@ def load():
     L.ea_batch_bench_eval.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp, dp]
     L.ea_batch_set_tuning.argtypes = [vp, C.c_char_p, C.c_int]
     L.ea_batch_get_info.argtypes = [vp, C.c_char_p, i64p]
+    L.ea_selftest_wave_reduce.argtypes = [C.c_int, C.POINTER(C.c_float), dp, dp, C.POINTER(C.c_float)]
     _lib = L
     return L
 
@@ -296,3 +297,14 @@ class Batch:
         v = C.c_int64()
         _check(load().ea_batch_get_info(self._h, key.encode(), C.byref(v)))
         return v.value
+
+
+def selftest_wave_reduce(values, device=0):
+    """values: (32, 64) float32 -> (totals from the fp32 reduction, totals from the fp64 reduction, stages (30,64))"""
+    v = np.ascontiguousarray(values, dtype=np.float32)
+    assert v.shape == (32, 64)
+    o32, o64 = np.zeros(32), np.zeros(32)
+    st = np.zeros((30, 64), dtype=np.float32)
+    _check(load().ea_selftest_wave_reduce(device, v.ctypes.data_as(C.POINTER(C.c_float)), _dp(o32), _dp(o64),
+                                          st.ctypes.data_as(C.POINTER(C.c_float))))
+    return o32, o64, st

@@ -27,6 +27,8 @@ hipError_t launch_lm_step(const ProblemDesc *probs, int count, const double *par
                           LMState *states, LMTrace *traces, const LMOptions &opt, int *running_flags,
                           hipStream_t stream);
 hipError_t launch_pad_image(int dtype, const void *src, int H, int W, void *dst, int pitch, hipStream_t stream);
+hipError_t launch_selftest_reduce(const float *in, float *a, float *b, float *c, float *d, double *o32, double *o64,
+                                  hipStream_t stream);
 }  // namespace ea
 
 using namespace ea;
@@ -77,15 +79,17 @@ struct ea_batch {
   PoseState *d_poses = nullptr;
   double *d_partials = nullptr;
   EvalOut *d_out = nullptr;
+  unsigned char *d_lm_block = nullptr;  // [LMState x count | PoseState x count], one upload per solve
   LMState *d_states = nullptr;
   LMTrace *d_traces = nullptr;
-  int *d_running = nullptr;
+  int *d_progress = nullptr;            // device view of h_progress
   // pinned host mirrors
   PoseState *h_poses = nullptr;
   EvalOut *h_out = nullptr;
+  unsigned char *h_lm_block = nullptr;
   LMState *h_states = nullptr;
   LMTrace *h_traces = nullptr;
-  int *h_running = nullptr;
+  int *h_progress = nullptr;            // pinned, device-visible: [running x count | evaluations done x count]
   // tuning (-1 = heuristic)
   int t_lds_bytes = -1, t_ppt = -1, t_use_lds = -1, t_xcd = -1, t_nt = -1;
   int ppt = 1, nt = 256, lds_bytes = 0, xcd_remap = 1;
@@ -290,13 +294,14 @@ extern "C" int ea_problem_set_flavour(ea_problem *p, double z_guard, double z_ep
 // ---- batch --------------------------------------------------------------------------------------
 
 static void batch_free_device(ea_batch *b) {
-  (void)hipFree(b->d_probs); (void)hipFree(b->d_poses); (void)hipFree(b->d_traces);
-  (void)hipFree(b->d_partials); (void)hipFree(b->d_out); (void)hipFree(b->d_states); (void)hipFree(b->d_running);
-  (void)hipHostFree(b->h_poses); (void)hipHostFree(b->h_out); (void)hipHostFree(b->h_states);
-  (void)hipHostFree(b->h_traces); (void)hipHostFree(b->h_running);
-  b->d_probs = nullptr; b->d_poses = nullptr; b->d_partials = nullptr; b->d_traces = nullptr;
-  b->d_out = nullptr; b->d_states = nullptr; b->d_running = nullptr;
-  b->h_poses = nullptr; b->h_out = nullptr; b->h_states = nullptr; b->h_traces = nullptr; b->h_running = nullptr;
+  (void)hipFree(b->d_probs); (void)hipFree(b->d_lm_block); (void)hipFree(b->d_traces);
+  (void)hipFree(b->d_partials); (void)hipFree(b->d_out);
+  (void)hipHostFree(b->h_lm_block); (void)hipHostFree(b->h_out);
+  (void)hipHostFree(b->h_traces); (void)hipHostFree(b->h_progress);
+  b->d_probs = nullptr; b->d_poses = nullptr; b->d_partials = nullptr; b->d_traces = nullptr; b->d_lm_block = nullptr;
+  b->d_out = nullptr; b->d_states = nullptr; b->d_progress = nullptr;
+  b->h_poses = nullptr; b->h_out = nullptr; b->h_states = nullptr; b->h_traces = nullptr; b->h_progress = nullptr;
+  b->h_lm_block = nullptr;
 }
 
 extern "C" int ea_batch_create(ea_batch **out, ea_problem *const *problems, int count) {
@@ -317,17 +322,22 @@ extern "C" int ea_batch_create(ea_batch **out, ea_problem *const *problems, int 
   if (e != hipSuccess) { delete b; return fail(EA_ERR_HIP, hipGetErrorString(e)); }
   b->own_stream = true;
   const size_t c = (size_t)count;
+  const size_t lm_bytes = c * (sizeof(LMState) + sizeof(PoseState));
   e = hipMalloc(&b->d_probs, c * sizeof(ProblemDesc));
-  if (e == hipSuccess) e = hipMalloc(&b->d_poses, c * sizeof(PoseState));
+  if (e == hipSuccess) e = hipMalloc(&b->d_lm_block, lm_bytes);
   if (e == hipSuccess) e = hipMalloc(&b->d_out, c * sizeof(EvalOut));
-  if (e == hipSuccess) e = hipMalloc(&b->d_states, c * sizeof(LMState));
   if (e == hipSuccess) e = hipMalloc(&b->d_traces, c * sizeof(LMTrace));
-  if (e == hipSuccess) e = hipMalloc(&b->d_running, c * sizeof(int));
-  if (e == hipSuccess) e = hipHostMalloc(&b->h_poses, c * sizeof(PoseState));
+  if (e == hipSuccess) e = hipHostMalloc(&b->h_lm_block, lm_bytes);
   if (e == hipSuccess) e = hipHostMalloc(&b->h_out, c * sizeof(EvalOut));
-  if (e == hipSuccess) e = hipHostMalloc(&b->h_states, c * sizeof(LMState));
   if (e == hipSuccess) e = hipHostMalloc(&b->h_traces, c * sizeof(LMTrace));
-  if (e == hipSuccess) e = hipHostMalloc(&b->h_running, c * sizeof(int));
+  if (e == hipSuccess) e = hipHostMalloc(&b->h_progress, 2 * c * sizeof(int), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&b->d_progress), b->h_progress, 0);
+  if (e == hipSuccess) {
+    b->d_states = reinterpret_cast<LMState *>(b->d_lm_block);
+    b->d_poses = reinterpret_cast<PoseState *>(b->d_lm_block + c * sizeof(LMState));
+    b->h_states = reinterpret_cast<LMState *>(b->h_lm_block);
+    b->h_poses = reinterpret_cast<PoseState *>(b->h_lm_block + c * sizeof(LMState));
+  }
   if (e != hipSuccess) {
     batch_free_device(b);
     (void)hipStreamDestroy(b->stream);
@@ -525,28 +535,42 @@ extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, 
   for (int i = 0; i < count; ++i) {
     lm_init(&b->h_states[i], &lo, q + 4 * i, t + 3 * i, b->probs[i]->rot_transposed);
     host_pose_state(b->probs[i], q + 4 * i, t + 3 * i, &b->h_poses[i]);
-    b->h_running[i] = 1;
+    b->h_progress[i] = 1;          // running
+    b->h_progress[count + i] = 0;  // evaluations completed
   }
-  HIPCHK(hipMemcpyAsync(b->d_states, b->h_states, count * sizeof(LMState), hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(b->d_poses, b->h_poses, count * sizeof(PoseState), hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(b->d_running, b->h_running, count * sizeof(int), hipMemcpyHostToDevice, b->stream));
-  const int chunk = o.iterations_per_sync > 0 ? o.iterations_per_sync : 8;
-  // every (evaluate, step) pair consumes at least one iteration, so max+2 pairs always suffice
-  int budget = o.max_num_iterations + 2;
-  while (budget > 0) {
-    const int m = std::min(chunk, budget);
-    for (int k = 0; k < m; ++k) {
+  HIPCHK(hipMemcpyAsync(b->d_lm_block, b->h_lm_block, (size_t)count * (sizeof(LMState) + sizeof(PoseState)),
+                        hipMemcpyHostToDevice, b->stream));
+  // The loop runs on the device: each (evaluate, LM step) pair reads the pose the previous step
+  // published.  The step kernel reports progress into pinned host memory; the host only keeps a few
+  // pairs queued ahead of it and stops enqueueing when every problem has terminated (pairs that are
+  // already queued find `active == 0` and return at once).
+  const int ahead = o.iterations_per_sync > 0 ? o.iterations_per_sync : 3;
+  const int budget = o.max_num_iterations + 2;  // every pair consumes at least one iteration
+  int enq = 0;
+  unsigned spins = 0;
+  for (;;) {
+    bool any = false;
+    int done = 0;
+    for (int i = 0; i < count; ++i) {
+      any = any || (__atomic_load_n(&b->h_progress[i], __ATOMIC_ACQUIRE) != 0);
+      done = std::max(done, __atomic_load_n(&b->h_progress[count + i], __ATOMIC_ACQUIRE));
+    }
+    if (!any) break;
+    if (enq < budget && enq - done < ahead) {
       rc = batch_launch_eval(b);
       if (rc != EA_OK) return rc;
       HIPCHK(launch_lm_step(b->d_probs, count, b->d_partials, b->d_poses, b->d_states, b->d_traces, lo,
-                            b->d_running, b->stream));
+                            b->d_progress, b->stream));
+      ++enq;
+      spins = 0;
+    } else if (enq >= budget) {
+      HIPCHK(hipStreamSynchronize(b->stream));
+      break;
+    } else if ((++spins & 0x3fff) == 0) {
+      // nothing to enqueue and no progress for a while: make sure the stream is still healthy
+      hipError_t qe = hipStreamQuery(b->stream);
+      if (qe != hipSuccess && qe != hipErrorNotReady) return fail(EA_ERR_HIP, hipGetErrorString(qe));
     }
-    budget -= m;
-    HIPCHK(hipMemcpyAsync(b->h_running, b->d_running, count * sizeof(int), hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));
-    bool any = false;
-    for (int i = 0; i < count; ++i) any = any || (b->h_running[i] != 0);
-    if (!any) break;
   }
   HIPCHK(hipMemcpyAsync(b->h_states, b->d_states, count * sizeof(LMState), hipMemcpyDeviceToHost, b->stream));
   if (summaries || o.minimizer_progress_to_stdout)
@@ -702,4 +726,29 @@ extern "C" int ea_solve(ea_problem *p, const ea_options *opt, double q[4], doubl
   int rc = self_batch(p, &b);
   if (rc != EA_OK) return rc;
   return ea_batch_solve(b, opt, q, t, summary);
+}
+
+// ---- self-test of the wavefront reduction primitives (DPP row_mirror / row_half_mirror with bank
+// masks, v_permlane16/32_swap, quad_perm): in = 32 slots x 64 lanes (fp32); out32/out64 = the 32 wave
+// totals from the fp32 and fp64 reductions; stages (nullable) = 16+8+4+2 rows of 64 lanes.
+extern "C" int ea_selftest_wave_reduce(int device, const float *in, double *out32, double *out64, float *stages) {
+  if (!in || !out32 || !out64) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  int rc = check_device(device);
+  if (rc != EA_OK) return rc;
+  HIPCHK(hipSetDevice(device));
+  float *d_in = nullptr, *d_st = nullptr;
+  double *d_o = nullptr;
+  HIPCHK(hipMalloc(&d_in, 32 * 64 * sizeof(float)));
+  HIPCHK(hipMalloc(&d_st, 30 * 64 * sizeof(float)));
+  HIPCHK(hipMalloc(&d_o, 64 * sizeof(double)));
+  HIPCHK(hipMemcpy(d_in, in, 32 * 64 * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(d_o, 0, 64 * sizeof(double)));
+  hipError_t e = launch_selftest_reduce(d_in, d_st, d_st + 16 * 64, d_st + 24 * 64, d_st + 28 * 64, d_o, d_o + 32, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(out32, d_o, 32 * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(out64, d_o + 32, 32 * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && stages) e = hipMemcpy(stages, d_st, 30 * 64 * sizeof(float), hipMemcpyDeviceToHost);
+  (void)hipFree(d_in); (void)hipFree(d_st); (void)hipFree(d_o);
+  if (e != hipSuccess) return fail(EA_ERR_HIP, hipGetErrorString(e));
+  return EA_OK;
 }

@@ -272,6 +272,137 @@ __device__ __forceinline__ int wave_max_i32(int x) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp32 wavefront reduction with write-masked DPP adds and lane-swap instructions (gfx950).
+//
+// Same transposing idea as wave_reduce32, but the "keep my half, add the partner's copy" step is
+// two instructions and no select:
+//   t = lo + dpp(lo)                       all lanes
+//   t = hi + dpp(hi)   bank_mask / rows    only the lanes that keep the upper half
+// row_mirror pairs lane L with L^15 and the banks 2,3 (L&8) take the upper half; row_half_mirror
+// pairs L with L^7, banks 1,3 (L&4).  The cross-row steps use v_permlane16_swap / v_permlane32_swap:
+// swapping the odd rows (upper half-wave) of `lo` with the even rows (lower half-wave) of `hi` and
+// adding the two results is exactly the transposing step for L^16 (L^32).  Two plain quad_perm
+// adds finish the four lanes of a quad.  64 VALU instructions for 32 slots.
+// On return lanes with (L & 3) == 0 hold slots  j + 2*b5 + 4*b4 + 8*b2 + 16*b3  in v[j], j = 0, 1.
+//
+// The DPP adds are inline asm: hipcc cannot see their read-after-write wait states, so every block
+// starts with `s_nop 1` (VALU write -> DPP read of the same VGPR needs two wait states).
+
+#define EA_DPP_FULL(o, a, CTRL) "v_add_f32_dpp %" #o ", %" #a ", %" #a " " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+#define EA_DPP_MASK(o, a, CTRL, BM) "v_add_f32_dpp %" #o ", %" #a ", %" #a " " CTRL " row_mask:0xf bank_mask:" BM "\n\t"
+#define EA_DPP_LEVEL8(CTRL, BM)                                                                              \
+  "s_nop 1\n\t" EA_DPP_FULL(0, 8, CTRL) EA_DPP_FULL(1, 9, CTRL) EA_DPP_FULL(2, 10, CTRL) EA_DPP_FULL(3, 11, CTRL) \
+      EA_DPP_FULL(4, 12, CTRL) EA_DPP_FULL(5, 13, CTRL) EA_DPP_FULL(6, 14, CTRL) EA_DPP_FULL(7, 15, CTRL)         \
+          EA_DPP_MASK(0, 16, CTRL, BM) EA_DPP_MASK(1, 17, CTRL, BM) EA_DPP_MASK(2, 18, CTRL, BM)                 \
+              EA_DPP_MASK(3, 19, CTRL, BM) EA_DPP_MASK(4, 20, CTRL, BM) EA_DPP_MASK(5, 21, CTRL, BM)             \
+                  EA_DPP_MASK(6, 22, CTRL, BM) EA_DPP_MASK(7, 23, CTRL, BM)
+
+// o[i] = (lanes selected by BM ? hi[i] + partner(hi[i]) : lo[i] + partner(lo[i])), 8 pairs
+#define EA_DPP_CALL8(CTRL, BM, o, lo, hi)                                                                     \
+  asm volatile(EA_DPP_LEVEL8(CTRL, BM)                                                                         \
+               : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]) \
+               : "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(lo[4]), "v"(lo[5]), "v"(lo[6]), "v"(lo[7]),  \
+                 "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(hi[4]), "v"(hi[5]), "v"(hi[6]), "v"(hi[7]))
+
+// v_permlane16_swap / v_permlane32_swap through inline asm (with ROCm 7.2's hipcc the second result of
+// __builtin_amdgcn_permlane*_swap aliases the first).  Both operands are swapped in place; the
+// leading s_nop covers the VALU-write -> permlane-swap-read wait states hipcc cannot see inside asm.
+__device__ __forceinline__ void swap16_x4(float (&lo)[4], float (&hi)[4]) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
+               "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\ts_nop 0"
+               : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+}
+__device__ __forceinline__ void swap32_x2(float (&lo)[2], float (&hi)[2]) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 0"
+               : "+v"(lo[0]), "+v"(lo[1]), "+v"(hi[0]), "+v"(hi[1]));
+}
+
+// levels C and D of the fp32 reduction: 8 values -> 2 (see wave_reduce32_f32)
+__device__ __forceinline__ void swap_levels(const float (&b)[8], float (&c)[4], float (&d)[2]) {
+  float lo4[4] = {b[0], b[1], b[2], b[3]}, hi4[4] = {b[4], b[5], b[6], b[7]};
+  swap16_x4(lo4, hi4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) c[i] = lo4[i] + hi4[i];
+  float lo2[2] = {c[0], c[1]}, hi2[2] = {c[2], c[3]};
+  swap32_x2(lo2, hi2);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) d[i] = lo2[i] + hi2[i];
+}
+
+__device__ __forceinline__ int masked_slot(int lane, int j) {
+  return j + ((lane & 32) >> 4) + ((lane & 16) >> 2) + ((lane & 4) << 1) + ((lane & 8) << 1);
+}
+
+__device__ __forceinline__ void wave_reduce32_f32(float (&v)[32]) {
+  float a[16], b[8];
+  {
+    float *o = a, *lo = v, *hi = v + 16;
+    EA_DPP_CALL8("row_mirror", "0xc", o, lo, hi);
+  }
+  {
+    float *o = a + 8, *lo = v + 8, *hi = v + 24;
+    EA_DPP_CALL8("row_mirror", "0xc", o, lo, hi);
+  }
+  {
+    float *o = b, *lo = a, *hi = a + 8;
+    EA_DPP_CALL8("row_half_mirror", "0xa", o, lo, hi);
+  }
+  float c[4], d[2];
+  swap_levels(b, c, d);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    d[i] += lane_xchg<kDppQuadXor1>(d[i]);
+    d[i] += lane_xchg<kDppQuadXor2>(d[i]);
+  }
+  v[0] = d[0];
+  v[1] = d[1];
+}
+
+// self-test of the cross-lane primitives: one wave, lane L loads in[s*64+L] for slot s; dumps the
+// stages of wave_reduce32_f32 (a: 16x64, b: 8x64, c: 4x64, d: 2x64) and the fp64 butterfly result
+__global__ void ea_selftest_reduce_kernel(const float *in, float *stage_a, float *stage_b, float *stage_c,
+                                          float *stage_d, double *out_f32 /*32*/, double *out_f64 /*32*/) {
+  const int lane = threadIdx.x & 63;
+  float v[32];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) v[s] = in[s * 64 + lane];
+  double w[32];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) w[s] = (double)v[s];
+  float a[16], b[8];
+  { float *o = a, *lo = v, *hi = v + 16; EA_DPP_CALL8("row_mirror", "0xc", o, lo, hi); }
+  { float *o = a + 8, *lo = v + 8, *hi = v + 24; EA_DPP_CALL8("row_mirror", "0xc", o, lo, hi); }
+  { float *o = b, *lo = a, *hi = a + 8; EA_DPP_CALL8("row_half_mirror", "0xa", o, lo, hi); }
+  float c[4], d[2];
+  swap_levels(b, c, d);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) stage_a[i * 64 + lane] = a[i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) stage_b[i * 64 + lane] = b[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) stage_c[i * 64 + lane] = c[i];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) stage_d[i * 64 + lane] = d[i];
+  wave_reduce32_f32(v);
+  if ((lane & 3) == 0) {
+    out_f32[masked_slot(lane, 0)] = (double)v[0];
+    out_f32[masked_slot(lane, 1)] = (double)v[1];
+  }
+  wave_reduce32<double>(w, lane);
+  if (lane < 32) out_f64[butterfly_slot(lane)] = w[0];
+}
+
+template <typename T> using GPtr = const T __attribute__((address_space(1))) *;
+
+// four consecutive texels through a global-address-space pointer (merged into dwordx4 loads)
+template <typename T>
+__device__ __forceinline__ Row4<T> load_row4(GPtr<T> p) {
+  Row4<T> r;
+  r.p0 = p[0]; r.p1 = p[1]; r.p2 = p[2]; r.p3 = p[3];
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
 // fused evaluation kernel: residual + Jacobian + loss + JtJ/Jtr/cost partials, one row per workgroup
 //
 // grid = (8 * ceil(chunks/8), problems).  Workgroup (c, p) owns points [c*chunk, (c+1)*chunk) of
@@ -297,47 +428,58 @@ __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
   // XCD a contiguous run of chunks (neighbouring chunks read neighbouring image rows -> one L2).
   const int bx = blockIdx.x;
   const int c = xcd_remap ? (bx & 7) * chunks_per_xcd + (bx >> 3) : bx;
-  const ProblemDesc &pd = probs[blockIdx.y];
+  // descriptor and pose by value: every scalar load is issued here, behind one wait, instead of a
+  // chain of dependent loads at the points of use
+  const ProblemDesc pd = probs[blockIdx.y];
   const PoseState &ps = poses[blockIdx.y];
+  const int active = ps.active;
   const long long start = (long long)c * chunk;
-  if (start >= pd.n || !ps.active) return;
+  if (start >= pd.n || !active) return;
   const int count = min(chunk, (int)(pd.n - start));
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
 
-  const T *__restrict__ px = static_cast<const T *>(pd.x) + start;
-  const T *__restrict__ py = static_cast<const T *>(pd.y) + start;
-  const T *__restrict__ pz = static_cast<const T *>(pd.z) + start;
+  const GPtr<T> px = (GPtr<T>)(static_cast<const T *>(pd.x) + start);
+  const GPtr<T> py = (GPtr<T>)(static_cast<const T *>(pd.y) + start);
+  const GPtr<T> pz = (GPtr<T>)(static_cast<const T *>(pd.z) + start);
   const int pitch = pd.pitch;
-  const T *__restrict__ gimg = static_cast<const T *>(pd.dt) + (size_t)kImagePad * (size_t)pitch + kImagePad;
+  const GPtr<T> gimg = (GPtr<T>)(static_cast<const T *>(pd.dt) + (size_t)kImagePad * (size_t)pitch + kImagePad);
   const int loss_kind = pd.loss_kind;
   const T loss_a = Uni<T>::loss_a(pd);
 
-  // ---- phase 1: coalesced point loads, warp + projection
+  // ---- phase 1: coalesced point loads, warp + projection.  Lanes past the end of the chunk
+  // re-read its last point and lanes whose functor fails are moved to a harmless sample; both
+  // get weight 0 below, so the arithmetic needs no divergent branch.
   Proj<T> pr[PPT];
   T X[PPT], Y[PPT], Z[PPT];
+  bool valid[PPT];
+  int n_bad = 0;
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
     const int j = tid + k * NT;
-    pr[k].state = 0;
-    if (j < count) { X[k] = px[j]; Y[k] = py[j]; Z[k] = pz[j]; }
+    const int jj = min(j, count - 1);
+    X[k] = px[jj]; Y[k] = py[jj]; Z[k] = pz[jj];
   }
   int bb_u0 = 0x7fffffff, bb_u1 = -0x7fffffff, bb_v0 = 0x7fffffff, bb_v1 = -0x7fffffff;
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
-    const int j = tid + k * NT;
-    if (j < count) {
-      project_point<T>(pd, ps, X[k], Y[k], Z[k], pr[k]);
-      if (USE_LDS && pr[k].state == 1) {
-        bb_u0 = min(bb_u0, pr[k].iu); bb_u1 = max(bb_u1, pr[k].iu);
-        bb_v0 = min(bb_v0, pr[k].iv); bb_v1 = max(bb_v1, pr[k].iv);
-      }
+    const bool inb = tid + k * NT < count;
+    project_point<T>(pd, ps, X[k], Y[k], Z[k], pr[k]);
+    valid[k] = inb && pr[k].state == 1;
+    n_bad += (inb && pr[k].state == 2) ? 1 : 0;
+    if (!valid[k]) {
+      pr[k].iu = 0; pr[k].iv = 0; pr[k].fu = T(0); pr[k].fv = T(0);
+      pr[k].bx = T(0); pr[k].by = T(0); pr[k].iz = T(1);
+    }
+    if (USE_LDS && valid[k]) {
+      bb_u0 = min(bb_u0, pr[k].iu); bb_u1 = max(bb_u1, pr[k].iu);
+      bb_v0 = min(bb_v0, pr[k].iv); bb_v1 = max(bb_v1, pr[k].iv);
     }
   }
 
-  // ---- phase 2: footprint of the sub-chunk, staged through LDS when it fits
+  // ---- phase 2: footprint of the chunk, staged through LDS when it fits
   bool in_lds = false;
   int u0 = 0, v0 = 0, tw = 0;
   if (USE_LDS) {
@@ -355,13 +497,14 @@ __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
       V0 = min(V0, s_box[4 * w + 2]); V1 = max(V1, s_box[4 * w + 3]);
     }
     if (U1 >= U0) {
-      u0 = U0 - 1; v0 = V0 - 1;
-      tw = U1 - U0 + 4;
-      const int th = V1 - V0 + 4;
+      u0 = min(U0, 0) - 1; v0 = min(V0, 0) - 1;  // weight-0 lanes sample texel (0,0): keep it inside
+      U1 = max(U1, 0); V1 = max(V1, 0);
+      tw = U1 - (u0 + 1) + 4;
+      const int th = V1 - (v0 + 1) + 4;
       const long long area = (long long)tw * (long long)th;
       if (area <= (long long)lds_texels) {
         in_lds = true;
-        const T *__restrict__ img = gimg + (ptrdiff_t)v0 * pitch + u0;
+        const GPtr<T> img = gimg + ((ptrdiff_t)v0 * pitch + u0);
         const float inv_tw = 1.0f / (float)tw;
         for (int idx = tid; idx < (int)area; idx += NT) {
           int row = (int)((float)idx * inv_tw);
@@ -378,12 +521,7 @@ __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
   // ---- phase 3: sample, Jacobian, weights, accumulate
   T acc[28];
 #pragma unroll
-  for (int i = 0; i < 28; ++i) acc[i] = T(0);
-  int n_bad = 0;
-#pragma unroll
   for (int k = 0; k < PPT; ++k) {
-    if (pr[k].state == 2) n_bad += 1;
-    if (pr[k].state != 1) continue;
     T f, Fu, Fv;
     if (USE_LDS && in_lds) {
       const T *base = s_tile + (pr[k].iv - 1 - v0) * tw + (pr[k].iu - 1 - u0);
@@ -391,36 +529,46 @@ __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
       bicubic<T>(pr[k].fu, pr[k].fv,
                  [&](int l) { return *reinterpret_cast<const Row4<T> *>(base + l * stride); }, f, Fu, Fv);
     } else {
-      const T *base = gimg + (ptrdiff_t)(pr[k].iv - 1) * pitch + (pr[k].iu - 1);
+      const GPtr<T> base = gimg + ((ptrdiff_t)(pr[k].iv - 1) * pitch + (pr[k].iu - 1));
       bicubic<T>(pr[k].fu, pr[k].fv,
-                 [&](int l) { return *reinterpret_cast<const Row4<T> *>(base + (ptrdiff_t)l * pitch); }, f, Fu, Fv);
+                 [&](int l) { return load_row4<T>(base + (ptrdiff_t)l * pitch); }, f, Fu, Fv);
     }
     T J[6];
     jacobian_row<T>(pd, ps, pr[k], X[k], Y[k], Z[k], Fu, Fv, J);
     T rho, w;
     loss_eval<T>(loss_kind, loss_a, f * f, rho, w);
+    w = valid[k] ? w : T(0);
+    rho = valid[k] ? rho : T(0);
     const T wr = w * f;
     int s = 0;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
       const T wJa = w * J[a];
 #pragma unroll
-      for (int b = a; b < 6; ++b) { acc[s] = t_fma<T>(wJa, J[b], acc[s]); ++s; }
-      acc[kAccJtr + a] = t_fma<T>(J[a], wr, acc[kAccJtr + a]);
+      for (int b = a; b < 6; ++b) { acc[s] = k == 0 ? wJa * J[b] : t_fma<T>(wJa, J[b], acc[s]); ++s; }
+      acc[kAccJtr + a] = k == 0 ? J[a] * wr : t_fma<T>(J[a], wr, acc[kAccJtr + a]);
     }
-    acc[kAccCost] = t_fma<T>(T(0.5), rho, acc[kAccCost]);
+    acc[kAccCost] = k == 0 ? T(0.5) * rho : t_fma<T>(T(0.5), rho, acc[kAccCost]);
   }
 
-  // ---- phase 4: wavefront butterfly in the kernel's arithmetic type (a lane's accumulators and
+  // ---- phase 4: wavefront reduction in the kernel's arithmetic type (a lane's accumulators and
   // a wavefront's 64-lane sums are T; everything above a wavefront is fp64), then the
   // fixed-order cross-wave sum
   T v[32];
 #pragma unroll
   for (int i = 0; i < 28; ++i) v[i] = acc[i];
   v[28] = (T)n_bad; v[29] = T(0); v[30] = T(0); v[31] = T(0);
-  wave_reduce32<T>(v, lane);
   if (USE_LDS) __syncthreads();  // tile readers done before the scratch rows are written
-  if (lane < 32) s_red[wave * kAccSlots + butterfly_slot(lane)] = (double)v[0];
+  if constexpr (sizeof(T) == 4) {
+    wave_reduce32_f32(v);
+    if ((lane & 3) == 0) {
+      s_red[wave * kAccSlots + masked_slot(lane, 0)] = (double)v[0];
+      s_red[wave * kAccSlots + masked_slot(lane, 1)] = (double)v[1];
+    }
+  } else {
+    wave_reduce32<T>(v, lane);
+    if (lane < 32) s_red[wave * kAccSlots + butterfly_slot(lane)] = (double)v[0];
+  }
   __syncthreads();
   if (tid < kAccSlots) {
     double sum = 0.0;
@@ -473,7 +621,8 @@ __global__ __launch_bounds__(kBlockThreads) void ea_eval_points_kernel(
 // fixed-order reduction of a problem's tile partials -> 32 accumulators
 
 constexpr int kFoldThreads = 1024;  // plain fold: 32 slots x 32 strided groups
-constexpr int kLmThreads = 512;     // fold + scalar LM code (8 waves leave it 256 VGPRs)
+constexpr int kLmThreads = 256;     // fold + scalar LM code: 4 waves = one per SIMD, so the scalar code can keep
+                                    // its ~300 live registers without spilling to scratch
 
 template <int NTHREADS>
 __device__ __forceinline__ void reduce_tiles(const double *__restrict__ partials, int tile_begin,
@@ -516,7 +665,7 @@ __global__ __launch_bounds__(kFoldThreads) void ea_reduce_kernel(const ProblemDe
 __global__ __launch_bounds__(kLmThreads) void ea_lm_step_kernel(
     const ProblemDesc *__restrict__ probs, const double *__restrict__ partials,
     PoseState *__restrict__ poses, LMState *__restrict__ states, LMTrace *__restrict__ traces,
-    LMOptions opt, int *__restrict__ running_flags) {
+    LMOptions opt, int *__restrict__ progress /* pinned host: [running x n | evals x n] */) {
   __shared__ double s_part[(kLmThreads / 32) * kAccSlots];
   __shared__ double s_acc[kAccSlots];
   __shared__ LMState s_st;
@@ -538,7 +687,9 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_step_kernel(
     if (s_st.num_evals == 0) lm_begin(&s_st, traces + p, &opt, acc);
     else lm_advance(&s_st, traces + p, &opt, acc);
     make_pose_state(s_st.cand, s_st.rot_transposed, s_st.running, &s_ps);
-    running_flags[p] = s_st.running;
+    // system-scope release: the host polls these two words
+    __hip_atomic_store(progress + gridDim.x + p, s_st.num_evals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(progress + p, s_st.running, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
   {
@@ -617,11 +768,17 @@ hipError_t launch_reduce(const ProblemDesc *probs, int count, const double *part
 }
 
 hipError_t launch_lm_step(const ProblemDesc *probs, int count, const double *partials, PoseState *poses,
-                          LMState *states, LMTrace *traces, const LMOptions &opt, int *running_flags,
+                          LMState *states, LMTrace *traces, const LMOptions &opt, int *progress,
                           hipStream_t stream) {
   if (count <= 0) return hipSuccess;
   hipLaunchKernelGGL(ea_lm_step_kernel, dim3(count), dim3(kLmThreads), 0, stream, probs, partials, poses,
-                     states, traces, opt, running_flags);
+                     states, traces, opt, progress);
+  return hipGetLastError();
+}
+
+hipError_t launch_selftest_reduce(const float *in, float *a, float *b, float *c, float *d, double *o32, double *o64,
+                                  hipStream_t stream) {
+  hipLaunchKernelGGL(ea_selftest_reduce_kernel, dim3(1), dim3(64), 0, stream, in, a, b, c, d, o32, o64);
   return hipGetLastError();
 }
 

@@ -73,8 +73,10 @@ EA_HD inline double norm_n(const double *v, int n) {
 EA_HD inline void quat_plus(const double x[4], const double d[3], double out[4]) {
   const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
   if (nd > 0.0) {
-    const double s = sin(nd) / nd;
-    const double q0 = cos(nd), q1 = s * d[0], q2 = s * d[1], q3 = s * d[2];
+    double sn, cs;
+    sincos(nd, &sn, &cs);
+    const double s = sn / nd;
+    const double q0 = cs, q1 = s * d[0], q2 = s * d[1], q3 = s * d[2];
     out[0] = q0 * x[0] - q1 * x[1] - q2 * x[2] - q3 * x[3];
     out[1] = q0 * x[1] + q1 * x[0] + q2 * x[3] - q3 * x[2];
     out[2] = q0 * x[2] - q1 * x[3] + q2 * x[0] + q3 * x[1];
@@ -102,18 +104,24 @@ EA_HD inline void make_pose_state(const double x[7], int rot_transposed, int act
   R[0] = 1.0 - 2.0 * (qy * qy + qz * qz); R[1] = 2.0 * (qx * qy - w * qz); R[2] = 2.0 * (qx * qz + w * qy);
   R[3] = 2.0 * (qx * qy + w * qz); R[4] = 1.0 - 2.0 * (qx * qx + qz * qz); R[5] = 2.0 * (qy * qz - w * qx);
   R[6] = 2.0 * (qx * qz - w * qy); R[7] = 2.0 * (qy * qz + w * qx); R[8] = 1.0 - 2.0 * (qx * qx + qy * qy);
-  const double dR[4][9] = {
-      {0, -2 * qz, 2 * qy, 2 * qz, 0, -2 * qx, -2 * qy, 2 * qx, 0},
-      {0, 2 * qy, 2 * qz, 2 * qy, -4 * qx, -2 * w, 2 * qz, 2 * w, -4 * qx},
-      {-4 * qy, 2 * qx, 2 * w, 2 * qx, 0, 2 * qz, -2 * w, 2 * qz, -4 * qy},
-      {-4 * qz, -2 * w, 2 * qx, 2 * w, -4 * qz, 2 * qy, 2 * qx, 2 * qy, 0}};
-  const double P[12] = {-qx, -qy, -qz, w, qz, -qy, -qz, w, qx, qy, -qx, w};
-  for (int j = 0; j < 3; ++j)
-    for (int e = 0; e < 9; ++e) {
-      double s = 0.0;
-      for (int i = 0; i < 4; ++i) s += dR[i][e] * P[3 * i + j];
-      ps->G[9 * j + e] = s;
-    }
+  const double n2 = w * w + qx * qx + qy * qy + qz * qz;
+  const int unit_q = (fabs(n2 - 1.0) <= 1e-12 && !rot_transposed) ? 1 : 0;
+  if (!unit_q) {
+    const double dR[4][9] = {
+        {0, -2 * qz, 2 * qy, 2 * qz, 0, -2 * qx, -2 * qy, 2 * qx, 0},
+        {0, 2 * qy, 2 * qz, 2 * qy, -4 * qx, -2 * w, 2 * qz, 2 * w, -4 * qx},
+        {-4 * qy, 2 * qx, 2 * w, 2 * qx, 0, 2 * qz, -2 * w, 2 * qz, -4 * qy},
+        {-4 * qz, -2 * w, 2 * qx, 2 * w, -4 * qz, 2 * qy, 2 * qx, 2 * qy, 0}};
+    const double P[12] = {-qx, -qy, -qz, w, qz, -qy, -qz, w, qx, qy, -qx, w};
+    for (int j = 0; j < 3; ++j)
+      for (int e = 0; e < 9; ++e) {
+        double s = 0.0;
+        for (int i = 0; i < 4; ++i) s += dR[i][e] * P[3 * i + j];
+        ps->G[9 * j + e] = s;
+      }
+  } else {
+    for (int e = 0; e < 27; ++e) ps->G[e] = 0.0;  // never read: the kernels take the -2 [R a]x form
+  }
   for (int e = 0; e < 9; ++e) ps->R[e] = R[e];
   if (rot_transposed) {  // ref: include/EAResidue.h:99-101 applies R^T
     for (int a = 0; a < 3; ++a)
@@ -131,38 +139,47 @@ EA_HD inline void make_pose_state(const double x[7], int rot_transposed, int act
   for (int e = 0; e < 9; ++e) ps->Rf[e] = (float)ps->R[e];
   for (int e = 0; e < 27; ++e) ps->Gf[e] = (float)ps->G[e];
   for (int e = 0; e < 3; ++e) ps->tf[e] = (float)ps->t[e];
-  const double n2 = w * w + qx * qx + qy * qy + qz * qz;
-  ps->unit_q = (fabs(n2 - 1.0) <= 1e-12 && !rot_transposed) ? 1 : 0;
+  ps->unit_q = unit_q;
   ps->active = active;
 }
 
 // (A + diag(D^2)) y = g, 6x6 Cholesky.  Returns false when not positive definite / not finite.
+// One reciprocal per pivot; the triangular solves reuse them (this runs on a single GPU lane).
 EA_HD inline bool solve_spd6(const double A[36], const double D[6], const double g[6], double y[6]) {
-  double L[36];
-  for (int i = 0; i < 36; ++i) L[i] = 0.0;
-  for (int i = 0; i < 6; ++i) {
-    for (int j = 0; j <= i; ++j) {
-      double s = A[6 * i + j] + (i == j ? D[i] * D[i] : 0.0);
-      for (int k = 0; k < j; ++k) s -= L[6 * i + k] * L[6 * j + k];
-      if (i == j) {
-        if (!(s > 0.0)) return false;
-        L[6 * i + i] = sqrt(s);
-      } else {
-        L[6 * i + j] = s / L[6 * j + j];
-      }
+  double L[36], inv[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double s = A[6 * j + j] + D[j] * D[j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) s -= L[6 * j + k] * L[6 * j + k];
+    if (!(s > 0.0)) return false;
+    const double d = sqrt(s);
+    L[6 * j + j] = d;
+    inv[j] = 1.0 / d;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      double t = A[6 * i + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= L[6 * i + k] * L[6 * j + k];
+      L[6 * i + j] = t * inv[j];
     }
   }
   double z[6];
+#pragma unroll
   for (int i = 0; i < 6; ++i) {
     double s = g[i];
+#pragma unroll
     for (int k = 0; k < i; ++k) s -= L[6 * i + k] * z[k];
-    z[i] = s / L[6 * i + i];
+    z[i] = s * inv[i];
   }
+#pragma unroll
   for (int i = 5; i >= 0; --i) {
     double s = z[i];
+#pragma unroll
     for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * y[k];
-    y[i] = s / L[6 * i + i];
+    y[i] = s * inv[i];
   }
+#pragma unroll
   for (int i = 0; i < 6; ++i)
     if (!(fabs(y[i]) <= DBL_MAX)) return false;
   return true;
@@ -237,7 +254,8 @@ EA_HD inline bool lm_strategy_step(LMState *s, const LMOptions *o, const double 
       for (int i = 0; i < 6; ++i)
         s->diagonal[i] = fmin(fmax(As[6 * i + i], o->min_lm_diagonal), o->max_lm_diagonal);
     double D[6], y[6];
-    for (int i = 0; i < 6; ++i) D[i] = sqrt(s->diagonal[i] / s->radius);
+    const double inv_radius = 1.0 / s->radius;
+    for (int i = 0; i < 6; ++i) D[i] = sqrt(s->diagonal[i] * inv_radius);
     s->reuse_diagonal = 1;
     if (!solve_spd6(As, D, gs, y)) return false;
     for (int i = 0; i < 6; ++i) step[i] = -y[i];

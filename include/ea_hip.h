@@ -194,6 +194,12 @@ int ea_batch_bench_eval(ea_batch *b, const double *q, const double *t, int warmu
 int ea_batch_set_tuning(ea_batch *b, const char *key, int value);
 int ea_batch_get_info(const ea_batch *b, const char *key, int64_t *value);
 
+/* Self-test of the wavefront reduction primitives the kernels rely on (write-masked DPP adds,
+ * v_permlane16/32_swap, quad_perm): in = 32 slots x 64 lanes (fp32, slot-major); out32 / out64 = the 32
+ * wave totals from the fp32 and the fp64 reduction; stages (nullable, 30 x 64 floats) = the
+ * intermediate levels of the fp32 reduction. */
+int ea_selftest_wave_reduce(int device, const float *in, double *out32, double *out64, float *stages);
+
 #ifdef __cplusplus
 }
 #endif

@@ -391,3 +391,16 @@ def test_c3_pyramid_coarse_to_fine(hip):
         P.close()
     assert synth.rotation_angle_between(q, levels[0]["q_true"]) < 1e-4
     assert np.linalg.norm(t - levels[0]["t_true"]) < 1e-3
+
+
+def test_wave_reduce_primitives(hip):
+    """The cross-lane building blocks of the fused kernel on real hardware: write-masked DPP adds
+    (row_mirror / row_half_mirror), v_permlane16/32_swap, quad_perm — against exact integer sums."""
+    rng = np.random.default_rng(77)
+    V = np.floor(rng.random((32, 64)) * 4096).astype(np.float32)  # integers: every fp32 sum is exact
+    o32, o64, stages = hip.selftest_wave_reduce(V)
+    tot = V.astype(np.float64).sum(axis=1)
+    assert np.array_equal(o64, tot) and np.array_equal(o32, tot)
+    lanes = np.arange(64)
+    a = np.array([np.where(lanes & 8, V[i + 16] + V[i + 16][lanes ^ 15], V[i] + V[i][lanes ^ 15]) for i in range(16)])
+    assert np.array_equal(stages[:16], a)
