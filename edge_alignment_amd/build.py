@@ -5,7 +5,7 @@ import shutil
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["csrc/ea_kernels.hip", "csrc/ea_capi.hip"]
+SOURCES = ["csrc/ea_kernels.hip", "csrc/ea_preprocess.hip", "csrc/ea_capi.hip"]
 HEADERS = ["csrc/ea_types.h", "csrc/ea_lm.h", "../include/ea_hip.h"]
 LIB = os.path.join(_HERE, "lib", "libea_hip.so")
 

@@ -29,6 +29,8 @@ EXPORTED = [
     "ea_eval", "ea_eval_points", "ea_cost", "ea_solve",
     "ea_batch_create", "ea_batch_destroy", "ea_batch_count", "ea_batch_eval", "ea_batch_solve",
     "ea_batch_bench_eval", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
+    "ea_problem_set_ref_frame", "ea_problem_set_now_frame", "ea_problem_debug_now_frame",
+    "ea_problem_get_points", "ea_problem_get_dt",
 ]
 
 
@@ -111,6 +113,13 @@ def load():
     L.ea_batch_set_tuning.argtypes = [vp, C.c_char_p, C.c_int]
     L.ea_batch_get_info.argtypes = [vp, C.c_char_p, i64p]
     L.ea_selftest_wave_reduce.argtypes = [C.c_int, C.POINTER(C.c_float), dp, dp, C.POINTER(C.c_float)]
+    u8p, u16p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint16)
+    L.ea_problem_set_ref_frame.argtypes = [vp, u8p, u16p, C.c_int, C.c_int, C.c_double, C.c_int]
+    L.ea_problem_set_now_frame.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.ea_problem_debug_now_frame.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u8p, u8p,
+                                             C.POINTER(C.c_int32), C.POINTER(C.c_float)]
+    L.ea_problem_get_points.argtypes = [vp, dp, C.c_int64]
+    L.ea_problem_get_dt.argtypes = [vp, dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     _lib = L
     return L
 
@@ -201,6 +210,43 @@ class Problem:
 
     def set_dt_image_device(self, ptr, height, width):
         _check(load().ea_problem_set_dt_image_device(self._h, ptr, height, width))
+
+    def set_ref_frame(self, bgr, depth_u16, z_scaling=5000.0, threshold=35):
+        """get_aX on the GPU: bgr (H,W,3) uint8 as cv::imread returns it, depth (H,W) uint16"""
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        depth_u16 = np.ascontiguousarray(depth_u16, dtype=np.uint16)
+        H, W = depth_u16.shape
+        assert bgr.shape == (H, W, 3)
+        _check(load().ea_problem_set_ref_frame(self._h, bgr.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                               depth_u16.ctypes.data_as(C.POINTER(C.c_uint16)), H, W, z_scaling, threshold))
+
+    def set_now_frame(self, bgr, threshold=35, median=True, normalize=True, debug=False):
+        """get_distance_transform on the GPU, written straight into the problem's DT image"""
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        H, W = bgr.shape[:2]
+        u8 = C.POINTER(C.c_uint8)
+        if not debug:
+            _check(load().ea_problem_set_now_frame(self._h, bgr.ctypes.data_as(u8), H, W, threshold, int(median), int(normalize)))
+            return None
+        lap = np.zeros((H, W), np.uint8); mask = np.zeros((H, W), np.uint8)
+        cham = np.zeros((H, W), np.int32); dt = np.zeros((H, W), np.float32)
+        _check(load().ea_problem_debug_now_frame(self._h, bgr.ctypes.data_as(u8), H, W, threshold, int(median), int(normalize),
+                                                 lap.ctypes.data_as(u8), mask.ctypes.data_as(u8),
+                                                 cham.ctypes.data_as(C.POINTER(C.c_int32)), dt.ctypes.data_as(C.POINTER(C.c_float))))
+        return dict(lap=lap, mask=mask, chamfer=cham, dt=dt)
+
+    def get_points(self):
+        n = self.num_points
+        xyz = np.zeros((n, 3))
+        _check(load().ea_problem_get_points(self._h, _dp(xyz), n))
+        return xyz
+
+    def get_dt(self):
+        h, w = C.c_int(), C.c_int()
+        _check(load().ea_problem_get_dt(self._h, None, C.byref(h), C.byref(w)))
+        img = np.zeros((h.value, w.value))
+        _check(load().ea_problem_get_dt(self._h, _dp(img), None, None))
+        return img
 
     def set_loss(self, kind, a=1.0):
         _check(load().ea_problem_set_loss(self._h, kind, a))

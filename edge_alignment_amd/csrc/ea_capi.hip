@@ -29,6 +29,17 @@ hipError_t launch_lm_step(const ProblemDesc *probs, int count, const double *par
 hipError_t launch_pad_image(int dtype, const void *src, int H, int W, void *dst, int pitch, hipStream_t stream);
 hipError_t launch_selftest_reduce(const float *in, float *a, float *b, float *c, float *d, double *o32, double *o64,
                                   hipStream_t stream);
+// ea_preprocess.hip
+hipError_t launch_edge_strength(const uint8_t *bgr, int H, int W, uint8_t *gray, uint8_t *lap, hipStream_t s);
+hipError_t launch_threshold_median(const uint8_t *lap, int H, int W, int thr, int median, uint8_t *mask, hipStream_t s);
+hipError_t launch_chamfer(const uint8_t *mask, int H, int W, int *G, int *dist_fix, unsigned int *minmax, hipStream_t s);
+hipError_t launch_dt_store(int dtype, const int *dist_fix, int H, int W, const unsigned int *minmax, int normalize,
+                           void *dst, int pitch, float *plain, hipStream_t s);
+hipError_t launch_edge_count_scan(const uint8_t *lap, const uint16_t *depth, int H, int W, int thr, int *block_counts,
+                                  int *total, hipStream_t s);
+hipError_t launch_edge_scatter(int dtype, const uint8_t *lap, const uint16_t *depth, int H, int W, int thr,
+                               const int *block_offsets, double fx, double fy, double cx, double cy, double z_scaling,
+                               void *X, void *Y, void *Z, int capacity, hipStream_t s);
 }  // namespace ea
 
 using namespace ea;
@@ -64,6 +75,9 @@ struct ea_problem {
   uint64_t version = 1;  // bumped by every setter; batches rebuild their descriptors lazily
   ea_batch *self = nullptr;
   hipStream_t stream = nullptr;
+  // scratch for the frame pre-processing kernels (grown on demand, reused across frames)
+  unsigned char *ws = nullptr;
+  size_t ws_bytes = 0;
 };
 
 struct ea_batch {
@@ -178,6 +192,7 @@ extern "C" void ea_problem_destroy(ea_problem *p) {
   if (p->self) ea_batch_destroy(p->self);
   free_points(p);
   if (p->d_dt) (void)hipFree(p->d_dt);
+  if (p->ws) (void)hipFree(p->ws);
   delete p;
 }
 
@@ -750,5 +765,176 @@ extern "C" int ea_selftest_wave_reduce(int device, const float *in, double *out3
   if (e == hipSuccess && stages) e = hipMemcpy(stages, d_st, 30 * 64 * sizeof(float), hipMemcpyDeviceToHost);
   (void)hipFree(d_in); (void)hipFree(d_st); (void)hipFree(d_o);
   if (e != hipSuccess) return fail(EA_ERR_HIP, hipGetErrorString(e));
+  return EA_OK;
+}
+
+// ---- frame producers: raw images -> edge points / DT image, on the device -------
+
+namespace {
+struct WsCarver {
+  unsigned char *base;
+  size_t off = 0;
+  template <typename U> U *take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    U *r = reinterpret_cast<U *>(base + off);
+    off += n * sizeof(U);
+    return r;
+  }
+};
+}  // namespace
+
+static int ensure_ws(ea_problem *p, size_t bytes) {
+  if (p->ws_bytes >= bytes) return EA_OK;
+  if (p->ws) { (void)hipFree(p->ws); p->ws = nullptr; p->ws_bytes = 0; }
+  HIPCHK(hipMalloc(&p->ws, bytes));
+  p->ws_bytes = bytes;
+  return EA_OK;
+}
+
+static size_t frame_ws_bytes(int H, int W) {
+  const size_t np = (size_t)H * W;
+  return np * 3 + np * 2 + np * 3 /*gray, lap, mask*/ + np * 4 * 2 /*G, dist*/ + np * 4 /*plain float*/ +
+         ((np + 1023) / 1024 + 8) * 4 + 64 * 256;
+}
+
+extern "C" int ea_problem_set_ref_frame(ea_problem *p, const uint8_t *bgr, const uint16_t *depth, int height, int width,
+                                        double z_scaling, int threshold) {
+  if (!p || !bgr || !depth) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  if (height < 3 || width < 3 || (int64_t)height * width > 0x3fffffff) return fail(EA_ERR_INVALID_ARG, "image extent out of range");
+  if (!(z_scaling > 0.0)) return fail(EA_ERR_INVALID_ARG, "z_scaling must be > 0");
+  HIPCHK(hipSetDevice(p->device));
+  int rc = ensure_ws(p, frame_ws_bytes(height, width));
+  if (rc != EA_OK) return rc;
+  const size_t np = (size_t)height * width;
+  WsCarver ws{p->ws};
+  uint8_t *d_bgr = ws.take<uint8_t>(np * 3);
+  uint16_t *d_depth = ws.take<uint16_t>(np);
+  uint8_t *d_gray = ws.take<uint8_t>(np), *d_lap = ws.take<uint8_t>(np);
+  const int nblocks = (int)((np + 1023) / 1024);
+  int *d_counts = ws.take<int>(nblocks + 1);
+  int *d_total = d_counts + nblocks;
+  HIPCHK(hipMemcpyAsync(d_bgr, bgr, np * 3, hipMemcpyHostToDevice, nullptr));
+  HIPCHK(hipMemcpyAsync(d_depth, depth, np * 2, hipMemcpyHostToDevice, nullptr));
+  HIPCHK(launch_edge_strength(d_bgr, height, width, d_gray, d_lap, nullptr));
+  HIPCHK(launch_edge_count_scan(d_lap, d_depth, height, width, threshold, d_counts, d_total, nullptr));
+  int total = 0;
+  HIPCHK(hipMemcpy(&total, d_total, sizeof(int), hipMemcpyDeviceToHost));
+  free_points(p);
+  p->version++;
+  if (total > 0) {
+    const size_t esz = p->dtype == EA_F32 ? 4 : 8;
+    HIPCHK(hipMalloc(&p->d_x, (size_t)total * esz));
+    HIPCHK(hipMalloc(&p->d_y, (size_t)total * esz));
+    HIPCHK(hipMalloc(&p->d_z, (size_t)total * esz));
+    p->own_points = true;
+    HIPCHK(launch_edge_scatter(p->dtype, d_lap, d_depth, height, width, threshold, d_counts, p->cam.fx, p->cam.fy, p->cam.cx,
+                               p->cam.cy, z_scaling, p->d_x, p->d_y, p->d_z, total, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+  }
+  p->n = total;
+  return EA_OK;
+}
+
+static int run_dt(ea_problem *p, WsCarver &ws, const uint8_t *d_bgr, int height, int width, int threshold, int median,
+                  int normalize, uint8_t **lap_out, uint8_t **mask_out, int **dist_out, float **plain_out) {
+  const size_t np = (size_t)height * width;
+  uint8_t *d_gray = ws.take<uint8_t>(np), *d_lap = ws.take<uint8_t>(np), *d_mask = ws.take<uint8_t>(np);
+  int *d_G = ws.take<int>(np), *d_dist = ws.take<int>(np);
+  float *d_plain = ws.take<float>(np);
+  unsigned int *d_minmax = ws.take<unsigned int>(2);
+  HIPCHK(launch_edge_strength(d_bgr, height, width, d_gray, d_lap, nullptr));
+  HIPCHK(launch_threshold_median(d_lap, height, width, threshold, median, d_mask, nullptr));
+  HIPCHK(launch_chamfer(d_mask, height, width, d_G, d_dist, d_minmax, nullptr));
+  int rc = EA_OK;
+  {
+    if (p->d_dt) { (void)hipFree(p->d_dt); p->d_dt = nullptr; }
+    p->W = width; p->H = height;
+    p->pitch = (width + 2 * kImagePad + 3) & ~3;
+    const size_t esz = p->dtype == EA_F32 ? 4 : 8;
+    HIPCHK(hipMalloc(&p->d_dt, (size_t)p->pitch * (size_t)(height + 2 * kImagePad) * esz));
+  }
+  HIPCHK(launch_dt_store(p->dtype, d_dist, height, width, d_minmax, normalize, p->d_dt, p->pitch, d_plain, nullptr));
+  HIPCHK(hipDeviceSynchronize());
+  p->version++;
+  if (lap_out) *lap_out = d_lap;
+  if (mask_out) *mask_out = d_mask;
+  if (dist_out) *dist_out = d_dist;
+  if (plain_out) *plain_out = d_plain;
+  return rc;
+}
+
+extern "C" int ea_problem_set_now_frame(ea_problem *p, const uint8_t *bgr, int height, int width, int threshold,
+                                        int median, int normalize) {
+  if (!p || !bgr) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  if (height < 3 || width < 3 || height > 32768 || width > 32768) return fail(EA_ERR_INVALID_ARG, "image extent out of range");
+  HIPCHK(hipSetDevice(p->device));
+  int rc = ensure_ws(p, frame_ws_bytes(height, width));
+  if (rc != EA_OK) return rc;
+  WsCarver ws{p->ws};
+  uint8_t *d_bgr = ws.take<uint8_t>((size_t)height * width * 3);
+  HIPCHK(hipMemcpyAsync(d_bgr, bgr, (size_t)height * width * 3, hipMemcpyHostToDevice, nullptr));
+  return run_dt(p, ws, d_bgr, height, width, threshold, median, normalize, nullptr, nullptr, nullptr, nullptr);
+}
+
+// stages of the DT producer for parity checks: any output may be NULL
+extern "C" int ea_problem_debug_now_frame(ea_problem *p, const uint8_t *bgr, int height, int width, int threshold,
+                                          int median, int normalize, uint8_t *lap_out, uint8_t *mask_out,
+                                          int32_t *chamfer_fix_out, float *dt_out) {
+  if (!p || !bgr) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  if (height < 3 || width < 3 || height > 32768 || width > 32768) return fail(EA_ERR_INVALID_ARG, "image extent out of range");
+  HIPCHK(hipSetDevice(p->device));
+  int rc = ensure_ws(p, frame_ws_bytes(height, width));
+  if (rc != EA_OK) return rc;
+  WsCarver ws{p->ws};
+  const size_t np = (size_t)height * width;
+  uint8_t *d_bgr = ws.take<uint8_t>(np * 3);
+  HIPCHK(hipMemcpyAsync(d_bgr, bgr, np * 3, hipMemcpyHostToDevice, nullptr));
+  uint8_t *d_lap, *d_mask;
+  int *d_dist;
+  float *d_plain;
+  rc = run_dt(p, ws, d_bgr, height, width, threshold, median, normalize, &d_lap, &d_mask, &d_dist, &d_plain);
+  if (rc != EA_OK) return rc;
+  if (lap_out) HIPCHK(hipMemcpy(lap_out, d_lap, np, hipMemcpyDeviceToHost));
+  if (mask_out) HIPCHK(hipMemcpy(mask_out, d_mask, np, hipMemcpyDeviceToHost));
+  if (chamfer_fix_out) HIPCHK(hipMemcpy(chamfer_fix_out, d_dist, np * 4, hipMemcpyDeviceToHost));
+  if (dt_out) HIPCHK(hipMemcpy(dt_out, d_plain, np * 4, hipMemcpyDeviceToHost));
+  return EA_OK;
+}
+
+// read back what the problem holds in HBM: points as n x 3 doubles, DT as H x W doubles ([v][u])
+extern "C" int ea_problem_get_points(ea_problem *p, double *xyz, int64_t capacity) {
+  if (!p || (!xyz && p->n > 0)) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  if (capacity < p->n) return fail(EA_ERR_INVALID_ARG, "capacity smaller than the number of points");
+  if (p->n == 0) return EA_OK;
+  HIPCHK(hipSetDevice(p->device));
+  const size_t n = (size_t)p->n, esz = p->dtype == EA_F32 ? 4 : 8;
+  std::vector<unsigned char> buf(3 * n * esz);
+  HIPCHK(hipMemcpy(buf.data(), p->d_x, n * esz, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(buf.data() + n * esz, p->d_y, n * esz, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(buf.data() + 2 * n * esz, p->d_z, n * esz, hipMemcpyDeviceToHost));
+  for (int c = 0; c < 3; ++c)
+    for (size_t i = 0; i < n; ++i)
+      xyz[3 * i + c] = p->dtype == EA_F32 ? (double)reinterpret_cast<float *>(buf.data())[c * n + i]
+                                          : reinterpret_cast<double *>(buf.data())[c * n + i];
+  return EA_OK;
+}
+
+extern "C" int ea_problem_get_dt(ea_problem *p, double *image, int *height, int *width) {
+  if (!p) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  if (height) *height = p->H;
+  if (width) *width = p->W;
+  if (!image) return EA_OK;
+  if (!p->d_dt) return fail(EA_ERR_STATE, "distance-transform image not set");
+  HIPCHK(hipSetDevice(p->device));
+  const size_t esz = p->dtype == EA_F32 ? 4 : 8;
+  const size_t rows = (size_t)p->H + 2 * kImagePad;
+  std::vector<unsigned char> buf((size_t)p->pitch * rows * esz);
+  HIPCHK(hipMemcpy(buf.data(), p->d_dt, buf.size(), hipMemcpyDeviceToHost));
+  for (int v = 0; v < p->H; ++v)
+    for (int u = 0; u < p->W; ++u) {
+      const size_t idx = (size_t)(v + kImagePad) * p->pitch + (u + kImagePad);
+      image[(size_t)v * p->W + u] = p->dtype == EA_F32 ? (double)reinterpret_cast<float *>(buf.data())[idx]
+                                                       : reinterpret_cast<double *>(buf.data())[idx];
+    }
   return EA_OK;
 }

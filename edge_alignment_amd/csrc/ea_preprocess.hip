@@ -1,0 +1,302 @@
+// ea_preprocess.hip — the producers either side of the hot path, on the GPU:
+//   edge-point extractor  = get_aX                  ref: standalone/utils.cpp:201-281
+//   DT image producer     = get_distance_transform  ref: standalone/utils.cpp:38-83
+// so that a frame pair goes from raw images to a solved pose without the CPU touching a pixel.
+//
+// All of it is 8/16/32-bit integer work plus one float scaling — bit-exact against
+// oracle/preprocess_np.py (tests/test_gpu_preprocess.py).  OpenCV semantics restated:
+//   GaussianBlur 3x3 sigma 0 (8-bit): ([1 2 1]x[1 2 1] + 8) >> 4, reflect-101 border
+//   cvtColor RGB2GRAY (8-bit):       (4899 c0 + 9617 c1 + 1868 c2 + 8192) >> 14
+//   Laplacian CV_16S ksize 3:        [[2,0,2],[0,-8,0],[2,0,2]], reflect-101; convertScaleAbs = min(|x|,255)
+//   medianBlur 3 on a {0,255} image: majority of the 3x3 window, replicate border
+//   distanceTransform(DIST_L2, 3):   3x3 chamfer, a = 0.955, b = 1.3693 in 16.16 fixed point
+//   normalize(NORM_MINMAX, 0, 1):    float32  src * scale + shift
+//
+// The two-pass raster chamfer of OpenCV is inherently sequential; what it computes is the exact
+// shortest 8-connected path length, which has the closed form  a*max(dx,dy) + (b-a)*min(dx,dy).
+// For a fixed column x' the nearest feature row minimises it, so
+//   DT(x,y) = min_x'  f(|x-x'|, G(x',y)),   G = per-column distance to the nearest feature row,
+// which is embarrassingly parallel: a column scan for G, then a bounded search along each row.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ea_types.h"
+
+namespace ea {
+
+constexpr int kChamferA = 62587;   // CV_FLT_TO_FIX(0.955f, 16)
+constexpr int kChamferB = 89738;   // CV_FLT_TO_FIX(1.3693f, 16)
+constexpr int kChamferBig = 0x3fffffff;
+constexpr int kNoFeature = 1 << 28;
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  return min(max(i, 0), n - 1);
+}
+
+// blur (3 channels) + gray in one pass
+__global__ void ea_blur_gray_kernel(const uint8_t *__restrict__ bgr, int H, int W, uint8_t *__restrict__ gray) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
+  if (u >= W) return;
+  int acc[3] = {0, 0, 0};
+  const int wv[3] = {1, 2, 1};
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy) {
+    const int yy = reflect101(v + dy, H);
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int xx = reflect101(u + dx, W);
+      const uint8_t *p = bgr + ((size_t)yy * W + xx) * 3;
+      const int w = wv[dy + 1] * wv[dx + 1];
+      acc[0] += w * p[0]; acc[1] += w * p[1]; acc[2] += w * p[2];
+    }
+  }
+  const int c0 = (acc[0] + 8) >> 4, c1 = (acc[1] + 8) >> 4, c2 = (acc[2] + 8) >> 4;
+  gray[(size_t)v * W + u] = (uint8_t)((4899 * c0 + 9617 * c1 + 1868 * c2 + 8192) >> 14);
+}
+
+__global__ void ea_laplacian_abs_kernel(const uint8_t *__restrict__ gray, int H, int W, uint8_t *__restrict__ lap) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
+  if (u >= W) return;
+  const int ym = reflect101(v - 1, H), yp = reflect101(v + 1, H);
+  const int xm = reflect101(u - 1, W), xp = reflect101(u + 1, W);
+  const int s = 2 * ((int)gray[(size_t)ym * W + xm] + gray[(size_t)ym * W + xp] + gray[(size_t)yp * W + xm] +
+                     gray[(size_t)yp * W + xp]) - 8 * (int)gray[(size_t)v * W + u];
+  lap[(size_t)v * W + u] = (uint8_t)min(abs(s), 255);
+}
+
+// B = (lap > thr) ? 0 : 255, then 3x3 median with replicate border; on a two-valued image the
+// median is the majority.  mask: 0 = edge (DT source), 255 = background.
+__global__ void ea_threshold_median_kernel(const uint8_t *__restrict__ lap, int H, int W, int thr, int median,
+                                           uint8_t *__restrict__ mask) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
+  if (u >= W) return;
+  if (!median) {
+    mask[(size_t)v * W + u] = lap[(size_t)v * W + u] > thr ? 0 : 255;
+    return;
+  }
+  int bg = 0;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy) {
+    const int yy = min(max(v + dy, 0), H - 1);
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int xx = min(max(u + dx, 0), W - 1);
+      bg += lap[(size_t)yy * W + xx] > thr ? 0 : 1;
+    }
+  }
+  mask[(size_t)v * W + u] = bg >= 5 ? 255 : 0;
+}
+
+// G(x,y) = |y - y'| to the nearest feature pixel (mask == 0) of column x; kNoFeature if none
+__global__ void ea_column_nearest_kernel(const uint8_t *__restrict__ mask, int H, int W, int *__restrict__ G) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= W) return;
+  int d = kNoFeature;
+  for (int y = 0; y < H; ++y) {
+    d = mask[(size_t)y * W + x] == 0 ? 0 : min(d + 1, kNoFeature);
+    G[(size_t)y * W + x] = d;
+  }
+  d = kNoFeature;
+  for (int y = H - 1; y >= 0; --y) {
+    d = mask[(size_t)y * W + x] == 0 ? 0 : min(d + 1, kNoFeature);
+    G[(size_t)y * W + x] = min(G[(size_t)y * W + x], d);
+  }
+}
+
+__device__ __forceinline__ int chamfer_cost(int dx, int dy) {
+  const int mx = max(dx, dy), mn = min(dx, dy);
+  return kChamferA * mx + (kChamferB - kChamferA) * mn;
+}
+
+// One workgroup per image row: G row staged in LDS, every lane searches outwards from its own
+// column and stops as soon as a*dx alone exceeds the best distance found.
+__global__ void ea_chamfer_row_kernel(const int *__restrict__ G, int H, int W, int *__restrict__ dist_fix,
+                                      unsigned int *__restrict__ minmax /* [0]=min bits, [1]=max bits of dist*2^-16 as float */) {
+  extern __shared__ int s_g[];
+  const int y = blockIdx.x;
+  for (int x = threadIdx.x; x < W; x += blockDim.x) s_g[x] = G[(size_t)y * W + x];
+  __syncthreads();
+  float lmin = 3.0e38f, lmax = 0.0f;
+  for (int x = threadIdx.x; x < W; x += blockDim.x) {
+    int best = kChamferBig;
+    {
+      const int g = s_g[x];
+      if (g < kNoFeature) best = min(best, kChamferA * g);
+    }
+    for (int dx = 1; dx < W; ++dx) {
+      if ((long long)kChamferA * dx >= best) break;
+      const int xl = x - dx, xr = x + dx;
+      if (xl < 0 && xr >= W) break;
+      if (xl >= 0) {
+        const int g = s_g[xl];
+        if (g < kNoFeature) best = min(best, chamfer_cost(dx, g));
+      }
+      if (xr < W) {
+        const int g = s_g[xr];
+        if (g < kNoFeature) best = min(best, chamfer_cost(dx, g));
+      }
+    }
+    dist_fix[(size_t)y * W + x] = best;
+    const float f = (float)((double)best * (1.0 / 65536.0));
+    lmin = fminf(lmin, f); lmax = fmaxf(lmax, f);
+  }
+  // floats >= 0: the bit pattern orders like the value
+  atomicMin(&minmax[0], __float_as_uint(lmin));
+  atomicMax(&minmax[1], __float_as_uint(lmax));
+}
+
+// dist (16.16 fixed) -> float32 [-> min-max normalised] -> padded image of the problem dtype
+template <typename T>
+__global__ void ea_dt_store_kernel(const int *__restrict__ dist_fix, int H, int W, const unsigned int *__restrict__ minmax,
+                                   int normalize, T *__restrict__ dst, int pitch, float *__restrict__ plain /*nullable HxW*/) {
+  const int pu = blockIdx.x * blockDim.x + threadIdx.x, pv = blockIdx.y;  // padded coordinates
+  if (pu >= W + 2 * kImagePad) return;
+  const int u = min(max(pu - kImagePad, 0), W - 1), v = min(max(pv - kImagePad, 0), H - 1);
+  float f = (float)((double)dist_fix[(size_t)v * W + u] * (1.0 / 65536.0));
+  if (normalize) {
+    // cv::normalize(NORM_MINMAX, 0, 1) on CV_32F: scale/shift in double, applied in float
+    const double smin = (double)__uint_as_float(minmax[0]), smax = (double)__uint_as_float(minmax[1]);
+    const double scale = (smax - smin) > 2.220446049250313e-16 ? 1.0 / (smax - smin) : 0.0;
+    const double shift = 0.0 - smin * scale;
+    f = __fadd_rn(__fmul_rn(f, (float)scale), (float)shift);
+  }
+  dst[(size_t)pv * pitch + pu] = (T)f;
+  if (plain && pu >= kImagePad && pu < W + kImagePad && pv >= kImagePad && pv < H + kImagePad)
+    plain[(size_t)(pv - kImagePad) * W + (pu - kImagePad)] = f;
+}
+
+// ---- edge points: flag, count per block, scan, scatter (raster order preserved) ----------------
+
+constexpr int kScanBlock = 1024;
+
+__device__ __forceinline__ bool edge_flag(const uint8_t *lap, const uint16_t *depth, size_t i, int thr) {
+  return lap[i] > thr && depth[i] > 0;  // ref: utils.cpp:258-262  grad > threshold && Z > 0
+}
+
+__global__ void ea_edge_count_kernel(const uint8_t *__restrict__ lap, const uint16_t *__restrict__ depth, int npix,
+                                     int thr, int *__restrict__ block_counts) {
+  __shared__ int s_cnt[kScanBlock / 64];
+  const int i = blockIdx.x * kScanBlock + threadIdx.x;
+  const bool f = i < npix && edge_flag(lap, depth, (size_t)i, thr);
+  const unsigned long long m = __ballot(f);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int w = 0; w < kScanBlock / 64; ++w) s += s_cnt[w];
+    block_counts[blockIdx.x] = s;
+  }
+}
+
+// exclusive scan of the block counts by one workgroup (sequential over chunks of 1024)
+__global__ void ea_edge_scan_kernel(int *__restrict__ block_counts, int nblocks, int *__restrict__ total) {
+  __shared__ int s_buf[kScanBlock];
+  __shared__ int s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nblocks; base += kScanBlock) {
+    const int i = base + threadIdx.x;
+    const int v = i < nblocks ? block_counts[i] : 0;
+    s_buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < kScanBlock; off <<= 1) {  // Hillis-Steele inclusive scan
+      const int t = threadIdx.x >= off ? s_buf[threadIdx.x - off] : 0;
+      __syncthreads();
+      s_buf[threadIdx.x] += t;
+      __syncthreads();
+    }
+    const int incl = s_buf[threadIdx.x], carry = s_carry;
+    if (i < nblocks) block_counts[i] = carry + incl - v;
+    __syncthreads();
+    if (threadIdx.x == kScanBlock - 1) s_carry = carry + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = s_carry;
+}
+
+template <typename T>
+__global__ void ea_edge_scatter_kernel(const uint8_t *__restrict__ lap, const uint16_t *__restrict__ depth, int H, int W,
+                                       int thr, const int *__restrict__ block_offsets, double fx, double fy, double cx,
+                                       double cy, double z_scaling, T *__restrict__ X, T *__restrict__ Y, T *__restrict__ Z,
+                                       int capacity) {
+  __shared__ int s_cnt[kScanBlock / 64];
+  const int npix = H * W;
+  const int i = blockIdx.x * kScanBlock + threadIdx.x;
+  const bool f = i < npix && edge_flag(lap, depth, (size_t)i, thr);
+  const unsigned long long m = __ballot(f);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) s_cnt[wave] = __popcll(m);
+  __syncthreads();
+  if (!f) return;
+  int off = block_offsets[blockIdx.x];
+  for (int w = 0; w < wave; ++w) off += s_cnt[w];
+  off += __popcll(m & ((1ull << lane) - 1ull));
+  if (off >= capacity) return;
+  const int v = i / W, u = i - v * W;
+  // ref: utils.cpp:238-240 — Z = depth / factor; X = (u - cx) * Z / fx; Y = (v - cy) * Z / fy  (double)
+  const double z = (double)depth[i] / z_scaling;
+  const double x = __dmul_rn((double)u - cx, z) / fx;
+  const double y = __dmul_rn((double)v - cy, z) / fy;
+  X[off] = (T)x; Y[off] = (T)y; Z[off] = (T)z;
+}
+
+// ---- launchers ----------------------------------------------------------------------------------
+
+hipError_t launch_edge_strength(const uint8_t *bgr, int H, int W, uint8_t *gray, uint8_t *lap, hipStream_t s) {
+  dim3 block(256), grid((W + 255) / 256, H);
+  hipLaunchKernelGGL(ea_blur_gray_kernel, grid, block, 0, s, bgr, H, W, gray);
+  hipLaunchKernelGGL(ea_laplacian_abs_kernel, grid, block, 0, s, gray, H, W, lap);
+  return hipGetLastError();
+}
+
+hipError_t launch_threshold_median(const uint8_t *lap, int H, int W, int thr, int median, uint8_t *mask, hipStream_t s) {
+  dim3 block(256), grid((W + 255) / 256, H);
+  hipLaunchKernelGGL(ea_threshold_median_kernel, grid, block, 0, s, lap, H, W, thr, median, mask);
+  return hipGetLastError();
+}
+
+hipError_t launch_chamfer(const uint8_t *mask, int H, int W, int *G, int *dist_fix, unsigned int *minmax, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(minmax, 0xff, sizeof(unsigned int), s);  // min slot = max uint
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(minmax + 1, 0, sizeof(unsigned int), s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(ea_column_nearest_kernel, dim3((W + 255) / 256), dim3(256), 0, s, mask, H, W, G);
+  hipLaunchKernelGGL(ea_chamfer_row_kernel, dim3(H), dim3(256), (size_t)W * sizeof(int), s, G, H, W, dist_fix, minmax);
+  return hipGetLastError();
+}
+
+hipError_t launch_dt_store(int dtype, const int *dist_fix, int H, int W, const unsigned int *minmax, int normalize,
+                           void *dst, int pitch, float *plain, hipStream_t s) {
+  dim3 block(256), grid((W + 2 * kImagePad + 255) / 256, H + 2 * kImagePad);
+  if (dtype == 1)
+    hipLaunchKernelGGL((ea_dt_store_kernel<float>), grid, block, 0, s, dist_fix, H, W, minmax, normalize, (float *)dst, pitch, plain);
+  else
+    hipLaunchKernelGGL((ea_dt_store_kernel<double>), grid, block, 0, s, dist_fix, H, W, minmax, normalize, (double *)dst, pitch, plain);
+  return hipGetLastError();
+}
+
+hipError_t launch_edge_count_scan(const uint8_t *lap, const uint16_t *depth, int H, int W, int thr, int *block_counts,
+                                  int *total, hipStream_t s) {
+  const int npix = H * W, nblocks = (npix + kScanBlock - 1) / kScanBlock;
+  hipLaunchKernelGGL(ea_edge_count_kernel, dim3(nblocks), dim3(kScanBlock), 0, s, lap, depth, npix, thr, block_counts);
+  hipLaunchKernelGGL(ea_edge_scan_kernel, dim3(1), dim3(kScanBlock), 0, s, block_counts, nblocks, total);
+  return hipGetLastError();
+}
+
+hipError_t launch_edge_scatter(int dtype, const uint8_t *lap, const uint16_t *depth, int H, int W, int thr,
+                               const int *block_offsets, double fx, double fy, double cx, double cy, double z_scaling,
+                               void *X, void *Y, void *Z, int capacity, hipStream_t s) {
+  const int npix = H * W, nblocks = (npix + kScanBlock - 1) / kScanBlock;
+  if (dtype == 1)
+    hipLaunchKernelGGL((ea_edge_scatter_kernel<float>), dim3(nblocks), dim3(kScanBlock), 0, s, lap, depth, H, W, thr,
+                       block_offsets, fx, fy, cx, cy, z_scaling, (float *)X, (float *)Y, (float *)Z, capacity);
+  else
+    hipLaunchKernelGGL((ea_edge_scatter_kernel<double>), dim3(nblocks), dim3(kScanBlock), 0, s, lap, depth, H, W, thr,
+                       block_offsets, fx, fy, cx, cy, z_scaling, (double *)X, (double *)Y, (double *)Z, capacity);
+  return hipGetLastError();
+}
+
+}  // namespace ea

@@ -194,6 +194,27 @@ int ea_batch_bench_eval(ea_batch *b, const double *q, const double *t, int warmu
 int ea_batch_set_tuning(ea_batch *b, const char *key, int value);
 int ea_batch_get_info(const ea_batch *b, const char *key, int64_t *value);
 
+/* ---- producers either side of the hot path, on the device ----------------
+ * Reference frame: replaces get_aX (standalone/utils.cpp:201-281) + the residual-block loop at stride 1:
+ * GaussianBlur 3x3 -> CV_RGB2GRAY -> Laplacian k3 -> |.| > threshold && depth > 0 -> back-projection with the
+ * problem's intrinsics, points kept in raster order.  bgr: H x W x 3 bytes as cv::imread returns them,
+ * depth: H x W uint16 (TUM: z_scaling 5000).  Host pointers. */
+int ea_problem_set_ref_frame(ea_problem *p, const uint8_t *bgr, const uint16_t *depth, int height, int width,
+                             double z_scaling, int threshold);
+/* Current frame: replaces get_distance_transform (utils.cpp:38-83) + cv2eigen + Grid2D (:201-206, :258):
+ * edge map (same gradient, > threshold) -> [3x3 median] -> 3x3 chamfer DT (DIST_L2, mask 3) -> [min-max
+ * normalise to [0,1]] written straight into the problem's DT image in HBM. */
+int ea_problem_set_now_frame(ea_problem *p, const uint8_t *bgr, int height, int width, int threshold, int median,
+                             int normalize);
+/* same, and copies the intermediate stages back (any may be NULL): |Laplacian| (H*W bytes), edge mask after
+ * the median (0 = edge), chamfer distance in 16.16 fixed point, final float32 DT */
+int ea_problem_debug_now_frame(ea_problem *p, const uint8_t *bgr, int height, int width, int threshold, int median,
+                               int normalize, uint8_t *lap_out, uint8_t *mask_out, int32_t *chamfer_fix_out,
+                               float *dt_out);
+/* read back what the problem holds in HBM: points (n x 3 doubles), DT image (H x W doubles, [v][u]) */
+int ea_problem_get_points(ea_problem *p, double *xyz, int64_t capacity);
+int ea_problem_get_dt(ea_problem *p, double *image, int *height, int *width);
+
 /* Self-test of the wavefront reduction primitives the kernels rely on (write-masked DPP adds,
  * v_permlane16/32_swap, quad_perm): in = 32 slots x 64 lanes (fp32, slot-major); out32 / out64 = the 32
  * wave totals from the fp32 and the fp64 reduction; stages (nullable, 30 x 64 floats) = the

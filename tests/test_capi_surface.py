@@ -62,9 +62,12 @@ def test_argument_validation_needs_no_device(lib):
 
 
 def test_product_never_imports_the_oracle():
-    pkg = os.path.join(ROOT, "edge_alignment_amd")
-    for dirpath, _, files in os.walk(pkg):
-        for f in files:
-            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
-                src = open(os.path.join(dirpath, f)).read()
-                assert "oracle" not in src.replace("the oracle's", "").lower() or f == "synth.py" and False, (dirpath, f)
+    """oracle/ is test infrastructure: nothing under edge_alignment_amd/ (or include/) may import, include,
+    link or dlopen it.  (Comments may mention it.)"""
+    pat = re.compile(r"(^\s*(from|import)\s+oracle\b)|(#\s*include\s*[\"<][^\">]*oracle)|(ea_oracle)|(libea_oracle)|(oracle[./]ea_)", re.M)
+    for top in ("edge_alignment_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
+                    src = open(os.path.join(dirpath, f)).read()
+                    assert not pat.search(src), (dirpath, f, pat.search(src).group(0))

@@ -1,0 +1,115 @@
+"""SURVEY §8(f) rows 1-2 on the GPU: edge-point extractor (get_aX, standalone/utils.cpp:201-281) and DT
+producer (get_distance_transform, utils.cpp:38-83).  Integer / byte / index work: BIT-EXACT against the
+numpy restatement (oracle/preprocess_np.py); the one reference-held number, 44457 edge points = 1482
+residual blocks at stride 30 (standalone/README.md:34), is reproduced by the GPU path too."""
+import os
+
+import numpy as np
+import pytest
+
+from edge_alignment_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden", "rgbd")
+K = (525.0, 525.0, 319.5, 239.5)
+
+
+@pytest.fixture(scope="module")
+def frames():
+    from oracle import preprocess_np as pp
+    return dict(pp=pp,
+                rgb1=pp.load_rgb_as_bgr(os.path.join(G, "rgb_1.png")), depth1=pp.load_depth_u16(os.path.join(G, "depth_1.png")),
+                rgb3=pp.load_rgb_as_bgr(os.path.join(G, "rgb_3.png")), rgb5=pp.load_rgb_as_bgr(os.path.join(G, "rgb_5.png")))
+
+
+@pytest.mark.parametrize("name", ["rgb3", "rgb5", "rgb1"])
+@pytest.mark.parametrize("median,normalize", [(True, True), (False, False)])
+def test_dt_producer_stages_bit_exact(hip, frames, name, median, normalize):
+    pp = frames["pp"]
+    img = frames[name]
+    P = hip.Problem(*K, dtype=hip.EA_F64)
+    st = P.set_now_frame(img, threshold=35, median=median, normalize=normalize, debug=True)
+    lap = pp.edge_strength(img)
+    assert np.array_equal(st["lap"], lap)
+    B = np.where(lap > 35, 0, 255).astype(np.uint8)
+    mask = pp.median_blur3_u8(B) if median else B
+    assert np.array_equal(st["mask"], mask)
+    cham = pp.chamfer3x3_fixed(mask == 0)  # OpenCV's two-pass raster chamfer
+    assert np.array_equal(st["chamfer"].astype(np.int64), cham)  # == closed-form shortest-path search on the GPU
+    dist = pp.distance_transform_l2_3(mask)
+    want = pp.normalize_minmax_f32(dist) if normalize else dist
+    assert st["dt"].dtype == np.float32 and np.array_equal(st["dt"], want)
+    # and what the problem holds in HBM is that image (fp32 values are exact in the fp64 problem)
+    assert np.array_equal(P.get_dt(), want.astype(np.float64))
+    P.close()
+
+
+def test_dt_producer_edge_cases(hip, frames):
+    pp = frames["pp"]
+    rng = np.random.default_rng(3)
+    # tiny, odd-sized, and feature-free images
+    for (H, W) in [(3, 3), (5, 17), (37, 64), (64, 257)]:
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        P = hip.Problem(*K, dtype=hip.EA_F32)
+        st = P.set_now_frame(img, threshold=35, median=True, normalize=True, debug=True)
+        lap = pp.edge_strength(img)
+        mask = pp.median_blur3_u8(np.where(lap > 35, 0, 255).astype(np.uint8))
+        assert np.array_equal(st["lap"], lap) and np.array_equal(st["mask"], mask)
+        assert np.array_equal(st["chamfer"].astype(np.int64), pp.chamfer3x3_fixed(mask == 0))
+        P.close()
+    flat = np.full((40, 50, 3), 77, dtype=np.uint8)  # no edges at all: every distance saturates
+    P = hip.Problem(*K, dtype=hip.EA_F32)
+    st = P.set_now_frame(flat, debug=True, normalize=False)
+    assert (st["mask"] == 255).all() and (st["chamfer"] == 2 ** 30 - 1).all()
+    P.close()
+
+
+@pytest.mark.parametrize("dtype_name", ["f64", "f32"])
+def test_edge_point_extractor_bit_exact(hip, frames, dtype_name):
+    pp = frames["pp"]
+    aX, (vv, uu) = pp.get_aX(frames["rgb1"], frames["depth1"], *K)
+    P = hip.Problem(*K, dtype=hip.EA_F64 if dtype_name == "f64" else hip.EA_F32)
+    P.set_ref_frame(frames["rgb1"], frames["depth1"], z_scaling=5000.0, threshold=35)
+    assert P.num_points == 44457 == aX.shape[1]          # the reference log's 1482 blocks x stride 30
+    assert -(-P.num_points // 30) == 1482
+    xyz = P.get_points()
+    want = aX[:3].T
+    if dtype_name == "f64":
+        assert np.array_equal(xyz, want)                  # same doubles, same raster order
+    else:
+        assert np.array_equal(xyz, want.astype(np.float32).astype(np.float64))
+    P.close()
+
+
+def test_edge_point_extractor_edge_cases(hip, frames):
+    pp = frames["pp"]
+    rng = np.random.default_rng(4)
+    for (H, W) in [(3, 3), (31, 33), (100, 1030)]:
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        depth = rng.integers(0, 3, (H, W)).astype(np.uint16) * rng.integers(0, 20000, (H, W)).astype(np.uint16)
+        aX, _ = pp.get_aX(img, depth, *K, z_scaling=5000.0, threshold=35)
+        P = hip.Problem(*K, dtype=hip.EA_F64)
+        P.set_ref_frame(img, depth)
+        assert P.num_points == aX.shape[1]
+        assert np.array_equal(P.get_points(), aX[:3].T)
+        P.close()
+    P = hip.Problem(*K, dtype=hip.EA_F64)   # no depth anywhere -> empty cloud
+    P.set_ref_frame(frames["rgb1"], np.zeros_like(frames["depth1"]))
+    assert P.num_points == 0
+    P.close()
+
+
+@pytest.mark.parametrize("b", [3, 5])
+def test_frames_to_pose_end_to_end(hip, frames, golden, b):
+    """raw frames -> GPU edge points + GPU DT -> device LM: the whole of edge_align_test1's compute
+    (standalone_edge_align.cpp:170-286, stride 1) without the CPU touching a pixel"""
+    P = hip.Problem(*K, dtype=hip.EA_F64)
+    P.set_ref_frame(frames["rgb1"], frames["depth1"])
+    P.set_now_frame(frames["rgb%d" % b])
+    q, t, s = P.solve([1, 0, 0, 0], [0, 0, 0])
+    tag = "b%d_s1" % b
+    assert s["num_iterations"] == int(golden[tag + "_lm_iterations"]) and s["why"] == str(golden[tag + "_lm_why"])
+    assert synth.rotation_angle_between(q, golden[tag + "_lm_q"]) < 1e-7
+    assert np.linalg.norm(t - golden[tag + "_lm_t"]) < 1e-7
+    P.close()
