@@ -393,17 +393,24 @@ static int batch_build(ea_batch *b) {
   // points per lane; a workgroup owns chunk = nt*ppt consecutive points and emits one partial row.
   // Small problems are latency-bound: one point per lane and as many waves as possible.  Large
   // ones take 1024-thread workgroups so that the partial rows to fold stay in the hundreds.
-  // (measured on MI355X, profiles/r01_sweep.txt): fp32 single problems >= 2.5e5 points take
-  // 1024-thread workgroups with two points per lane (fewer partial rows to fold); fp64 and batches of
-  // mid-size problems take 256-thread workgroups, two points per lane once the batch is large.
+  // Measured on MI355X (profiles/r01_sweep*.txt).  Small problems are latency-bound: one point per lane
+  // and as many waves as possible.  Large fp32 problems take 1024-thread workgroups with 2-4 points per
+  // lane: the kernel time hardly moves, but the partial rows to fold drop to a few hundred.
   int64_t max_n = 0;
   for (ea_problem *p : b->probs) max_n = std::max<int64_t>(max_n, p->n);
-  const bool big_f32 = b->dtype == EA_F32 && max_n >= 250000;
-  int nt = (b->t_nt == 1024 || b->t_nt == 256) ? b->t_nt : (big_f32 ? 1024 : 256);
+  int nt_auto = 256, ppt_auto = 1;
+  if (b->dtype == EA_F32) {
+    if (max_n >= 800000) { nt_auto = 1024; ppt_auto = 4; }
+    else if (max_n >= 300000) { nt_auto = 1024; ppt_auto = 2; }
+    else if (max_n >= 150000) { nt_auto = 256; ppt_auto = 4; }
+    else ppt_auto = total >= 1000000 ? 2 : 1;
+  } else {
+    ppt_auto = total >= 300000 ? 2 : 1;
+  }
+  int nt = (b->t_nt == 1024 || b->t_nt == 256) ? b->t_nt : nt_auto;
   int ppt = b->t_ppt;
-  if (ppt != 1 && ppt != 2 && ppt != 4)
-    ppt = b->dtype == EA_F32 ? ((big_f32 || total >= 1000000) ? 2 : 1) : (total >= 300000 ? 2 : 1);
-  if (nt == 1024) ppt = b->dtype == EA_F32 ? std::min(ppt, 2) : 1;  // 128-VGPR budget at 16 waves/CU
+  if (ppt != 1 && ppt != 2 && ppt != 4) ppt = ppt_auto;
+  if (nt == 1024 && b->dtype == EA_F64) ppt = 1;  // 128-VGPR budget at 16 waves/CU
   if (b->dtype == EA_F64 && ppt > 2) ppt = 2;
   b->ppt = ppt;
   b->nt = nt;
@@ -436,6 +443,7 @@ static int batch_build(ea_batch *b) {
     b->d_partials = nullptr;
     b->tiles_cap = b->ntiles + b->ntiles / 4 + 16;
     HIPCHK(hipMalloc(&b->d_partials, (size_t)b->tiles_cap * kAccSlots * sizeof(double)));
+    HIPCHK(hipMemset(b->d_partials, 0, (size_t)b->tiles_cap * kAccSlots * sizeof(double)));
   }
   HIPCHK(hipMemcpy(b->d_probs, descs.data(), descs.size() * sizeof(ProblemDesc), hipMemcpyHostToDevice));
   // LDS staging of the DT footprint is available but off by default: on MI355X the unaligned 16-byte

@@ -733,7 +733,7 @@ hipError_t launch_eval_fused(int dtype, int ppt, int nt, const ProblemDesc *prob
     if (lds_texels > 0) EA_LAUNCH(T, P, true, N); else EA_LAUNCH(T, P, false, N); \
   } while (0)
   if (dtype == 1) {
-    if (nt == 1024) { if (ppt == 1) EA_LAUNCH_L(float, 1, 1024); else EA_LAUNCH_L(float, 2, 1024); }
+    if (nt == 1024) { if (ppt == 1) EA_LAUNCH_L(float, 1, 1024); else if (ppt == 2) EA_LAUNCH_L(float, 2, 1024); else EA_LAUNCH_L(float, 4, 1024); }
     else if (ppt == 1) EA_LAUNCH_L(float, 1, 256);
     else if (ppt == 2) EA_LAUNCH_L(float, 2, 256);
     else EA_LAUNCH_L(float, 4, 256);
