@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--workload", default="c2", choices=["c2", "c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    # rehearsal knobs (the driver never passes them): run the N>1 control flow on a one-GPU box
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--force-device", type=int, default=None, help="use this HIP device on every rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -93,11 +96,17 @@ def main():
 
     import torch  # plumbing only: process group (RCCL), barriers, device sync
     dist = None
+    if args.force_device is not None:
+        local_rank = args.force_device
+    coll_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
 
@@ -131,7 +140,7 @@ def main():
     barrier_sync()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     value = world * n_pts * args.steps / elapsed
@@ -171,10 +180,10 @@ def main():
         # the one collective: all-gather of the solved poses (7 doubles + status per problem)
         tg = time.perf_counter()
         qa, ta, st = ead.gather_poses([q], [t], [s["termination"]], world, rank, world,
-                                      device="cuda" if world > 1 else "cpu")
+                                      device=coll_dev if world > 1 else "cpu")
         gather_ms = (time.perf_counter() - tg) * 1e3
         if dist is not None:
-            tt = torch.tensor([lm_local], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([lm_local], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.SUM)
             lm_total = float(tt.item())
         else:

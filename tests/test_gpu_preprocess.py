@@ -113,3 +113,42 @@ def test_frames_to_pose_end_to_end(hip, frames, golden, b):
     assert synth.rotation_angle_between(q, golden[tag + "_lm_q"]) < 1e-7
     assert np.linalg.norm(t - golden[tag + "_lm_t"]) < 1e-7
     P.close()
+
+
+def test_c4_batch_of_frame_pairs(hip, oracle):
+    """C4 (BASELINE.json configs[3]): the TUM fr1_desk sequence is not available, so the batch is
+    synthesised as prescribed — the 20 ordered pairs of the 5 bundled frames x seeded initial-pose
+    perturbations (rotation <= 1 deg, translation <= 2 cm, seed 4) — 40 problems here (32 per GPU in the
+    8-GPU layout).  Everything from raw frames to poses runs on the device; the batch must equal the
+    single-problem solves bit for bit, and sampled problems must land on the oracle's pose."""
+    from oracle import preprocess_np as pp
+    rgb = {k: pp.load_rgb_as_bgr(os.path.join(G, "rgb_%d.png" % k)) for k in range(1, 6)}
+    dep = {k: pp.load_depth_u16(os.path.join(G, "depth_%d.png" % k)) for k in range(1, 6)}
+    rng = np.random.default_rng(4)
+    pairs = [(a, b) for a in range(1, 6) for b in range(1, 6) if a != b]
+    Ps, q0s, t0s, meta = [], [], [], []
+    for (a, b) in pairs:
+        for rep in range(2):
+            P = hip.Problem(*K, dtype=hip.EA_F64)
+            P.set_ref_frame(rgb[a], dep[a])
+            P.set_now_frame(rgb[b])
+            ax = rng.normal(size=3)
+            q0 = synth.quat_from_axis_angle(ax, np.deg2rad(rng.uniform(0, 1.0))) if rep else np.array([1.0, 0, 0, 0])
+            t0 = rng.uniform(-0.02, 0.02, 3) / np.sqrt(3) if rep else np.zeros(3)
+            Ps.append(P); q0s.append(q0); t0s.append(t0); meta.append((a, b))
+    B = hip.Batch(Ps)
+    q, t, ss = B.solve(np.array(q0s), np.array(t0s))
+    assert all(s["termination"] in (hip.CONVERGENCE, hip.NO_CONVERGENCE) for s in ss)
+    for i in (0, 7, 13, 22, 39):   # batch == single, bit for bit
+        q1, t1, s1 = Ps[i].solve(q0s[i], t0s[i])
+        assert np.array_equal(q1, q[i]) and np.array_equal(t1, t[i]) and s1["num_iterations"] == ss[i]["num_iterations"]
+    for i in (1, 18, 31):          # and the oracle (numpy pre-processing + C LM) lands on the same pose
+        a, b = meta[i]
+        aX, _ = pp.get_aX(rgb[a], dep[a], *K)
+        O = oracle.OracleProblem(pp.grid_view_of_image(pp.get_distance_transform(rgb[b])), *K)
+        qo, to, so = O.solve(aX[:3].T.copy(), q0s[i], t0s[i])
+        assert synth.rotation_angle_between(q[i], qo) < 1e-4 and np.linalg.norm(t[i] - to) < 1e-3
+        assert ss[i]["num_iterations"] == so["num_iterations"]
+    B.close()
+    for P in Ps:
+        P.close()
