@@ -31,6 +31,7 @@ EXPORTED = [
     "ea_batch_bench_eval", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
     "ea_problem_set_ref_frame", "ea_problem_set_now_frame", "ea_problem_debug_now_frame",
     "ea_problem_get_points", "ea_problem_get_dt",
+    "ea_problem_set_distortion", "ea_problem_set_second_camera", "ea_problem_add_term", "ea_problem_clear_terms",
 ]
 
 
@@ -120,6 +121,10 @@ def load():
                                              C.POINTER(C.c_int32), C.POINTER(C.c_float)]
     L.ea_problem_get_points.argtypes = [vp, dp, C.c_int64]
     L.ea_problem_get_dt.argtypes = [vp, dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.ea_problem_set_distortion.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]
+    L.ea_problem_set_second_camera.argtypes = [vp, dp, dp]
+    L.ea_problem_add_term.argtypes = [vp, vp]
+    L.ea_problem_clear_terms.argtypes = [vp]
     _lib = L
     return L
 
@@ -247,6 +252,18 @@ class Problem:
         img = np.zeros((h.value, w.value))
         _check(load().ea_problem_get_dt(self._h, _dp(img), None, None))
         return img
+
+    def set_distortion(self, k1, k2, p1, p2, k3):
+        _check(load().ea_problem_set_distortion(self._h, k1, k2, p1, p2, k3))
+
+    def set_second_camera(self, T12, T12inv=None):
+        T12 = _f64(T12).reshape(16)
+        T12inv = _f64(T12inv if T12inv is not None else np.linalg.inv(T12.reshape(4, 4))).reshape(16)
+        _check(load().ea_problem_set_second_camera(self._h, _dp(T12), _dp(T12inv)))
+
+    def add_term(self, term):
+        self._keep.append(term)
+        _check(load().ea_problem_add_term(self._h, term.handle))
 
     def set_loss(self, kind, a=1.0):
         _check(load().ea_problem_set_loss(self._h, kind, a))

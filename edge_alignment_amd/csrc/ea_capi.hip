@@ -16,14 +16,14 @@
 #include "ea_types.h"
 
 namespace ea {
-hipError_t launch_eval_fused(int dtype, int ppt, int nt, const ProblemDesc *probs, int count, int chunk,
+hipError_t launch_eval_fused(int dtype, int ppt, int nt, int variant, const ProblemDesc *probs, int nterms, int chunk,
                              int max_chunks, int xcd_remap, const PoseState *poses, double *partials,
-                             int lds_bytes, hipStream_t stream);
+                             int lds_bytes, int terms_are_groups, hipStream_t stream);
 hipError_t launch_eval_points(int dtype, const ProblemDesc *probs, int problem, int n, const PoseState *poses,
                               double *r_out, double *J_out, int corrected, hipStream_t stream);
-hipError_t launch_reduce(const ProblemDesc *probs, int count, const double *partials, EvalOut *out,
+hipError_t launch_reduce(const GroupDesc *groups, int count, const double *partials, EvalOut *out,
                          hipStream_t stream);
-hipError_t launch_lm_step(const ProblemDesc *probs, int count, const double *partials, PoseState *poses,
+hipError_t launch_lm_step(const GroupDesc *groups, int count, const double *partials, PoseState *poses,
                           LMState *states, LMTrace *traces, const LMOptions &opt, int *running_flags,
                           hipStream_t stream);
 hipError_t launch_pad_image(int dtype, const void *src, int H, int W, void *dst, int pitch, hipStream_t stream);
@@ -67,6 +67,12 @@ struct ea_problem {
   double loss_a = 1.0;
   double z_guard = 0.01, z_eps = 0.0;
   int rot_transposed = 0;
+  // residual variants (utils.h:102-421)
+  int variant = 0;                       // bit 0 distortion, bit 1 second camera
+  double dist[5] = {0, 0, 0, 0, 0};      // k1, k2, p1, p2, k3
+  double T12[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  double T12inv[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  std::vector<ea_problem *> terms;       // further residual families sharing this problem's pose
   int64_t n = 0;
   void *d_x = nullptr, *d_y = nullptr, *d_z = nullptr;
   bool own_points = false;
@@ -87,7 +93,10 @@ struct ea_batch {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   // device
-  ProblemDesc *d_probs = nullptr;
+  ProblemDesc *d_probs = nullptr;       // one per term (problem + its additional terms), groups contiguous
+  GroupDesc *d_groups = nullptr;         // one per problem (= pose)
+  int nterms = 0, terms_cap = 0;
+  int any_variant = 0, terms_are_groups = 1;
   int ntiles = 0, tiles_cap = 0;  // rows of the partial-sum array (one per workgroup with work)
   int chunk = 256, max_chunks = 0; // points per workgroup; largest per-problem workgroup count
   PoseState *d_poses = nullptr;
@@ -197,6 +206,50 @@ extern "C" void ea_problem_destroy(ea_problem *p) {
 }
 
 extern "C" int64_t ea_problem_num_points(const ea_problem *p) { return p ? p->n : 0; }
+
+extern "C" int ea_problem_set_distortion(ea_problem *p, double k1, double k2, double p1, double p2, double k3) {
+  if (!p) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  p->dist[0] = k1; p->dist[1] = k2; p->dist[2] = p1; p->dist[3] = p2; p->dist[4] = k3;
+  const bool on = k1 != 0.0 || k2 != 0.0 || p1 != 0.0 || p2 != 0.0 || k3 != 0.0;
+  p->variant = on ? (p->variant | 1) : (p->variant & ~1);
+  p->version++;
+  return EA_OK;
+}
+
+extern "C" int ea_problem_set_second_camera(ea_problem *p, const double trans_1to2[16], const double trans_1to2_inv[16]) {
+  if (!p) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  if (!trans_1to2 || !trans_1to2_inv) {  // back to the first camera
+    for (int i = 0; i < 16; ++i) p->T12[i] = p->T12inv[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    p->variant &= ~2;
+    p->version++;
+    return EA_OK;
+  }
+  for (int k = 0; k < 2; ++k) {
+    const double *m = k ? trans_1to2_inv : trans_1to2;
+    if (m[12] != 0.0 || m[13] != 0.0 || m[14] != 0.0 || m[15] != 1.0)
+      return fail(EA_ERR_INVALID_ARG, "rig transforms must be affine (last row 0 0 0 1)");
+  }
+  for (int i = 0; i < 16; ++i) { p->T12[i] = trans_1to2[i]; p->T12inv[i] = trans_1to2_inv[i]; }
+  p->variant |= 2;
+  p->version++;
+  return EA_OK;
+}
+
+extern "C" int ea_problem_add_term(ea_problem *p, ea_problem *term) {
+  if (!p || !term || p == term) return fail(EA_ERR_INVALID_ARG, "bad argument");
+  if (!term->terms.empty()) return fail(EA_ERR_INVALID_ARG, "a term cannot have terms of its own");
+  if (p->device != term->device || p->dtype != term->dtype) return fail(EA_ERR_INVALID_ARG, "terms must share device and dtype");
+  p->terms.push_back(term);
+  p->version++;
+  return EA_OK;
+}
+
+extern "C" int ea_problem_clear_terms(ea_problem *p) {
+  if (!p) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  p->terms.clear();
+  p->version++;
+  return EA_OK;
+}
 
 extern "C" int ea_problem_set_points(ea_problem *p, const double *xyz, int64_t n, int64_t stride) {
   if (!p || (n > 0 && !xyz)) return fail(EA_ERR_INVALID_ARG, "NULL argument");
@@ -309,11 +362,11 @@ extern "C" int ea_problem_set_flavour(ea_problem *p, double z_guard, double z_ep
 // ---- batch --------------------------------------------------------------------------------------
 
 static void batch_free_device(ea_batch *b) {
-  (void)hipFree(b->d_probs); (void)hipFree(b->d_lm_block); (void)hipFree(b->d_traces);
+  (void)hipFree(b->d_probs); (void)hipFree(b->d_groups); (void)hipFree(b->d_lm_block); (void)hipFree(b->d_traces);
   (void)hipFree(b->d_partials); (void)hipFree(b->d_out);
   (void)hipHostFree(b->h_lm_block); (void)hipHostFree(b->h_out);
   (void)hipHostFree(b->h_traces); (void)hipHostFree(b->h_progress);
-  b->d_probs = nullptr; b->d_poses = nullptr; b->d_partials = nullptr; b->d_traces = nullptr; b->d_lm_block = nullptr;
+  b->d_probs = nullptr; b->d_groups = nullptr; b->d_poses = nullptr; b->d_partials = nullptr; b->d_traces = nullptr; b->d_lm_block = nullptr;
   b->d_out = nullptr; b->d_states = nullptr; b->d_progress = nullptr;
   b->h_poses = nullptr; b->h_out = nullptr; b->h_states = nullptr; b->h_traces = nullptr; b->h_progress = nullptr;
   b->h_lm_block = nullptr;
@@ -338,7 +391,7 @@ extern "C" int ea_batch_create(ea_batch **out, ea_problem *const *problems, int 
   b->own_stream = true;
   const size_t c = (size_t)count;
   const size_t lm_bytes = c * (sizeof(LMState) + sizeof(PoseState));
-  e = hipMalloc(&b->d_probs, c * sizeof(ProblemDesc));
+  e = hipMalloc(&b->d_groups, c * sizeof(GroupDesc));
   if (e == hipSuccess) e = hipMalloc(&b->d_lm_block, lm_bytes);
   if (e == hipSuccess) e = hipMalloc(&b->d_out, c * sizeof(EvalOut));
   if (e == hipSuccess) e = hipMalloc(&b->d_traces, c * sizeof(LMTrace));
@@ -377,27 +430,66 @@ extern "C" void ea_batch_destroy(ea_batch *b) {
 extern "C" int ea_batch_count(const ea_batch *b) { return b ? (int)b->probs.size() : 0; }
 
 // (re)build descriptors and the tile list when any problem changed
+static void fill_desc(const ea_problem *p, ProblemDesc &d) {
+  std::memset(&d, 0, sizeof(d));
+  d.x = p->d_x; d.y = p->d_y; d.z = p->d_z; d.dt = p->d_dt;
+  d.n = (int32_t)p->n; d.W = p->W; d.H = p->H; d.pitch = p->pitch;
+  d.fx = p->cam.fx; d.fy = p->cam.fy; d.cx = p->cam.cx; d.cy = p->cam.cy;
+  d.loss_a = p->loss_a; d.z_guard = p->z_guard; d.z_eps = p->z_eps;
+  d.fxf = (float)d.fx; d.fyf = (float)d.fy; d.cxf = (float)d.cx; d.cyf = (float)d.cy;
+  d.loss_af = (float)d.loss_a; d.z_guardf = (float)d.z_guard; d.z_epsf = (float)d.z_eps;
+  d.loss_kind = p->loss_kind; d.rot_transposed = p->rot_transposed;
+  d.variant = p->variant;
+  for (int i = 0; i < 5; ++i) { d.dist[i] = p->dist[i]; d.distf[i] = (float)p->dist[i]; }
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) {
+      d.A[3 * r + c] = p->T12[4 * r + c]; d.Ai[3 * r + c] = p->T12inv[4 * r + c];
+      d.Af[3 * r + c] = (float)d.A[3 * r + c]; d.Aif[3 * r + c] = (float)d.Ai[3 * r + c];
+    }
+    d.d[r] = p->T12[4 * r + 3]; d.di[r] = p->T12inv[4 * r + 3];
+    d.df[r] = (float)d.d[r]; d.dif[r] = (float)d.di[r];
+  }
+}
+
+// (re)build descriptors when any problem (or one of its terms) changed
 static int batch_build(ea_batch *b) {
+  uint64_t sig = 0;
   bool dirty = !b->built;
-  for (size_t i = 0; i < b->probs.size(); ++i)
-    if (b->versions[i] != b->probs[i]->version) dirty = true;
+  for (size_t i = 0; i < b->probs.size(); ++i) {
+    uint64_t v = b->probs[i]->version;
+    for (ea_problem *tm : b->probs[i]->terms) v = v * 1000003u + tm->version + 17;
+    if (b->versions[i] != v) dirty = true;
+    sig += v;
+  }
+  (void)sig;
   if (!dirty) return EA_OK;
   HIPCHK(hipSetDevice(b->device));
-  int64_t total = 0;
-  for (ea_problem *p : b->probs) {
-    if (!p->d_dt) return fail(EA_ERR_STATE, "distance-transform image not set (ea_problem_set_dt)");
-    if (p->n > 0 && !p->d_x) return fail(EA_ERR_STATE, "edge points not set (ea_problem_set_points)");
-    total += p->n;
+  // terms of a problem follow it; all share its pose
+  std::vector<const ea_problem *> terms;
+  std::vector<int> term_group;
+  int64_t total = 0, max_n = 0;
+  int any_variant = 0;
+  for (size_t i = 0; i < b->probs.size(); ++i) {
+    std::vector<const ea_problem *> fam;
+    fam.push_back(b->probs[i]);
+    for (ea_problem *tm : b->probs[i]->terms) fam.push_back(tm);
+    for (const ea_problem *p : fam) {
+      if (p->device != b->device || p->dtype != b->dtype) return fail(EA_ERR_INVALID_ARG, "terms must share device and dtype");
+      if (!p->d_dt) return fail(EA_ERR_STATE, "distance-transform image not set (ea_problem_set_dt)");
+      if (p->n > 0 && !p->d_x) return fail(EA_ERR_STATE, "edge points not set (ea_problem_set_points)");
+      if (p->rot_transposed != b->probs[i]->rot_transposed) return fail(EA_ERR_INVALID_ARG, "terms of one problem must agree on rot_transposed");
+      total += p->n;
+      max_n = std::max<int64_t>(max_n, p->n);
+      any_variant |= p->variant;
+      terms.push_back(p);
+      term_group.push_back((int)i);
+    }
   }
-  // Workgroup sizing.  nt = threads per workgroup (256, or 1024 = one workgroup per CU), ppt =
-  // points per lane; a workgroup owns chunk = nt*ppt consecutive points and emits one partial row.
-  // Small problems are latency-bound: one point per lane and as many waves as possible.  Large
-  // ones take 1024-thread workgroups so that the partial rows to fold stay in the hundreds.
-  // Measured on MI355X (profiles/r01_sweep*.txt).  Small problems are latency-bound: one point per lane
-  // and as many waves as possible.  Large fp32 problems take 1024-thread workgroups with 2-4 points per
-  // lane: the kernel time hardly moves, but the partial rows to fold drop to a few hundred.
-  int64_t max_n = 0;
-  for (ea_problem *p : b->probs) max_n = std::max<int64_t>(max_n, p->n);
+  b->any_variant = any_variant;
+  b->terms_are_groups = terms.size() == b->probs.size() ? 1 : 0;
+  // Launch shape, measured on MI355X (profiles/r01_sweep*.txt).  Small problems are latency-bound: one
+  // point per lane and as many waves as possible.  Large fp32 problems take 1024-thread workgroups with 2-4
+  // points per lane: the kernel time hardly moves, but the partial rows to fold drop to a few hundred.
   int nt_auto = 256, ppt_auto = 1;
   if (b->dtype == EA_F32) {
     if (max_n >= 800000) { nt_auto = 1024; ppt_auto = 4; }
@@ -405,39 +497,50 @@ static int batch_build(ea_batch *b) {
     else if (max_n >= 150000) { nt_auto = 256; ppt_auto = 4; }
     else ppt_auto = total >= 1000000 ? 2 : 1;
   } else {
-    ppt_auto = total >= 300000 ? 2 : 1;
+    ppt_auto = total >= 80000 ? 2 : 1;  // same kernel time at 1e5 points, half the rows for the LM step to fold
   }
   int nt = (b->t_nt == 1024 || b->t_nt == 256) ? b->t_nt : nt_auto;
   int ppt = b->t_ppt;
   if (ppt != 1 && ppt != 2 && ppt != 4) ppt = ppt_auto;
   if (nt == 1024 && b->dtype == EA_F64) ppt = 1;  // 128-VGPR budget at 16 waves/CU
   if (b->dtype == EA_F64 && ppt > 2) ppt = 2;
+  if (any_variant) { nt = 256; ppt = std::min(ppt, 2); }  // the variant kernel is built for this shape only
   b->ppt = ppt;
   b->nt = nt;
   const int64_t chunk = (int64_t)nt * ppt;
   b->chunk = (int)chunk;
-  std::vector<ProblemDesc> descs(b->probs.size());
+  std::vector<ProblemDesc> descs(terms.size());
+  std::vector<GroupDesc> groups(b->probs.size());
   int rows = 0, max_chunks = 0;
-  for (size_t i = 0; i < b->probs.size(); ++i) {
-    ea_problem *p = b->probs[i];
-    ProblemDesc &d = descs[i];
-    std::memset(&d, 0, sizeof(d));
-    d.x = p->d_x; d.y = p->d_y; d.z = p->d_z; d.dt = p->d_dt;
-    d.n = (int32_t)p->n; d.W = p->W; d.H = p->H; d.pitch = p->pitch;
-    d.fx = p->cam.fx; d.fy = p->cam.fy; d.cx = p->cam.cx; d.cy = p->cam.cy;
-    d.loss_a = p->loss_a; d.z_guard = p->z_guard; d.z_eps = p->z_eps;
-    d.fxf = (float)d.fx; d.fyf = (float)d.fy; d.cxf = (float)d.cx; d.cyf = (float)d.cy;
-    d.loss_af = (float)d.loss_a; d.z_guardf = (float)d.z_guard; d.z_epsf = (float)d.z_eps;
-    d.loss_kind = p->loss_kind; d.rot_transposed = p->rot_transposed;
+  for (size_t k = 0; k < terms.size(); ++k) {
+    const ea_problem *p = terms[k];
+    ProblemDesc &d = descs[k];
+    fill_desc(p, d);
+    d.group = term_group[k];
     const int nchunks = (int)((p->n + chunk - 1) / chunk);
     d.tile_begin = rows;
     rows += nchunks;
     d.tile_end = rows;
     max_chunks = std::max(max_chunks, nchunks);
-    b->versions[i] = p->version;
+    GroupDesc &g = groups[term_group[k]];
+    if (k == 0 || term_group[k - 1] != term_group[k]) { g.tile_begin = d.tile_begin; g.term_begin = (int)k; }
+    g.tile_end = d.tile_end;
+    g.term_end = (int)k + 1;
   }
+  for (size_t i = 0; i < b->probs.size(); ++i) {
+    uint64_t v = b->probs[i]->version;
+    for (ea_problem *tm : b->probs[i]->terms) v = v * 1000003u + tm->version + 17;
+    b->versions[i] = v;
+  }
+  b->nterms = (int)terms.size();
   b->ntiles = rows;
   b->max_chunks = max_chunks;
+  if (b->nterms > b->terms_cap) {
+    (void)hipFree(b->d_probs);
+    b->d_probs = nullptr;
+    b->terms_cap = b->nterms + 8;
+    HIPCHK(hipMalloc(&b->d_probs, (size_t)b->terms_cap * sizeof(ProblemDesc)));
+  }
   if (b->ntiles > b->tiles_cap) {
     (void)hipFree(b->d_partials);
     b->d_partials = nullptr;
@@ -446,12 +549,13 @@ static int batch_build(ea_batch *b) {
     HIPCHK(hipMemset(b->d_partials, 0, (size_t)b->tiles_cap * kAccSlots * sizeof(double)));
   }
   HIPCHK(hipMemcpy(b->d_probs, descs.data(), descs.size() * sizeof(ProblemDesc), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b->d_groups, groups.data(), groups.size() * sizeof(GroupDesc), hipMemcpyHostToDevice));
   // LDS staging of the DT footprint is available but off by default: on MI355X the unaligned 16-byte
   // row loads served by the XCD's L2 beat it at every size measured
   int use_lds = b->t_use_lds < 0 ? 0 : b->t_use_lds;
   int lds = b->t_lds_bytes >= 0 ? b->t_lds_bytes : (b->dtype == EA_F32 ? 32768 : 49152);
   if (lds > 61440) lds = 61440;
-  b->lds_bytes = use_lds ? lds : 0;
+  b->lds_bytes = (use_lds && !any_variant) ? lds : 0;
   b->xcd_remap = b->t_xcd < 0 ? 1 : (b->t_xcd ? 1 : 0);
   b->built = true;
   return EA_OK;
@@ -463,8 +567,8 @@ static void host_pose_state(const ea_problem *p, const double *q, const double *
 }
 
 static int batch_launch_eval(ea_batch *b) {
-  HIPCHK(launch_eval_fused(b->dtype, b->ppt, b->nt, b->d_probs, (int)b->probs.size(), b->chunk, b->max_chunks,
-                           b->xcd_remap, b->d_poses, b->d_partials, b->lds_bytes, b->stream));
+  HIPCHK(launch_eval_fused(b->dtype, b->ppt, b->nt, b->any_variant, b->d_probs, b->nterms, b->chunk, b->max_chunks,
+                           b->xcd_remap, b->d_poses, b->d_partials, b->lds_bytes, b->terms_are_groups, b->stream));
   return EA_OK;
 }
 
@@ -485,7 +589,7 @@ extern "C" int ea_batch_eval(ea_batch *b, const double *q, const double *t, doub
   if (rc != EA_OK) return rc;
   rc = batch_launch_eval(b);
   if (rc != EA_OK) return rc;
-  HIPCHK(launch_reduce(b->d_probs, count, b->d_partials, b->d_out, b->stream));
+  HIPCHK(launch_reduce(b->d_groups, count, b->d_partials, b->d_out, b->stream));
   HIPCHK(hipMemcpyAsync(b->h_out, b->d_out, count * sizeof(EvalOut), hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
   for (int i = 0; i < count; ++i) {
@@ -582,7 +686,7 @@ extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, 
     if (enq < budget && enq - done < ahead) {
       rc = batch_launch_eval(b);
       if (rc != EA_OK) return rc;
-      HIPCHK(launch_lm_step(b->d_probs, count, b->d_partials, b->d_poses, b->d_states, b->d_traces, lo,
+      HIPCHK(launch_lm_step(b->d_groups, count, b->d_partials, b->d_poses, b->d_states, b->d_traces, lo,
                             b->d_progress, b->stream));
       ++enq;
       spins = 0;
@@ -605,7 +709,9 @@ extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, 
     for (int k = 0; k < 4; ++k) q[4 * i + k] = s.x[k];
     for (int k = 0; k < 3; ++k) t[3 * i + k] = s.x[4 + k];
     const LMTrace &tr = b->h_traces[i];
-    if (summaries) fill_summary(s, tr, b->probs[i]->n, ms, &summaries[i]);
+    int64_t npts = b->probs[i]->n;
+    for (ea_problem *tm : b->probs[i]->terms) npts += tm->n;
+    if (summaries) fill_summary(s, tr, npts, ms, &summaries[i]);
     if (o.minimizer_progress_to_stdout) {
       std::printf("problem %d\niter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n", i);
       const int ni = std::min(s.iteration + 1, (int)kTrace);
@@ -631,7 +737,7 @@ extern "C" int ea_batch_bench_eval(ea_batch *b, const double *q, const double *t
   auto one_step = [&]() -> int {
     int r = batch_launch_eval(b);
     if (r != EA_OK) return r;
-    HIPCHK(launch_reduce(b->d_probs, count, b->d_partials, b->d_out, b->stream));
+    HIPCHK(launch_reduce(b->d_groups, count, b->d_partials, b->d_out, b->stream));
     return EA_OK;
   };
   for (int i = 0; i < warmup; ++i) if ((rc = one_step()) != EA_OK) return rc;
@@ -652,7 +758,7 @@ extern "C" int ea_batch_bench_eval(ea_batch *b, const double *q, const double *t
       HIPCHK(hipEventRecord(ev[2 * i], b->stream));
       if ((rc = batch_launch_eval(b)) != EA_OK) return rc;
       HIPCHK(hipEventRecord(ev[2 * i + 1], b->stream));
-      HIPCHK(launch_reduce(b->d_probs, count, b->d_partials, b->d_out, b->stream));
+      HIPCHK(launch_reduce(b->d_groups, count, b->d_partials, b->d_out, b->stream));
     }
     HIPCHK(hipStreamSynchronize(b->stream));
     double sum = 0.0;

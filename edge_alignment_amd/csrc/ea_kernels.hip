@@ -19,6 +19,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "ea_lm.h"
 #include "ea_types.h"
 
@@ -70,6 +72,11 @@ template <> struct Uni<double> {
   static __device__ __forceinline__ double loss_a(const ProblemDesc &pd) { return pd.loss_a; }
   static __device__ __forceinline__ double z_guard(const ProblemDesc &pd) { return pd.z_guard; }
   static __device__ __forceinline__ double z_eps(const ProblemDesc &pd) { return pd.z_eps; }
+  static __device__ __forceinline__ const double *dist(const ProblemDesc &pd) { return pd.dist; }
+  static __device__ __forceinline__ const double *A(const ProblemDesc &pd) { return pd.A; }
+  static __device__ __forceinline__ const double *d(const ProblemDesc &pd) { return pd.d; }
+  static __device__ __forceinline__ const double *Ai(const ProblemDesc &pd) { return pd.Ai; }
+  static __device__ __forceinline__ const double *di(const ProblemDesc &pd) { return pd.di; }
 };
 template <> struct Uni<float> {
   static __device__ __forceinline__ const float *R(const PoseState &ps) { return ps.Rf; }
@@ -82,6 +89,11 @@ template <> struct Uni<float> {
   static __device__ __forceinline__ float loss_a(const ProblemDesc &pd) { return pd.loss_af; }
   static __device__ __forceinline__ float z_guard(const ProblemDesc &pd) { return pd.z_guardf; }
   static __device__ __forceinline__ float z_eps(const ProblemDesc &pd) { return pd.z_epsf; }
+  static __device__ __forceinline__ const float *dist(const ProblemDesc &pd) { return pd.distf; }
+  static __device__ __forceinline__ const float *A(const ProblemDesc &pd) { return pd.Af; }
+  static __device__ __forceinline__ const float *d(const ProblemDesc &pd) { return pd.df; }
+  static __device__ __forceinline__ const float *Ai(const ProblemDesc &pd) { return pd.Aif; }
+  static __device__ __forceinline__ const float *di(const ProblemDesc &pd) { return pd.dif; }
 };
 
 // per-point state carried from the projection phase to the sampling phase
@@ -120,6 +132,106 @@ __device__ __forceinline__ void project_point(const ProblemDesc &pd, const PoseS
   o.iu = (int)fmin(fmax(uf, T(-2)), (T)pd.W);
   o.iv = (int)fmin(fmax(vf, T(-2)), (T)pd.H);
   o.state = bad ? 2 : 1;
+}
+
+// ---- residual variants: EAResidueEx (Brown-Conrady distortion, utils.h:102-177),
+// EAResidueSecondCam (second camera of a rigid rig, b_T_a' = T12 b_T_a T12^-1, utils.h:179-292) and both
+// (utils.h:295-421).  Same skeleton as the plain functor with an affine map either side of the pose and the
+// distortion chain rule in the gradient.
+template <typename T>
+struct ProjV {
+  T x, y, iz;       // normalised image coordinates and 1 / (b_z + z_eps)
+  T ax, ay, az;     // a' = T12^-1 a (the point the pose acts on)
+  T cx_, cy_, cz_;  // R a'
+  T xdx, xdy, ydx, ydy;  // d(distorted x,y) / d(x,y)
+  T fu, fv;
+  int iu, iv;
+  int state;
+};
+
+template <typename T>
+__device__ __forceinline__ void project_point_var(const ProblemDesc &pd, const PoseState &ps, T px, T py, T pz,
+                                                  ProjV<T> &o) {
+  const T *R = Uni<T>::R(ps);
+  const T *t = Uni<T>::t(ps);
+  T ax = px, ay = py, az = pz;
+  if (pd.variant & 2) {
+    const T *Ai = Uni<T>::Ai(pd), *di = Uni<T>::di(pd);
+    ax = t_fma<T>(Ai[2], pz, t_fma<T>(Ai[1], py, Ai[0] * px)) + di[0];
+    ay = t_fma<T>(Ai[5], pz, t_fma<T>(Ai[4], py, Ai[3] * px)) + di[1];
+    az = t_fma<T>(Ai[8], pz, t_fma<T>(Ai[7], py, Ai[6] * px)) + di[2];
+  }
+  const T cxr = t_fma<T>(R[2], az, t_fma<T>(R[1], ay, R[0] * ax));
+  const T cyr = t_fma<T>(R[5], az, t_fma<T>(R[4], ay, R[3] * ax));
+  const T czr = t_fma<T>(R[8], az, t_fma<T>(R[7], ay, R[6] * ax));
+  T bx = cxr + t[0], by = cyr + t[1], bz = czr + t[2];
+  if (pd.variant & 2) {
+    const T *A = Uni<T>::A(pd), *d = Uni<T>::d(pd);
+    const T c0 = bx, c1 = by, c2 = bz;
+    bx = t_fma<T>(A[2], c2, t_fma<T>(A[1], c1, A[0] * c0)) + d[0];
+    by = t_fma<T>(A[5], c2, t_fma<T>(A[4], c1, A[3] * c0)) + d[1];
+    bz = t_fma<T>(A[8], c2, t_fma<T>(A[7], c1, A[6] * c0)) + d[2];
+  }
+  const T zg = Uni<T>::z_guard(pd);
+  const bool bad = (zg > T(0)) && (bz < zg) && (bz > -zg);
+  const T iz = t_rcp<T>(bz + Uni<T>::z_eps(pd));
+  const T x = bx * iz, y = by * iz;
+  T xd = x, yd = y;
+  o.xdx = T(1); o.xdy = T(0); o.ydx = T(0); o.ydy = T(1);
+  if (pd.variant & 1) {
+    const T *k = Uni<T>::dist(pd);  // k1, k2, p1, p2, k3
+    const T r2 = t_fma<T>(x, x, y * y), r4 = r2 * r2, r6 = r4 * r2;
+    const T D = t_fma<T>(k[4], r6, t_fma<T>(k[1], r4, t_fma<T>(k[0], r2, T(1))));
+    const T Dp = t_fma<T>(T(3) * k[4], r4, t_fma<T>(T(2) * k[1], r2, k[0]));
+    const T xy = x * y;
+    xd = t_fma<T>(k[3], t_fma<T>(T(2) * x, x, r2), t_fma<T>(T(2) * k[2], xy, x * D));
+    yd = t_fma<T>(k[2], t_fma<T>(T(2) * y, y, r2), t_fma<T>(T(2) * k[3], xy, y * D));
+    o.xdx = t_fma<T>(T(6) * k[3], x, t_fma<T>(T(2) * k[2], y, t_fma<T>(T(2) * x * x, Dp, D)));
+    o.xdy = t_fma<T>(T(2) * k[3], y, t_fma<T>(T(2) * k[2], x, T(2) * xy * Dp));
+    o.ydx = t_fma<T>(T(2) * k[2], x, t_fma<T>(T(2) * k[3], y, T(2) * xy * Dp));
+    o.ydy = t_fma<T>(T(6) * k[2], y, t_fma<T>(T(2) * k[3], x, t_fma<T>(T(2) * y * y, Dp, D)));
+  }
+  const T u = t_fma<T>(Uni<T>::fx(pd), xd, Uni<T>::cx(pd));
+  const T v = t_fma<T>(Uni<T>::fy(pd), yd, Uni<T>::cy(pd));
+  const T uf = floor(u), vf = floor(v);
+  o.x = x; o.y = y; o.iz = iz;
+  o.ax = ax; o.ay = ay; o.az = az;
+  o.cx_ = cxr; o.cy_ = cyr; o.cz_ = czr;
+  o.fu = u - uf; o.fv = v - vf;
+  o.iu = (int)fmin(fmax(uf, T(-2)), (T)pd.W);
+  o.iv = (int)fmin(fmax(vf, T(-2)), (T)pd.H);
+  o.state = bad ? 2 : 1;
+}
+
+template <typename T>
+__device__ __forceinline__ void jacobian_row_var(const ProblemDesc &pd, const PoseState &ps, const ProjV<T> &pr,
+                                                 T Fu, T Fv, T J[6]) {
+  const T fu_ = Fu * Uni<T>::fx(pd), fv_ = Fv * Uni<T>::fy(pd);
+  const T rx = t_fma<T>(fv_, pr.ydx, fu_ * pr.xdx);  // d r / d x
+  const T ry = t_fma<T>(fv_, pr.ydy, fu_ * pr.xdy);  // d r / d y
+  T gx = rx * pr.iz, gy = ry * pr.iz, gz = -t_fma<T>(rx, pr.x, ry * pr.y) * pr.iz;  // d r / d b
+  if (pd.variant & 2) {  // back through b = A c + d:  g_c = A^T g_b
+    const T *A = Uni<T>::A(pd);
+    const T g0 = t_fma<T>(A[6], gz, t_fma<T>(A[3], gy, A[0] * gx));
+    const T g1 = t_fma<T>(A[7], gz, t_fma<T>(A[4], gy, A[1] * gx));
+    const T g2 = t_fma<T>(A[8], gz, t_fma<T>(A[5], gy, A[2] * gx));
+    gx = g0; gy = g1; gz = g2;
+  }
+  if (ps.unit_q) {
+    J[0] = T(2) * t_fma<T>(pr.cy_, gz, -(pr.cz_ * gy));
+    J[1] = T(2) * t_fma<T>(pr.cz_, gx, -(pr.cx_ * gz));
+    J[2] = T(2) * t_fma<T>(pr.cx_, gy, -(pr.cy_ * gx));
+  } else {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const T *G = Uni<T>::G(ps) + 9 * j;
+      const T d0 = t_fma<T>(G[2], pr.az, t_fma<T>(G[1], pr.ay, G[0] * pr.ax));
+      const T d1 = t_fma<T>(G[5], pr.az, t_fma<T>(G[4], pr.ay, G[3] * pr.ax));
+      const T d2 = t_fma<T>(G[8], pr.az, t_fma<T>(G[7], pr.ay, G[6] * pr.ax));
+      J[j] = t_fma<T>(gz, d2, t_fma<T>(gy, d1, gx * d0));
+    }
+  }
+  J[3] = gx; J[4] = gy; J[5] = gz;
 }
 
 // four consecutive texels of one image row; 4/8-byte aligned only (the hardware's unaligned
@@ -415,10 +527,11 @@ constexpr int kHdrBytes = kRedBytes + kMaxWaves * 16;  // + bbox words, keeps th
 
 // NT = workgroup size (256 or 1024).  1024 = one workgroup per CU: four times fewer partial rows
 // to fold afterwards at the same points-per-lane latency.
-template <typename T, int PPT, bool USE_LDS, int NT>
+template <typename T, int PPT, bool USE_LDS, int NT, bool VAR>
 __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
     const ProblemDesc *__restrict__ probs, const PoseState *__restrict__ poses,
-    double *__restrict__ partials, int chunk, int chunks_per_xcd, int xcd_remap, int lds_texels) {
+    double *__restrict__ partials, int chunk, int chunks_per_xcd, int xcd_remap, int lds_texels,
+    int terms_are_groups) {
   extern __shared__ __align__(16) unsigned char smem[];
   double *s_red = reinterpret_cast<double *>(smem);
   int *s_box = reinterpret_cast<int *>(smem + kRedBytes);
@@ -431,7 +544,9 @@ __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
   // descriptor and pose by value: every scalar load is issued here, behind one wait, instead of a
   // chain of dependent loads at the points of use
   const ProblemDesc pd = probs[blockIdx.y];
-  const PoseState &ps = poses[blockIdx.y];
+  // one pose per group of terms; when every problem is a single residual family the group index is
+  // the term index and the pose load does not have to wait for the descriptor
+  const PoseState &ps = poses[terms_are_groups ? (int)blockIdx.y : pd.group];
   const int active = ps.active;
   const long long start = (long long)c * chunk;
   if (start >= pd.n || !active) return;
@@ -452,7 +567,8 @@ __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
   // ---- phase 1: coalesced point loads, warp + projection.  Lanes past the end of the chunk
   // re-read its last point and lanes whose functor fails are moved to a harmless sample; both
   // get weight 0 below, so the arithmetic needs no divergent branch.
-  Proj<T> pr[PPT];
+  using ProjT = typename std::conditional<VAR, ProjV<T>, Proj<T>>::type;
+  ProjT pr[PPT];
   T X[PPT], Y[PPT], Z[PPT];
   bool valid[PPT];
   int n_bad = 0;
@@ -466,12 +582,19 @@ __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
     const bool inb = tid + k * NT < count;
-    project_point<T>(pd, ps, X[k], Y[k], Z[k], pr[k]);
+    if constexpr (VAR) project_point_var<T>(pd, ps, X[k], Y[k], Z[k], pr[k]);
+    else project_point<T>(pd, ps, X[k], Y[k], Z[k], pr[k]);
     valid[k] = inb && pr[k].state == 1;
     n_bad += (inb && pr[k].state == 2) ? 1 : 0;
     if (!valid[k]) {
       pr[k].iu = 0; pr[k].iv = 0; pr[k].fu = T(0); pr[k].fv = T(0);
-      pr[k].bx = T(0); pr[k].by = T(0); pr[k].iz = T(1);
+      pr[k].iz = T(1);
+      if constexpr (VAR) {
+        pr[k].x = T(0); pr[k].y = T(0);
+        pr[k].xdx = T(1); pr[k].xdy = T(0); pr[k].ydx = T(0); pr[k].ydy = T(1);
+      } else {
+        pr[k].bx = T(0); pr[k].by = T(0);
+      }
     }
     if (USE_LDS && valid[k]) {
       bb_u0 = min(bb_u0, pr[k].iu); bb_u1 = max(bb_u1, pr[k].iu);
@@ -534,7 +657,8 @@ __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
                  [&](int l) { return load_row4<T>(base + (ptrdiff_t)l * pitch); }, f, Fu, Fv);
     }
     T J[6];
-    jacobian_row<T>(pd, ps, pr[k], X[k], Y[k], Z[k], Fu, Fv, J);
+    if constexpr (VAR) jacobian_row_var<T>(pd, ps, pr[k], Fu, Fv, J);
+    else jacobian_row<T>(pd, ps, pr[k], X[k], Y[k], Z[k], Fu, Fv, J);
     T rho, w;
     loss_eval<T>(loss_kind, loss_a, f * f, rho, w);
     w = valid[k] ? w : T(0);
@@ -586,13 +710,40 @@ __global__ __launch_bounds__(kBlockThreads) void ea_eval_points_kernel(
     const ProblemDesc *__restrict__ probs, int problem, const PoseState *__restrict__ poses,
     double *__restrict__ r_out, double *__restrict__ J_out, int corrected) {
   const ProblemDesc &pd = probs[problem];
-  const PoseState &ps = poses[problem];
+  const PoseState &ps = poses[pd.group];
   const int i = blockIdx.x * kBlockThreads + threadIdx.x;
   if (i >= pd.n) return;
   const T x = static_cast<const T *>(pd.x)[i], y = static_cast<const T *>(pd.y)[i], z = static_cast<const T *>(pd.z)[i];
+  const double nan = __builtin_nan("");
+  if (pd.variant) {  // distortion / second-camera functors
+    ProjV<T> pv;
+    project_point_var<T>(pd, ps, x, y, z, pv);
+    if (pv.state != 1) {
+      if (r_out) r_out[i] = nan;
+      if (J_out)
+        for (int a = 0; a < 6; ++a) J_out[(size_t)i * 6 + a] = nan;
+      return;
+    }
+    const int pitchv = pd.pitch;
+    const T *basev = static_cast<const T *>(pd.dt) + (size_t)kImagePad * (size_t)pitchv + kImagePad +
+                     (ptrdiff_t)(pv.iv - 1) * pitchv + (pv.iu - 1);
+    T f, Fu, Fv;
+    bicubic<T>(pv.fu, pv.fv, [&](int l) { return *reinterpret_cast<const Row4<T> *>(basev + (ptrdiff_t)l * pitchv); }, f, Fu, Fv);
+    T J[6];
+    jacobian_row_var<T>(pd, ps, pv, Fu, Fv, J);
+    T sc = T(1);
+    if (corrected) {
+      T rho, w;
+      loss_eval<T>(pd.loss_kind, Uni<T>::loss_a(pd), f * f, rho, w);
+      sc = t_sqrt<T>(w);
+    }
+    if (r_out) r_out[i] = (double)(sc * f);
+    if (J_out)
+      for (int a = 0; a < 6; ++a) J_out[(size_t)i * 6 + a] = (double)(sc * J[a]);
+    return;
+  }
   Proj<T> pr;
   project_point<T>(pd, ps, x, y, z, pr);
-  const double nan = __builtin_nan("");
   if (pr.state != 1) {
     if (r_out) r_out[i] = nan;
     if (J_out)
@@ -651,19 +802,19 @@ __device__ __forceinline__ void reduce_tiles(const double *__restrict__ partials
   }
 }
 
-__global__ __launch_bounds__(kFoldThreads) void ea_reduce_kernel(const ProblemDesc *__restrict__ probs,
+__global__ __launch_bounds__(kFoldThreads) void ea_reduce_kernel(const GroupDesc *__restrict__ groups,
                                                                   const double *__restrict__ partials,
                                                                   EvalOut *__restrict__ out) {
   __shared__ double s_part[(kFoldThreads / 32) * kAccSlots];
-  const ProblemDesc &pd = probs[blockIdx.x];
-  reduce_tiles<kFoldThreads>(partials, pd.tile_begin, pd.tile_end, s_part, out[blockIdx.x].acc);
+  const GroupDesc gd = groups[blockIdx.x];
+  reduce_tiles<kFoldThreads>(partials, gd.tile_begin, gd.tile_end, s_part, out[blockIdx.x].acc);
 }
 
 // LM step: fold this problem's partial rows, advance the trust-region state machine, publish the
 // next pose to evaluate.  One workgroup per problem.  The state machine is scalar fp64 work on
 // lane 0; its state is staged in LDS so the dependent field accesses cost LDS, not HBM, latency.
 __global__ __launch_bounds__(kLmThreads) void ea_lm_step_kernel(
-    const ProblemDesc *__restrict__ probs, const double *__restrict__ partials,
+    const GroupDesc *__restrict__ groups, const double *__restrict__ partials,
     PoseState *__restrict__ poses, LMState *__restrict__ states, LMTrace *__restrict__ traces,
     LMOptions opt, int *__restrict__ progress /* pinned host: [running x n | evals x n] */) {
   __shared__ double s_part[(kLmThreads / 32) * kAccSlots];
@@ -678,8 +829,8 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_step_kernel(
     double *dst = reinterpret_cast<double *>(&s_st);
     for (int i = threadIdx.x; i < (int)(sizeof(LMState) / 8); i += kLmThreads) dst[i] = src[i];
   }
-  const ProblemDesc &pd = probs[p];
-  reduce_tiles<kLmThreads>(partials, pd.tile_begin, pd.tile_end, s_part, s_acc);
+  const GroupDesc gd = groups[p];
+  reduce_tiles<kLmThreads>(partials, gd.tile_begin, gd.tile_end, s_part, s_acc);
   __syncthreads();
   if (threadIdx.x == 0) {
     double acc[kAccSlots];
@@ -716,23 +867,26 @@ __global__ void ea_pad_image_kernel(const T *__restrict__ src, int H, int W, T *
 // ------------------------------------------------------------------------------------------------
 // launchers (called from ea_capi.cpp)
 
-hipError_t launch_eval_fused(int dtype, int ppt, int nt, const ProblemDesc *probs, int count, int chunk,
+hipError_t launch_eval_fused(int dtype, int ppt, int nt, int variant, const ProblemDesc *probs, int nterms, int chunk,
                              int max_chunks, int xcd_remap, const PoseState *poses, double *partials,
-                             int lds_bytes, hipStream_t stream) {
-  if (count <= 0 || max_chunks <= 0) return hipSuccess;
+                             int lds_bytes, int terms_are_groups, hipStream_t stream) {
+  if (nterms <= 0 || max_chunks <= 0) return hipSuccess;
   const int chunks_per_xcd = (max_chunks + 7) / 8;
-  const dim3 grid(xcd_remap ? chunks_per_xcd * 8 : max_chunks, count);
+  const dim3 grid(xcd_remap ? chunks_per_xcd * 8 : max_chunks, nterms);
   const int esz = dtype == 1 ? 4 : 8;
   const int lds_texels = lds_bytes > 0 ? lds_bytes / esz : 0;
   const size_t shmem = (size_t)kHdrBytes + (size_t)lds_texels * esz;
-#define EA_LAUNCH(T, P, L, N)                                                                \
-  hipLaunchKernelGGL((ea_eval_fused_kernel<T, P, L, N>), grid, dim3(N), shmem, stream, probs, \
-                     poses, partials, chunk, chunks_per_xcd, xcd_remap, lds_texels)
-#define EA_LAUNCH_L(T, P, N)                                          \
-  do {                                                                \
-    if (lds_texels > 0) EA_LAUNCH(T, P, true, N); else EA_LAUNCH(T, P, false, N); \
+#define EA_LAUNCH(T, P, L, N, V)                                                                \
+  hipLaunchKernelGGL((ea_eval_fused_kernel<T, P, L, N, V>), grid, dim3(N), shmem, stream, probs, \
+                     poses, partials, chunk, chunks_per_xcd, xcd_remap, lds_texels, terms_are_groups)
+#define EA_LAUNCH_L(T, P, N)                                                                  \
+  do {                                                                                        \
+    if (lds_texels > 0) EA_LAUNCH(T, P, true, N, false); else EA_LAUNCH(T, P, false, N, false); \
   } while (0)
-  if (dtype == 1) {
+  if (variant) {  // distortion / second-camera terms: 256-thread workgroups, L2 path, 1-2 points per lane
+    if (dtype == 1) { if (ppt == 1) EA_LAUNCH(float, 1, false, 256, true); else EA_LAUNCH(float, 2, false, 256, true); }
+    else { if (ppt == 1) EA_LAUNCH(double, 1, false, 256, true); else EA_LAUNCH(double, 2, false, 256, true); }
+  } else if (dtype == 1) {
     if (nt == 1024) { if (ppt == 1) EA_LAUNCH_L(float, 1, 1024); else if (ppt == 2) EA_LAUNCH_L(float, 2, 1024); else EA_LAUNCH_L(float, 4, 1024); }
     else if (ppt == 1) EA_LAUNCH_L(float, 1, 256);
     else if (ppt == 2) EA_LAUNCH_L(float, 2, 256);
@@ -760,18 +914,18 @@ hipError_t launch_eval_points(int dtype, const ProblemDesc *probs, int problem, 
   return hipGetLastError();
 }
 
-hipError_t launch_reduce(const ProblemDesc *probs, int count, const double *partials, EvalOut *out,
+hipError_t launch_reduce(const GroupDesc *groups, int count, const double *partials, EvalOut *out,
                          hipStream_t stream) {
   if (count <= 0) return hipSuccess;
-  hipLaunchKernelGGL(ea_reduce_kernel, dim3(count), dim3(kFoldThreads), 0, stream, probs, partials, out);
+  hipLaunchKernelGGL(ea_reduce_kernel, dim3(count), dim3(kFoldThreads), 0, stream, groups, partials, out);
   return hipGetLastError();
 }
 
-hipError_t launch_lm_step(const ProblemDesc *probs, int count, const double *partials, PoseState *poses,
+hipError_t launch_lm_step(const GroupDesc *groups, int count, const double *partials, PoseState *poses,
                           LMState *states, LMTrace *traces, const LMOptions &opt, int *progress,
                           hipStream_t stream) {
   if (count <= 0) return hipSuccess;
-  hipLaunchKernelGGL(ea_lm_step_kernel, dim3(count), dim3(kLmThreads), 0, stream, probs, partials, poses,
+  hipLaunchKernelGGL(ea_lm_step_kernel, dim3(count), dim3(kLmThreads), 0, stream, groups, partials, poses,
                      states, traces, opt, progress);
   return hipGetLastError();
 }

@@ -40,8 +40,22 @@ struct ProblemDesc {
   float loss_af, z_guardf, z_epsf;
   int32_t loss_kind;
   int32_t rot_transposed;
-  int32_t tile_begin, tile_end;  // this problem's rows in the partial-sum array (one per workgroup)
-  int32_t pad_;
+  int32_t tile_begin, tile_end;  // this term's rows in the partial-sum array (one per workgroup)
+  int32_t group;                 // which pose / LM state this residual family belongs to
+  // residual variants of standalone/utils.h:102-421 (variant != 0 selects the variant kernel)
+  int32_t variant;               // bit 0: Brown-Conrady distortion, bit 1: second camera of a rigid rig
+  int32_t pad_[3];
+  double dist[5];                // k1, k2, p1, p2, k3
+  double A[9], d[3];             // second camera: b = A (R a' + t) + d,  [A d] = affine part of T12
+  double Ai[9], di[3];           //                a' = Ai a + di,        [Ai di] = affine part of T12^-1
+  float distf[5];
+  float Af[9], df[3], Aif[9], dif[3];
+};
+
+// a group = the residual families (terms) that share one pose; its rows are contiguous
+struct GroupDesc {
+  int32_t tile_begin, tile_end;
+  int32_t term_begin, term_end;
 };
 
 // Pose-dependent constants, rebuilt whenever a pose changes (by the host for ea_eval, by the

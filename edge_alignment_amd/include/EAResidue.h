@@ -56,3 +56,111 @@ class EAResidue {
   double fx, fy, cx, cy;
   double a_Xx, a_Xy, a_Xz;
 };
+
+// ---- variants of standalone/utils.h:102-421: carriers with the reference's constructors and Create() -----
+
+// distortion (utils.h:102-177)
+class EAResidueEx {
+ public:
+  typedef EAResidue::Interpolator Interpolator;
+  EAResidueEx(const double fx, const double fy, const double cx, const double cy, const double k1, const double k2,
+              const double p1, const double p2, const double k3, const double a_Xx, const double a_Xy,
+              const double a_Xz, const Interpolator &__interpolated_a)
+      : interp_a(__interpolated_a), fx(fx), fy(fy), cx(cx), cy(cy), k1(k1), k2(k2), p1(p1), p2(p2), k3(k3),
+        a_Xx(a_Xx), a_Xy(a_Xy), a_Xz(a_Xz) {}
+  static ceres::CostFunction *Create(const double fx, const double fy, const double cx, const double cy,
+                                     const double k1, const double k2, const double p1, const double p2,
+                                     const double k3, const double a_Xx, const double a_Xy, const double a_Xz,
+                                     const Interpolator &__interpolated_a) {
+    return (new ceres::AutoDiffCostFunction<EAResidueEx, 1, 4, 3>(
+        new EAResidueEx(fx, fy, cx, cy, k1, k2, p1, p2, k3, a_Xx, a_Xy, a_Xz, __interpolated_a)));
+  }
+  bool ea_describe(ceres::EABlockInfo *b) const {
+    b->fx = fx; b->fy = fy; b->cx = cx; b->cy = cy;
+    b->X = a_Xx; b->Y = a_Xy; b->Z = a_Xz;
+    b->grid_data = interp_a.grid().data(); b->grid_rows = interp_a.grid().num_rows(); b->grid_cols = interp_a.grid().num_cols();
+    b->z_guard = 0.01; b->z_eps = 0.0; b->rot_transposed = 0;
+    b->variant = 1;
+    b->dist[0] = k1; b->dist[1] = k2; b->dist[2] = p1; b->dist[3] = p2; b->dist[4] = k3;
+    return true;
+  }
+
+ private:
+  const Interpolator &interp_a;
+  double fx, fy, cx, cy;
+  double k1, k2, p1, p2, k3;
+  double a_Xx, a_Xy, a_Xz;
+};
+
+// second camera of a rigid rig (utils.h:179-292): b_T_a_SecCam = trans_1to2 * b_T_a * trans_1to2_inv
+class EAResidueSecondCam {
+ public:
+  typedef EAResidue::Interpolator Interpolator;
+  EAResidueSecondCam(const double fx, const double fy, const double cx, const double cy, const double a_Xx,
+                     const double a_Xy, const double a_Xz, const double *ptrans_1to2, const double *ptrans_1to2_inv,
+                     const Interpolator &__interpolated_a)
+      : interp_a(__interpolated_a), fx(fx), fy(fy), cx(cx), cy(cy), a_Xx(a_Xx), a_Xy(a_Xy), a_Xz(a_Xz) {
+    for (int i = 0; i < 16; ++i) { T12[i] = ptrans_1to2[i]; T12inv[i] = ptrans_1to2_inv[i]; }
+  }
+  static ceres::CostFunction *Create(const double fx, const double fy, const double cx, const double cy,
+                                     const double a_Xx, const double a_Xy, const double a_Xz,
+                                     const double *ptrans_1to2, const double *ptrans_1to2_inv,
+                                     const Interpolator &__interpolated_a) {
+    return (new ceres::AutoDiffCostFunction<EAResidueSecondCam, 1, 4, 3>(
+        new EAResidueSecondCam(fx, fy, cx, cy, a_Xx, a_Xy, a_Xz, ptrans_1to2, ptrans_1to2_inv, __interpolated_a)));
+  }
+  bool ea_describe(ceres::EABlockInfo *b) const {
+    b->fx = fx; b->fy = fy; b->cx = cx; b->cy = cy;
+    b->X = a_Xx; b->Y = a_Xy; b->Z = a_Xz;
+    b->grid_data = interp_a.grid().data(); b->grid_rows = interp_a.grid().num_rows(); b->grid_cols = interp_a.grid().num_cols();
+    b->z_guard = 0.01; b->z_eps = 0.0; b->rot_transposed = 0;
+    b->variant = 2;
+    for (int i = 0; i < 16; ++i) { b->T12[i] = T12[i]; b->T12inv[i] = T12inv[i]; }
+    return true;
+  }
+
+ private:
+  const Interpolator &interp_a;
+  double fx, fy, cx, cy;
+  double a_Xx, a_Xy, a_Xz;
+  double T12[16], T12inv[16];
+};
+
+// second camera + distortion (utils.h:295-421)
+class EAResidueSecondCamEx {
+ public:
+  typedef EAResidue::Interpolator Interpolator;
+  EAResidueSecondCamEx(const double fx, const double fy, const double cx, const double cy, const double k1,
+                       const double k2, const double p1, const double p2, const double k3, const double a_Xx,
+                       const double a_Xy, const double a_Xz, const double *ptrans_1to2,
+                       const double *ptrans_1to2_inv, const Interpolator &__interpolated_a)
+      : interp_a(__interpolated_a), fx(fx), fy(fy), cx(cx), cy(cy), k1(k1), k2(k2), p1(p1), p2(p2), k3(k3),
+        a_Xx(a_Xx), a_Xy(a_Xy), a_Xz(a_Xz) {
+    for (int i = 0; i < 16; ++i) { T12[i] = ptrans_1to2[i]; T12inv[i] = ptrans_1to2_inv[i]; }
+  }
+  static ceres::CostFunction *Create(const double fx, const double fy, const double cx, const double cy,
+                                     const double k1, const double k2, const double p1, const double p2,
+                                     const double k3, const double a_Xx, const double a_Xy, const double a_Xz,
+                                     const double *ptrans_1to2, const double *ptrans_1to2_inv,
+                                     const Interpolator &__interpolated_a) {
+    return (new ceres::AutoDiffCostFunction<EAResidueSecondCamEx, 1, 4, 3>(new EAResidueSecondCamEx(
+        fx, fy, cx, cy, k1, k2, p1, p2, k3, a_Xx, a_Xy, a_Xz, ptrans_1to2, ptrans_1to2_inv, __interpolated_a)));
+  }
+  bool ea_describe(ceres::EABlockInfo *b) const {
+    b->fx = fx; b->fy = fy; b->cx = cx; b->cy = cy;
+    b->X = a_Xx; b->Y = a_Xy; b->Z = a_Xz;
+    b->grid_data = interp_a.grid().data(); b->grid_rows = interp_a.grid().num_rows(); b->grid_cols = interp_a.grid().num_cols();
+    b->z_guard = 0.01; b->z_eps = 0.0; b->rot_transposed = 0;
+    b->variant = 3;
+    b->dist[0] = k1; b->dist[1] = k2; b->dist[2] = p1; b->dist[3] = p2; b->dist[4] = k3;
+    for (int i = 0; i < 16; ++i) { b->T12[i] = T12[i]; b->T12inv[i] = T12inv[i]; }
+    return true;
+  }
+
+ private:
+  const Interpolator &interp_a;
+  double fx, fy, cx, cy;
+  double k1, k2, p1, p2, k3;
+  double a_Xx, a_Xy, a_Xz;
+  double T12[16], T12inv[16];
+};

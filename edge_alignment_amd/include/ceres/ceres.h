@@ -42,6 +42,11 @@ struct EABlockInfo {
   int grid_rows, grid_cols;
   double z_guard, z_eps;    // functor flavour (standalone: 0.01, 0; ROS: 0, 0.001)
   int rot_transposed;
+  // residual variants (utils.h:102-421); zero-initialised = plain EAResidue
+  int variant = 0;          // bit 0: distortion (k1,k2,p1,p2,k3), bit 1: second camera (T12, T12inv)
+  double dist[5] = {0, 0, 0, 0, 0};
+  double T12[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  double T12inv[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
 };
 
 class CostFunction {
@@ -227,30 +232,40 @@ class ProblemAccess {  // keeps Problem's internals private to user code
     if (options.minimizer_type != TRUST_REGION) return fail("only TRUST_REGION is supported");
     if (blocks.empty()) { s.termination_type = CONVERGENCE; s.message = "No residual blocks."; s.initial_cost = s.final_cost = 0; s.num_successful_steps = s.num_unsuccessful_steps = 0; return; }
     const auto &b0 = blocks[0];
-    std::vector<double> xyz(3 * blocks.size());
+    // Split the blocks into residual families: same interpolator, intrinsics, functor variant and loss.
+    // The first family becomes the problem, the others its terms; all of them share (q, t), the way the
+    // reference adds camera-1 and camera-2 blocks to one ceres::Problem (standalone_edge_align.cpp:791-803).
+    struct Family { const Problem::Block *first; std::vector<double> xyz; };
+    std::vector<Family> fams;
     for (size_t i = 0; i < blocks.size(); ++i) {
       const auto &b = blocks[i];
-      if (!b.ok) return fail("residual block is not an EAResidue block (this facade only hosts the edge-alignment hot path)");
+      if (!b.ok) return fail("residual block is not an EAResidue-family block (this facade only hosts the edge-alignment hot path)");
       if (b.q != b0.q || b.t != b0.t) return fail("all residual blocks must share one (quaternion, translation) pair");
-      if (b.info.grid_data != b0.info.grid_data || b.info.grid_rows != b0.info.grid_rows || b.info.grid_cols != b0.info.grid_cols)
-        return fail("all residual blocks must sample the same interpolator");
-      if (b.info.fx != b0.info.fx || b.info.fy != b0.info.fy || b.info.cx != b0.info.cx || b.info.cy != b0.info.cy)
-        return fail("all residual blocks must share the camera intrinsics");
-      if (!SameLoss(b.loss, b0.loss)) return fail("all residual blocks must use the same loss function");
-      xyz[3 * i + 0] = b.info.X; xyz[3 * i + 1] = b.info.Y; xyz[3 * i + 2] = b.info.Z;
+      Family *f = nullptr;
+      for (auto &cand : fams)
+        if (SameFamily(*cand.first, b)) { f = &cand; break; }
+      if (!f) { fams.push_back(Family{&b, {}}); f = &fams.back(); }
+      f->xyz.push_back(b.info.X); f->xyz.push_back(b.info.Y); f->xyz.push_back(b.info.Z);
     }
     if (problem->quat_param_on_ != b0.q)
       return fail("the quaternion block needs QuaternionParameterization (problem.SetParameterization)");
-    ea_camera cam = {b0.info.fx, b0.info.fy, b0.info.cx, b0.info.cy};
-    ea_problem *p = nullptr;
-    int rc = ea_problem_create(&p, &cam, options.ea_dtype, options.ea_device);
-    if (rc == EA_OK) rc = ea_problem_set_points(p, xyz.data(), (int64_t)blocks.size(), 3);
-    if (rc == EA_OK) rc = ea_problem_set_dt(p, b0.info.grid_data, b0.info.grid_rows, b0.info.grid_cols);
-    if (rc == EA_OK) rc = ea_problem_set_flavour(p, b0.info.z_guard, b0.info.z_eps, b0.info.rot_transposed);
-    if (rc == EA_OK) {
-      int kind = EA_LOSS_TRIVIAL; double a = 1.0;
-      if (b0.loss) { kind = b0.loss->ea_kind(); a = b0.loss->ea_scale(); }
-      rc = ea_problem_set_loss(p, kind, a);
+    std::vector<ea_problem *> ps(fams.size(), nullptr);
+    int rc = EA_OK;
+    for (size_t k = 0; k < fams.size() && rc == EA_OK; ++k) {
+      const auto &bi = fams[k].first->info;
+      ea_camera cam = {bi.fx, bi.fy, bi.cx, bi.cy};
+      rc = ea_problem_create(&ps[k], &cam, options.ea_dtype, options.ea_device);
+      if (rc == EA_OK) rc = ea_problem_set_points(ps[k], fams[k].xyz.data(), (int64_t)(fams[k].xyz.size() / 3), 3);
+      if (rc == EA_OK) rc = ea_problem_set_dt(ps[k], bi.grid_data, bi.grid_rows, bi.grid_cols);
+      if (rc == EA_OK) rc = ea_problem_set_flavour(ps[k], bi.z_guard, bi.z_eps, bi.rot_transposed);
+      if (rc == EA_OK && (bi.variant & 1)) rc = ea_problem_set_distortion(ps[k], bi.dist[0], bi.dist[1], bi.dist[2], bi.dist[3], bi.dist[4]);
+      if (rc == EA_OK && (bi.variant & 2)) rc = ea_problem_set_second_camera(ps[k], bi.T12, bi.T12inv);
+      if (rc == EA_OK) {
+        int kind = EA_LOSS_TRIVIAL; double a = 1.0;
+        if (fams[k].first->loss) { kind = fams[k].first->loss->ea_kind(); a = fams[k].first->loss->ea_scale(); }
+        rc = ea_problem_set_loss(ps[k], kind, a);
+      }
+      if (rc == EA_OK && k > 0) rc = ea_problem_add_term(ps[0], ps[k]);
     }
     ea_options o;
     ea_default_options(&o);
@@ -268,9 +283,11 @@ class ProblemAccess {  // keeps Problem's internals private to user code
     o.jacobi_scaling = options.jacobi_scaling ? 1 : 0;
     o.strategy = options.trust_region_strategy_type == DOGLEG ? EA_STRATEGY_DOGLEG : EA_STRATEGY_LM;
     o.minimizer_progress_to_stdout = options.minimizer_progress_to_stdout ? 1 : 0;
-    if (rc == EA_OK) rc = ea_solve(p, &o, b0.q, b0.t, &s.detail);  // q, t updated in place, like Ceres
-    if (p) ea_problem_destroy(p);
-    if (rc != EA_OK) return fail(std::string("libea_hip: ") + ea_last_error());
+    if (rc == EA_OK) rc = ea_solve(ps[0], &o, b0.q, b0.t, &s.detail);  // q, t updated in place, like Ceres
+    const std::string err = rc != EA_OK ? std::string(ea_last_error()) : std::string();
+    for (size_t k = 0; k < ps.size(); ++k)
+      if (ps[k]) ea_problem_destroy(ps[k]);
+    if (rc != EA_OK) return fail(std::string("libea_hip: ") + err);
     s.termination_type = s.detail.termination == EA_CONVERGENCE ? CONVERGENCE : (s.detail.termination == EA_NO_CONVERGENCE ? NO_CONVERGENCE : FAILURE);
     s.message = internal::WhyMessage(s.detail.why);
     s.initial_cost = s.detail.initial_cost;
@@ -281,6 +298,16 @@ class ProblemAccess {  // keeps Problem's internals private to user code
   }
 
  private:
+  static bool SameFamily(const Problem::Block &a, const Problem::Block &b) {
+    const EABlockInfo &x = a.info, &y = b.info;
+    if (x.grid_data != y.grid_data || x.grid_rows != y.grid_rows || x.grid_cols != y.grid_cols) return false;
+    if (x.fx != y.fx || x.fy != y.fy || x.cx != y.cx || x.cy != y.cy) return false;
+    if (x.z_guard != y.z_guard || x.z_eps != y.z_eps || x.rot_transposed != y.rot_transposed) return false;
+    if (x.variant != y.variant) return false;
+    for (int i = 0; i < 5; ++i) if (x.dist[i] != y.dist[i]) return false;
+    for (int i = 0; i < 16; ++i) if (x.T12[i] != y.T12[i] || x.T12inv[i] != y.T12inv[i]) return false;
+    return SameLoss(a.loss, b.loss);
+  }
   static bool SameLoss(const LossFunction *a, const LossFunction *b) {
     const int ka = a ? a->ea_kind() : EA_LOSS_TRIVIAL, kb = b ? b->ea_kind() : EA_LOSS_TRIVIAL;
     if (ka != kb) return false;

@@ -133,3 +133,38 @@ def config_c3_levels(seed=3):
                                    (cx0 + 0.5) / s - 0.5, (cy0 + 0.5) / s - 0.5,
                                    planted_q=q, planted_t=t, normalize=False))
     return levels
+
+
+def rigid_4x4(q, t):
+    T = np.eye(4)
+    T[:3, :3] = quat_to_R(np.asarray(q, float) / np.linalg.norm(q))
+    T[:3, 3] = t
+    return T
+
+
+def make_stereo_problem(H, W, n1, n2, seed, K1, K2, T12, planted_q, planted_t, distortion=None, normalize=True):
+    """Two residual families on one pose, the shape of the reference's stereo tests
+    (standalone_edge_align.cpp:791-803): camera-1 points with EAResidue[Ex], camera-2 points with
+    EAResidueSecondCam[Ex] whose pose is T12 * b_T_a * T12^-1.  Points are planted on the edges of each
+    camera's DT image (through the distortion model when given, by fixed-point inversion)."""
+    Tp = rigid_4x4(planted_q, planted_t)
+    T2 = T12 @ Tp @ np.linalg.inv(T12)
+    out = []
+    for cam, (K, n, Tcam) in enumerate(((K1, n1, Tp), (K2, n2, T2))):
+        pr = make_problem(H, W, n, max(8, n // 100), seed * 10 + cam, *K, normalize=normalize)
+        fx, fy, cx, cy = K
+        # make_problem planted identity: xyz are frame-B points on the edges; undistort, then move back by Tcam
+        b = pr["xyz"]
+        if distortion is not None:
+            k1, k2, p1, p2, k3 = distortion
+            xd, yd = b[:, 0] / b[:, 2], b[:, 1] / b[:, 2]
+            x, y = xd.copy(), yd.copy()
+            for _ in range(50):
+                r2 = x * x + y * y
+                D = 1 + k1 * r2 + k2 * r2 ** 2 + k3 * r2 ** 3
+                x = (xd - 2 * p1 * x * y - p2 * (r2 + 2 * x * x)) / D
+                y = (yd - 2 * p2 * x * y - p1 * (r2 + 2 * y * y)) / D
+            b = np.stack([x * b[:, 2], y * b[:, 2], b[:, 2]], axis=1)
+        a = (b - Tcam[:3, 3]) @ Tcam[:3, :3]   # a = R^T (b - t)
+        out.append(dict(xyz=a, grid=pr["grid"], image=pr["image"], K=K))
+    return out

@@ -152,6 +152,21 @@ int ea_problem_set_loss(ea_problem *p, int loss_kind, double a);
 int ea_problem_set_flavour(ea_problem *p, double z_guard, double z_eps, int rot_transposed);
 int64_t ea_problem_num_points(const ea_problem *p);
 
+/* Residual variants of standalone/utils.h.
+ * Distortion: EAResidueEx / EAResidueSecondCamEx (utils.h:102-177, :295-421), coefficients in the order
+ * of EAResidueEx::Create(fx,fy,cx,cy, k1,k2,p1,p2,k3, ...) (utils.h:156-160).  All zero = off. */
+int ea_problem_set_distortion(ea_problem *p, double k1, double k2, double p1, double p2, double k3);
+/* Second camera of a rigid rig: EAResidueSecondCam[Ex] (utils.h:179-292) evaluates
+ * b_T_a_SecCam = trans_1to2 * b_T_a * trans_1to2_inv; both row-major 4x4 with last row 0 0 0 1, exactly the
+ * ptrans_1to2 / ptrans_1to2_inv arrays.  NULL, NULL = first camera again. */
+int ea_problem_set_second_camera(ea_problem *p, const double trans_1to2[16], const double trans_1to2_inv[16]);
+/* Several residual families on ONE pose — the reference adds camera-1 and camera-2 blocks to the same
+ * ceres::Problem with the same (q,t) (standalone_edge_align.cpp:791-803, :3205-3218).  `term` keeps its own
+ * points, DT image, intrinsics, loss and variant; it must outlive `p` (borrowed).  ea_eval / ea_solve on `p`
+ * then cover p and all its terms. */
+int ea_problem_add_term(ea_problem *p, ea_problem *term);
+int ea_problem_clear_terms(ea_problem *p);
+
 /* One evaluation of the whole problem at pose (q,t) — what ceres' evaluator computes from the
  * N AutoDiffCostFunction<EAResidue,1,4,3> blocks + QuaternionParameterization + loss:
  *   cost = 1/2 sum rho(r_i^2);  JtJ (6x6 row-major) and Jtr (6) of the loss-corrected 1x6 rows

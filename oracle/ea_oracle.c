@@ -44,6 +44,9 @@ void ea_oracle_default_problem(ea_oracle_problem *p) {
   p->z_guard = 0.01;                    /* ref: standalone/utils.h:70 */
   p->z_eps = 0.0;
   p->rot_transposed = 0;
+  p->use_distortion = 0;
+  p->use_second_cam = 0;
+  for (int i = 0; i < 16; ++i) p->T12[i] = p->T12inv[i] = (i % 5 == 0) ? 1.0 : 0.0;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -177,22 +180,70 @@ static int functor_jet(const ea_oracle_problem *p, const jet quat[4], const jet 
         R[j][i] = tmp;
       }
   }
-  /* b_X = b_T_a * [a;1]  — utils.h:54-67 ; row i: R(i,0)a0 + R(i,1)a1 + R(i,2)a2 + t(i)*1 */
   jet b[3];
-  for (int i = 0; i < 3; ++i) {
-    jet s = jet_mul(R[i][0], jet_const(X[0]));
-    s = jet_add(s, jet_mul(R[i][1], jet_const(X[1])));
-    s = jet_add(s, jet_mul(R[i][2], jet_const(X[2])));
-    s = jet_add(s, jet_mul(t[i], jet_const(1.0)));
-    b[i] = s;
+  if (!p->use_second_cam) {
+    /* b_X = b_T_a * [a;1]  — utils.h:54-67 ; row i: R(i,0)a0 + R(i,1)a1 + R(i,2)a2 + t(i)*1 */
+    for (int i = 0; i < 3; ++i) {
+      jet s = jet_mul(R[i][0], jet_const(X[0]));
+      s = jet_add(s, jet_mul(R[i][1], jet_const(X[1])));
+      s = jet_add(s, jet_mul(R[i][2], jet_const(X[2])));
+      s = jet_add(s, jet_mul(t[i], jet_const(1.0)));
+      b[i] = s;
+    }
+  } else {
+    /* utils.h:242-256: b_T_a_SecCam = TransformFromFirstCam * b_T_a * TransformFromFirstCamInv  (4x4 Jet
+     * products, left to right), then b_X = b_T_a_SecCam * [a;1] */
+    jet M[4][4], L[4][4], S[4][4];
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) M[i][j] = jet_const(0.0);
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) M[i][j] = R[i][j];
+      M[i][3] = t[i];
+    }
+    M[3][3] = jet_const(1.0);
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        jet acc = jet_const(0.0);
+        for (int k = 0; k < 4; ++k) acc = jet_add(acc, jet_mul(jet_const(p->T12[4 * i + k]), M[k][j]));
+        L[i][j] = acc;
+      }
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        jet acc = jet_const(0.0);
+        for (int k = 0; k < 4; ++k) acc = jet_add(acc, jet_mul(L[i][k], jet_const(p->T12inv[4 * k + j])));
+        S[i][j] = acc;
+      }
+    for (int i = 0; i < 3; ++i) {
+      jet s = jet_mul(S[i][0], jet_const(X[0]));
+      s = jet_add(s, jet_mul(S[i][1], jet_const(X[1])));
+      s = jet_add(s, jet_mul(S[i][2], jet_const(X[2])));
+      s = jet_add(s, jet_mul(S[i][3], jet_const(1.0)));
+      b[i] = s;
+    }
   }
   /* z guard — utils.h:70-73 (comparisons look at the scalar part only) */
   if (p->z_guard > 0.0 && b[2].a < p->z_guard && b[2].a > -p->z_guard) return 0;
   jet bz = b[2];
   if (p->z_eps != 0.0) bz = jet_add(bz, jet_const(p->z_eps));
-  /* _u = T(fx)*b_X(0)/b_X(2) + T(cx) — utils.h:74-75 */
-  const jet u = jet_add(jet_div(jet_mul(jet_const(p->fx), b[0]), bz), jet_const(p->cx));
-  const jet v = jet_add(jet_div(jet_mul(jet_const(p->fy), b[1]), bz), jet_const(p->cy));
+  jet u, v;
+  if (!p->use_distortion) {
+    /* _u = T(fx)*b_X(0)/b_X(2) + T(cx) — utils.h:74-75 */
+    u = jet_add(jet_div(jet_mul(jet_const(p->fx), b[0]), bz), jet_const(p->cx));
+    v = jet_add(jet_div(jet_mul(jet_const(p->fy), b[1]), bz), jet_const(p->cy));
+  } else {
+    /* utils.h:140-149 (Brown-Conrady): x = X/Z, y = Y/Z, r2, r4, r6,
+     * distort_x = x (1 + k1 r2 + k2 r4 + k3 r6) + 2 p1 x y + p2 (r2 + 2 x x), distort_y likewise */
+    const jet x = jet_div(b[0], bz), y = jet_div(b[1], bz);
+    const jet r2 = jet_add(jet_mul(x, x), jet_mul(y, y));
+    const jet r4 = jet_mul(r2, r2), r6 = jet_mul(r4, r2);
+    const jet radial = jet_add(jet_add(jet_add(jet_const(1.0), jet_scale(p->k1, r2)), jet_scale(p->k2, r4)), jet_scale(p->k3, r6));
+    const jet dx = jet_add(jet_add(jet_mul(x, radial), jet_mul(jet_mul(jet_const(2.0 * p->p1), x), y)),
+                           jet_scale(p->p2, jet_add(r2, jet_mul(jet_scale(2.0, x), x))));
+    const jet dy = jet_add(jet_add(jet_mul(y, radial), jet_mul(jet_mul(jet_const(2.0 * p->p2), x), y)),
+                           jet_scale(p->p1, jet_add(r2, jet_mul(jet_scale(2.0, y), y))));
+    u = jet_add(jet_mul(jet_const(p->fx), dx), jet_const(p->cx));
+    v = jet_add(jet_mul(jet_const(p->fy), dy), jet_const(p->cy));
+  }
   /* interp_a.Evaluate(_u,_v,&residue[0]) — utils.h:77 ; ceres Jet overload:
    * value from the scalar parts, derivative = dfdr * r.v + dfdc * c.v */
   double f, dfdr, dfdc;
@@ -298,31 +349,63 @@ static void pose_prepare(const ea_oracle_problem *p, const double q[4], pose_con
 
 static int block_analytic_pc(const ea_oracle_problem *p, const pose_consts *pc, const double t[3],
                              const double X[3], double *r, double j6[6]) {
-  double b[3];
+  /* second camera: a' = T12inv [a;1], c = R a' + t, b = T12 [c;1]  (affine parts; the reference passes
+   * rigid transforms whose last row is 0 0 0 1) */
+  double a[3] = {X[0], X[1], X[2]};
+  if (p->use_second_cam)
+    for (int i = 0; i < 3; ++i)
+      a[i] = p->T12inv[4 * i + 0] * X[0] + p->T12inv[4 * i + 1] * X[1] + p->T12inv[4 * i + 2] * X[2] + p->T12inv[4 * i + 3];
+  double c[3], b[3];
   for (int i = 0; i < 3; ++i)
-    b[i] = ((pc->R[i][0] * X[0] + pc->R[i][1] * X[1]) + pc->R[i][2] * X[2]) + t[i];
+    c[i] = ((pc->R[i][0] * a[0] + pc->R[i][1] * a[1]) + pc->R[i][2] * a[2]) + t[i];
+  if (p->use_second_cam)
+    for (int i = 0; i < 3; ++i)
+      b[i] = p->T12[4 * i + 0] * c[0] + p->T12[4 * i + 1] * c[1] + p->T12[4 * i + 2] * c[2] + p->T12[4 * i + 3];
+  else
+    for (int i = 0; i < 3; ++i) b[i] = c[i];
   if (p->z_guard > 0.0 && b[2] < p->z_guard && b[2] > -p->z_guard) return 0;
   const double bz = b[2] + p->z_eps;
-  const double u = p->fx * b[0] / bz + p->cx;
-  const double v = p->fy * b[1] / bz + p->cy;
+  const double iz = 1.0 / bz;
+  const double x = b[0] * iz, y = b[1] * iz;
+  double u, v, xd_x = 1.0, xd_y = 0.0, yd_x = 0.0, yd_y = 1.0; /* d(distorted)/d(x,y) */
+  if (p->use_distortion) {
+    const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+    const double D = 1.0 + p->k1 * r2 + p->k2 * r4 + p->k3 * r6;
+    const double Dp = p->k1 + 2.0 * p->k2 * r2 + 3.0 * p->k3 * r4; /* dD/d(r2) */
+    const double xd = x * D + 2.0 * p->p1 * x * y + p->p2 * (r2 + 2.0 * x * x);
+    const double yd = y * D + 2.0 * p->p2 * x * y + p->p1 * (r2 + 2.0 * y * y);
+    xd_x = D + 2.0 * x * x * Dp + 2.0 * p->p1 * y + 6.0 * p->p2 * x;
+    xd_y = 2.0 * x * y * Dp + 2.0 * p->p1 * x + 2.0 * p->p2 * y;
+    yd_x = 2.0 * x * y * Dp + 2.0 * p->p2 * y + 2.0 * p->p1 * x;
+    yd_y = D + 2.0 * y * y * Dp + 2.0 * p->p2 * x + 6.0 * p->p1 * y;
+    u = p->fx * xd + p->cx;
+    v = p->fy * yd + p->cy;
+  } else {
+    u = p->fx * b[0] / bz + p->cx;
+    v = p->fy * b[1] / bz + p->cy;
+  }
   double f, Fu, Fv;
   ea_oracle_bicubic(p->grid, p->grid_rows, p->grid_cols, u, v, &f, &Fu, &Fv);
   *r = f;
   if (j6) {
-    /* g = d r / d b */
-    const double iz = 1.0 / bz;
-    const double gx = Fu * p->fx * iz;
-    const double gy = Fv * p->fy * iz;
-    const double gz = -(Fu * p->fx * b[0] + Fv * p->fy * b[1]) * iz * iz;
+    /* d r / d(x,y), then d r / d b, then (second camera) back through the affine map */
+    const double rx = Fu * p->fx * xd_x + Fv * p->fy * yd_x;
+    const double ry = Fu * p->fx * xd_y + Fv * p->fy * yd_y;
+    double gb[3] = {rx * iz, ry * iz, -(rx * x + ry * y) * iz};
+    double g[3];
+    if (p->use_second_cam)
+      for (int i = 0; i < 3; ++i) g[i] = p->T12[0 + i] * gb[0] + p->T12[4 + i] * gb[1] + p->T12[8 + i] * gb[2];
+    else
+      for (int i = 0; i < 3; ++i) g[i] = gb[i];
     for (int j = 0; j < 3; ++j) {
-      double d0 = pc->G[j][0][0] * X[0] + pc->G[j][0][1] * X[1] + pc->G[j][0][2] * X[2];
-      double d1 = pc->G[j][1][0] * X[0] + pc->G[j][1][1] * X[1] + pc->G[j][1][2] * X[2];
-      double d2 = pc->G[j][2][0] * X[0] + pc->G[j][2][1] * X[1] + pc->G[j][2][2] * X[2];
-      j6[j] = gx * d0 + gy * d1 + gz * d2;
+      double d0 = pc->G[j][0][0] * a[0] + pc->G[j][0][1] * a[1] + pc->G[j][0][2] * a[2];
+      double d1 = pc->G[j][1][0] * a[0] + pc->G[j][1][1] * a[1] + pc->G[j][1][2] * a[2];
+      double d2 = pc->G[j][2][0] * a[0] + pc->G[j][2][1] * a[1] + pc->G[j][2][2] * a[2];
+      j6[j] = g[0] * d0 + g[1] * d1 + g[2] * d2;
     }
-    j6[3] = gx;
-    j6[4] = gy;
-    j6[5] = gz;
+    j6[3] = g[0];
+    j6[4] = g[1];
+    j6[5] = g[2];
   }
   return 1;
 }
@@ -443,6 +526,47 @@ int64_t ea_oracle_cost(const ea_oracle_problem *p, const double *xyz, int64_t n,
   }
   *cost = c;
   return n_invalid;
+}
+
+/* one ceres::Problem with several residual families sharing (q,t): sums over the terms;
+ * r_out / J_out (nullable) are filled term after term */
+static int64_t eval_terms_full(const ea_oracle_term *terms, int nterms, const double q[4], const double t[3],
+                               int jacobian_mode, double *cost, double JtJ[36], double Jtr[6], double *r_out,
+                               double *J_out) {
+  double c = 0.0, A[36], g[6];
+  memset(A, 0, sizeof(A));
+  memset(g, 0, sizeof(g));
+  int64_t bad = 0, off = 0;
+  for (int k = 0; k < nterms; ++k) {
+    double ck, Ak[36], gk[6];
+    bad += ea_oracle_eval(terms[k].problem, terms[k].xyz, terms[k].n, terms[k].stride, q, t, jacobian_mode, &ck, Ak,
+                          gk, r_out ? r_out + off : NULL, J_out ? J_out + 6 * off : NULL, NULL, NULL);
+    c += ck;
+    for (int i = 0; i < 36; ++i) A[i] += Ak[i];
+    for (int i = 0; i < 6; ++i) g[i] += gk[i];
+    off += terms[k].n;
+  }
+  if (cost) *cost = c;
+  if (JtJ) memcpy(JtJ, A, sizeof(A));
+  if (Jtr) memcpy(Jtr, g, sizeof(g));
+  return bad;
+}
+
+int64_t ea_oracle_eval_terms(const ea_oracle_term *terms, int nterms, const double q[4], const double t[3],
+                             int jacobian_mode, double *cost, double JtJ[36], double Jtr[6]) {
+  return eval_terms_full(terms, nterms, q, t, jacobian_mode, cost, JtJ, Jtr, NULL, NULL);
+}
+
+static int64_t cost_terms(const ea_oracle_term *terms, int nterms, const double q[4], const double t[3], double *cost) {
+  double c = 0.0;
+  int64_t bad = 0;
+  for (int k = 0; k < nterms; ++k) {
+    double ck;
+    bad += ea_oracle_cost(terms[k].problem, terms[k].xyz, terms[k].n, terms[k].stride, q, t, &ck);
+    c += ck;
+  }
+  *cost = c;
+  return bad;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -665,7 +789,15 @@ static int dogleg_compute_step(tr_strategy *st, const ea_oracle_options *opt, co
 int ea_oracle_solve(const ea_oracle_problem *p, const double *xyz, int64_t n, int stride,
                     const ea_oracle_options *opt, double q[4], double t[3],
                     ea_oracle_summary *sum) {
+  ea_oracle_term term = {p, xyz, n, stride};
+  return ea_oracle_solve_terms(&term, 1, opt, q, t, sum);
+}
+
+int ea_oracle_solve_terms(const ea_oracle_term *terms, int nterms, const ea_oracle_options *opt, double q[4],
+                          double t[3], ea_oracle_summary *sum) {
   memset(sum, 0, sizeof(*sum));
+  int64_t n = 0;
+  for (int k = 0; k < nterms; ++k) n += terms[k].n;
   const int need_J = (opt->linear_solver == EA_ORACLE_LIN_DENSE_QR);
   double *Jc = NULL, *rc = NULL;
   if (need_J) {
@@ -691,8 +823,8 @@ int ea_oracle_solve(const ea_oracle_problem *p, const double *xyz, int64_t n, in
  * (ceres: TrustRegionMinimizer::EvaluateGradientAndJacobian) */
 #define EVAL_AT_X()                                                                             \
   do {                                                                                          \
-    int64_t bad = ea_oracle_eval(p, xyz, n, stride, x, x + 4, opt->jacobian_mode, &x_cost, JtJ, \
-                                 Jtr, rc, Jc, NULL, NULL);                                      \
+    int64_t bad = eval_terms_full(terms, nterms, x, x + 4, opt->jacobian_mode, &x_cost, JtJ,    \
+                                  Jtr, rc, Jc);                                                 \
     sum->num_residual_evals += n;                                                               \
     sum->num_jacobian_evals += n;                                                               \
     eval_ok = (bad == 0);                                                                       \
@@ -784,7 +916,7 @@ int ea_oracle_solve(const ea_oracle_problem *p, const double *xyz, int64_t n, in
     double cand[7], cand_cost;
     plus7(x, delta, cand);
     {
-      int64_t bad = ea_oracle_cost(p, xyz, n, stride, cand, cand + 4, &cand_cost);
+      int64_t bad = cost_terms(terms, nterms, cand, cand + 4, &cand_cost);
       sum->num_residual_evals += n;
       if (bad) cand_cost = DBL_MAX; /* "Step failed to evaluate. Treating it as a step with infinite cost" */
     }

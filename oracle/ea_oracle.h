@@ -68,7 +68,21 @@ typedef struct {
   double z_guard;  /* evaluation fails if -z_guard < bz < z_guard   (utils.h:70-73); 0 = no guard */
   double z_eps;    /* divisor is bz + z_eps                         (EAResidue.h:104-105) */
   int rot_transposed; /* apply R^T (EAResidue.h:90,99-101) */
+  /* residual variants of standalone/utils.h */
+  int use_distortion;      /* EAResidueEx / EAResidueSecondCamEx (utils.h:102-177, :295-421) */
+  double k1, k2, p1, p2, k3;
+  int use_second_cam;      /* EAResidueSecondCam[Ex] (utils.h:179-292): b_T_a_SecCam = T12 * b_T_a * T12inv */
+  double T12[16], T12inv[16]; /* row-major 4x4, as the ptrans_1to2 / ptrans_1to2_inv arrays */
 } ea_oracle_problem;
+
+/* one residual family of a problem: a functor flavour + its points; several terms share (q,t)
+ * (standalone_edge_align.cpp:791-803: EAResidue blocks of camera 1 + EAResidueSecondCam blocks of camera 2) */
+typedef struct {
+  const ea_oracle_problem *problem;
+  const double *xyz;
+  int64_t n;
+  int stride;
+} ea_oracle_term;
 
 #define EA_ORACLE_MAX_ITERS 512
 
@@ -146,6 +160,12 @@ int64_t ea_oracle_eval(const ea_oracle_problem *p, const double *xyz, int64_t n,
 /* residual-only evaluation (candidate cost) */
 int64_t ea_oracle_cost(const ea_oracle_problem *p, const double *xyz, int64_t n, int stride,
                        const double q[4], const double t[3], double *cost);
+
+/* multi-term versions: sums over all terms (one ceres::Problem with several residual families) */
+int64_t ea_oracle_eval_terms(const ea_oracle_term *terms, int nterms, const double q[4], const double t[3],
+                             int jacobian_mode, double *cost, double JtJ[36], double Jtr[6]);
+int ea_oracle_solve_terms(const ea_oracle_term *terms, int nterms, const ea_oracle_options *opt, double q[4],
+                          double t[3], ea_oracle_summary *summary);
 
 /* ceres::Solve(options, &problem, &summary) for this problem shape; q,t updated in place */
 int ea_oracle_solve(const ea_oracle_problem *p, const double *xyz, int64_t n, int stride,

@@ -27,7 +27,15 @@ class Problem(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("grid", C.POINTER(C.c_double)), ("grid_rows", C.c_int), ("grid_cols", C.c_int),
                 ("loss_kind", C.c_int), ("loss_a", C.c_double),
-                ("z_guard", C.c_double), ("z_eps", C.c_double), ("rot_transposed", C.c_int)]
+                ("z_guard", C.c_double), ("z_eps", C.c_double), ("rot_transposed", C.c_int),
+                ("use_distortion", C.c_int),
+                ("k1", C.c_double), ("k2", C.c_double), ("p1", C.c_double), ("p2", C.c_double), ("k3", C.c_double),
+                ("use_second_cam", C.c_int), ("T12", C.c_double * 16), ("T12inv", C.c_double * 16)]
+
+
+class Term(C.Structure):
+    _fields_ = [("problem", C.POINTER(Problem)), ("xyz", C.POINTER(C.c_double)), ("n", C.c_int64),
+                ("stride", C.c_int)]
 
 
 class Options(C.Structure):
@@ -93,6 +101,10 @@ def lib():
         L.ea_oracle_solve.argtypes = [C.POINTER(Problem), dp, C.c_int64, C.c_int,
                                       C.POINTER(Options), dp, dp, C.POINTER(Summary)]
         L.ea_oracle_solve.restype = C.c_int
+        L.ea_oracle_eval_terms.argtypes = [C.POINTER(Term), C.c_int, dp, dp, C.c_int, dp, dp, dp]
+        L.ea_oracle_eval_terms.restype = C.c_int64
+        L.ea_oracle_solve_terms.argtypes = [C.POINTER(Term), C.c_int, C.POINTER(Options), dp, dp, C.POINTER(Summary)]
+        L.ea_oracle_solve_terms.restype = C.c_int
         _lib = L
     return _lib
 
@@ -110,7 +122,7 @@ class OracleProblem:
     (standalone_edge_align.cpp:256-278)."""
 
     def __init__(self, grid, fx, fy, cx, cy, loss=LOSS_CAUCHY, loss_a=1.0,
-                 z_guard=0.01, z_eps=0.0, rot_transposed=False):
+                 z_guard=0.01, z_eps=0.0, rot_transposed=False, distortion=None, T12=None, T12inv=None):
         self.grid = _f64(grid)
         assert self.grid.ndim == 2
         p = Problem()
@@ -120,6 +132,16 @@ class OracleProblem:
         p.grid_rows, p.grid_cols = self.grid.shape
         p.loss_kind, p.loss_a = loss, loss_a
         p.z_guard, p.z_eps, p.rot_transposed = z_guard, z_eps, int(rot_transposed)
+        if distortion is not None:   # (k1, k2, p1, p2, k3) in EAResidueEx::Create's order (utils.h:156-160)
+            p.use_distortion = 1
+            p.k1, p.k2, p.p1, p.p2, p.k3 = [float(x) for x in distortion]
+        if T12 is not None:          # row-major 4x4, EAResidueSecondCam's ptrans_1to2 / ptrans_1to2_inv
+            p.use_second_cam = 1
+            T12 = _f64(T12).reshape(16)
+            T12inv = _f64(T12inv if T12inv is not None else np.linalg.inv(T12.reshape(4, 4))).reshape(16)
+            for i in range(16):
+                p.T12[i] = T12[i]
+                p.T12inv[i] = T12inv[i]
         self.p = p
 
     def bicubic(self, r, c):
@@ -198,6 +220,46 @@ class OracleProblem:
                        it_radius=np.array(s.it_radius[:ni]),
                        it_successful=np.array(s.it_successful[:ni]))
         return q, t, summary
+
+
+def _make_terms(problems, clouds):
+    arr = (Term * len(problems))()
+    keep = []
+    for i, (P, xyz) in enumerate(zip(problems, clouds)):
+        xyz = _f64(xyz)
+        keep.append(xyz)
+        arr[i].problem = C.pointer(P.p)
+        arr[i].xyz = _dp(xyz)
+        arr[i].n, arr[i].stride = xyz.shape
+    return arr, keep
+
+
+def eval_terms(problems, clouds, q, t, jacobian_mode=JAC_ANALYTIC):
+    """one ceres::Problem holding several residual families (e.g. camera 1 + camera 2) on one (q,t)"""
+    arr, keep = _make_terms(problems, clouds)
+    q, t = _f64(q), _f64(t)
+    cost = C.c_double()
+    JtJ, Jtr = np.zeros((6, 6)), np.zeros(6)
+    bad = lib().ea_oracle_eval_terms(arr, len(problems), _dp(q), _dp(t), jacobian_mode, C.byref(cost), _dp(JtJ), _dp(Jtr))
+    return dict(cost=cost.value, JtJ=JtJ, Jtr=Jtr, n_invalid=int(bad))
+
+
+def solve_terms(problems, clouds, q, t, **opts):
+    arr, keep = _make_terms(problems, clouds)
+    q, t = _f64(q).copy(), _f64(t).copy()
+    o = Options()
+    lib().ea_oracle_default_options(C.byref(o))
+    for k, v in opts.items():
+        if not hasattr(o, k):
+            raise KeyError(k)
+        setattr(o, k, v)
+    s = Summary()
+    lib().ea_oracle_solve_terms(arr, len(problems), C.byref(o), _dp(q), _dp(t), C.byref(s))
+    ni = s.num_iterations + 1
+    return q, t, dict(termination=s.termination, why=WHY[s.why], num_iterations=s.num_iterations,
+                      num_successful_steps=s.num_successful_steps, initial_cost=s.initial_cost,
+                      final_cost=s.final_cost, it_cost=np.array(s.it_cost[:ni]), it_radius=np.array(s.it_radius[:ni]),
+                      it_successful=np.array(s.it_successful[:ni]))
 
 
 def quat_plus(q, delta):

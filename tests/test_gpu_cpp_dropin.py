@@ -63,3 +63,39 @@ def test_solve_ea_class_dogleg(binaries, oracle, bundled_pair, tmp_path):
     qo, to, so = O.solve(X, [1, 0, 0, 0], [0, 0, 0], strategy=oracle.STRATEGY_DOGLEG, max_num_iterations=25)
     assert synth.rotation_angle_between(q, qo) < 1e-7 and np.linalg.norm(t - to) < 1e-7
     assert int(v[7]) == so["termination"]
+
+
+@pytest.mark.parametrize("ex", [False, True])
+def test_stereo_call_sequence(binaries, oracle, tmp_path, ex):
+    """standalone_edge_align.cpp:778-815 (EAResidue + EAResidueSecondCam, CauchyLoss) and :3195-3233
+    (EAResidueEx + EAResidueSecondCamEx, TrivialLoss, 100 iterations) through the drop-in headers"""
+    K1 = (130.0, 132.0, 79.5, 59.5)
+    K2 = (128.0, 129.0, 81.0, 58.0)
+    dist = (0.2624, -0.9531, -0.0054, 0.0026, 1.1633)
+    T12 = synth.rigid_4x4(synth.quat_from_axis_angle([0.1, 1.0, 0.2], 0.04), [0.11, 0.004, -0.012])
+    Q = synth.quat_from_axis_angle([1, 2, 3], np.deg2rad(1.0))
+    T = np.array([0.01, -0.005, 0.02])
+    fams = synth.make_stereo_problem(120, 160, 3000, 2000, 9, K1, K2, T12, Q, T, distortion=dist if ex else None)
+    p = str(tmp_path / "stereo.bin")
+    with open(p, "wb") as f:
+        f.write(struct.pack("<iiii", 3000, 2000, 120, 160))
+        f.write(struct.pack("<dddd", *K1)); f.write(struct.pack("<dddd", *K2)); f.write(struct.pack("<ddddd", *dist))
+        f.write(np.ascontiguousarray(T12, dtype=np.float64).tobytes())
+        f.write(np.ascontiguousarray(np.linalg.inv(T12), dtype=np.float64).tobytes())
+        for fam in fams:
+            aX = np.concatenate([fam["xyz"], np.ones((fam["xyz"].shape[0], 1))], axis=1)
+            f.write(np.ascontiguousarray(aX, dtype=np.float64).tobytes())
+        for fam in fams:
+            f.write(np.ascontiguousarray(fam["grid"], dtype=np.float64).tobytes())
+    out = subprocess.run([os.path.join(binaries, "stereo_test3"), p] + (["ex"] if ex else []), capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    v = [float(x) for x in out.stdout.split()]
+    q, t = np.array(v[:4]), np.array(v[4:7])
+    loss = oracle.LOSS_TRIVIAL if ex else oracle.LOSS_CAUCHY
+    O1 = oracle.OracleProblem(fams[0]["grid"], *K1, loss=loss, distortion=dist if ex else None)
+    O2 = oracle.OracleProblem(fams[1]["grid"], *K2, loss=loss, distortion=dist if ex else None, T12=T12)
+    qo, to, so = oracle.solve_terms([O1, O2], [fams[0]["xyz"], fams[1]["xyz"]], [1, 0, 0, 0], [0, 0, 0],
+                                    max_num_iterations=100 if ex else 50)
+    assert synth.rotation_angle_between(q, qo) < 1e-7 and np.linalg.norm(t - to) < 1e-7
+    assert int(v[8]) == so["termination"]
+    assert "Use Point count = 5000" in out.stderr
