@@ -32,7 +32,8 @@ hipError_t launch_selftest_reduce(const float *in, float *a, float *b, float *c,
 // ea_preprocess.hip
 hipError_t launch_edge_strength(const uint8_t *bgr, int H, int W, uint8_t *gray, uint8_t *lap, hipStream_t s);
 hipError_t launch_threshold_median(const uint8_t *lap, int H, int W, int thr, int median, uint8_t *mask, hipStream_t s);
-hipError_t launch_chamfer(const uint8_t *mask, int H, int W, int *G, int *dist_fix, unsigned int *minmax, hipStream_t s);
+hipError_t launch_chamfer(const uint8_t *mask, int H, int W, int *G, int *scratch, int *dist_fix, unsigned int *minmax,
+                          hipStream_t s);
 hipError_t launch_dt_store(int dtype, const int *dist_fix, int H, int W, const unsigned int *minmax, int normalize,
                            void *dst, int pitch, float *plain, hipStream_t s);
 hipError_t launch_edge_count_scan(const uint8_t *lap, const uint16_t *depth, int H, int W, int thr, int *block_counts,
@@ -908,6 +909,7 @@ static int ensure_ws(ea_problem *p, size_t bytes) {
 static size_t frame_ws_bytes(int H, int W) {
   const size_t np = (size_t)H * W;
   return np * 3 + np * 2 + np * 3 /*gray, lap, mask*/ + np * 4 * 2 /*G, dist*/ + np * 4 /*plain float*/ +
+         16 * (size_t)((H + 31) / 32 + 1) * W /*segment ends + carries*/ +
          ((np + 1023) / 1024 + 8) * 4 + 64 * 256;
 }
 
@@ -954,11 +956,12 @@ static int run_dt(ea_problem *p, WsCarver &ws, const uint8_t *d_bgr, int height,
   const size_t np = (size_t)height * width;
   uint8_t *d_gray = ws.take<uint8_t>(np), *d_lap = ws.take<uint8_t>(np), *d_mask = ws.take<uint8_t>(np);
   int *d_G = ws.take<int>(np), *d_dist = ws.take<int>(np);
+  int *d_scan = ws.take<int>(4 * (size_t)((height + 31) / 32) * width);
   float *d_plain = ws.take<float>(np);
   unsigned int *d_minmax = ws.take<unsigned int>(2);
   HIPCHK(launch_edge_strength(d_bgr, height, width, d_gray, d_lap, nullptr));
   HIPCHK(launch_threshold_median(d_lap, height, width, threshold, median, d_mask, nullptr));
-  HIPCHK(launch_chamfer(d_mask, height, width, d_G, d_dist, d_minmax, nullptr));
+  HIPCHK(launch_chamfer(d_mask, height, width, d_G, d_scan, d_dist, d_minmax, nullptr));
   int rc = EA_OK;
   {
     if (p->d_dt) { (void)hipFree(p->d_dt); p->d_dt = nullptr; }

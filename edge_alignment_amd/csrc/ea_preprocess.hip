@@ -90,19 +90,61 @@ __global__ void ea_threshold_median_kernel(const uint8_t *__restrict__ lap, int 
   mask[(size_t)v * W + u] = bg >= 5 ? 255 : 0;
 }
 
-// G(x,y) = |y - y'| to the nearest feature pixel (mask == 0) of column x; kNoFeature if none
-__global__ void ea_column_nearest_kernel(const uint8_t *__restrict__ mask, int H, int W, int *__restrict__ G) {
+// G(x,y) = |y - y'| to the nearest feature pixel (mask == 0) of column x; kNoFeature if none.
+// A column scan is a recurrence along y, so it is cut into segments of kSegRows rows that are scanned
+// independently (kernel A: local distances + what each segment sees at its two ends), a short per-column
+// pass chains the segment ends (kernel B: carries), and the consumer applies the carries on the fly.
+constexpr int kSegRows = 32;
+
+__global__ void ea_column_local_kernel(const uint8_t *__restrict__ mask, int H, int W, int *__restrict__ G,
+                                       int *__restrict__ end_dn /*S x W*/, int *__restrict__ end_up /*S x W*/) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= W) return;
+  const int s = blockIdx.y, y0 = s * kSegRows, y1 = min(H, y0 + kSegRows);
+  uint8_t m[kSegRows];
+#pragma unroll
+  for (int k = 0; k < kSegRows; ++k) m[k] = (y0 + k < y1) ? mask[(size_t)(y0 + k) * W + x] : (uint8_t)255;
+  int dn[kSegRows];
   int d = kNoFeature;
-  for (int y = 0; y < H; ++y) {
-    d = mask[(size_t)y * W + x] == 0 ? 0 : min(d + 1, kNoFeature);
-    G[(size_t)y * W + x] = d;
+#pragma unroll
+  for (int k = 0; k < kSegRows; ++k) {
+    d = m[k] == 0 ? 0 : min(d + 1, kNoFeature);
+    dn[k] = d;
   }
+  // distance from the segment's last row to the nearest feature above, inside the segment
+  int last = kNoFeature;
+#pragma unroll
+  for (int k = 0; k < kSegRows; ++k)
+    if (y0 + k == y1 - 1) last = dn[k];
+  end_dn[(size_t)s * W + x] = last;
   d = kNoFeature;
-  for (int y = H - 1; y >= 0; --y) {
-    d = mask[(size_t)y * W + x] == 0 ? 0 : min(d + 1, kNoFeature);
-    G[(size_t)y * W + x] = min(G[(size_t)y * W + x], d);
+#pragma unroll
+  for (int k = kSegRows - 1; k >= 0; --k) {
+    if (y0 + k < y1) {
+      d = m[k] == 0 ? 0 : min(d + 1, kNoFeature);
+      G[(size_t)(y0 + k) * W + x] = min(dn[k], d);
+    }
+  }
+  end_up[(size_t)s * W + x] = d;  // distance from the segment's first row to the nearest feature below
+}
+
+// carry_dn[s] = distance from the row just above segment s to the nearest feature above it;
+// carry_up[s] = distance from the row just below segment s to the nearest feature below it
+__global__ void ea_column_carry_kernel(const int *__restrict__ end_dn, const int *__restrict__ end_up, int H, int W,
+                                       int S, int *__restrict__ carry_dn, int *__restrict__ carry_up) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= W) return;
+  int c = kNoFeature;
+  for (int s = 0; s < S; ++s) {
+    carry_dn[(size_t)s * W + x] = c;
+    const int len = min(H, (s + 1) * kSegRows) - s * kSegRows;
+    c = min(end_dn[(size_t)s * W + x], min(c + len, kNoFeature));
+  }
+  c = kNoFeature;
+  for (int s = S - 1; s >= 0; --s) {
+    carry_up[(size_t)s * W + x] = c;
+    const int len = min(H, (s + 1) * kSegRows) - s * kSegRows;
+    c = min(end_up[(size_t)s * W + x], min(c + len, kNoFeature));
   }
 }
 
@@ -113,11 +155,19 @@ __device__ __forceinline__ int chamfer_cost(int dx, int dy) {
 
 // One workgroup per image row: G row staged in LDS, every lane searches outwards from its own
 // column and stops as soon as a*dx alone exceeds the best distance found.
-__global__ void ea_chamfer_row_kernel(const int *__restrict__ G, int H, int W, int *__restrict__ dist_fix,
+__global__ void ea_chamfer_row_kernel(const int *__restrict__ G, const int *__restrict__ carry_dn,
+                                      const int *__restrict__ carry_up, int H, int W, int *__restrict__ dist_fix,
                                       unsigned int *__restrict__ minmax /* [0]=min bits, [1]=max bits of dist*2^-16 as float */) {
   extern __shared__ int s_g[];
   const int y = blockIdx.x;
-  for (int x = threadIdx.x; x < W; x += blockDim.x) s_g[x] = G[(size_t)y * W + x];
+  const int seg = y / kSegRows, y0 = seg * kSegRows, y1 = min(H, y0 + kSegRows);
+  for (int x = threadIdx.x; x < W; x += blockDim.x) {
+    int g = G[(size_t)y * W + x];
+    const int cd = carry_dn[(size_t)seg * W + x], cu = carry_up[(size_t)seg * W + x];
+    if (cd < kNoFeature) g = min(g, cd + (y - y0 + 1));
+    if (cu < kNoFeature) g = min(g, cu + (y1 - y));
+    s_g[x] = g;
+  }
   __syncthreads();
   float lmin = 3.0e38f, lmax = 0.0f;
   for (int x = threadIdx.x; x < W; x += blockDim.x) {
@@ -258,13 +308,20 @@ hipError_t launch_threshold_median(const uint8_t *lap, int H, int W, int thr, in
   return hipGetLastError();
 }
 
-hipError_t launch_chamfer(const uint8_t *mask, int H, int W, int *G, int *dist_fix, unsigned int *minmax, hipStream_t s) {
+// scratch: 4 * ceil(H/32) * W ints
+hipError_t launch_chamfer(const uint8_t *mask, int H, int W, int *G, int *scratch, int *dist_fix, unsigned int *minmax,
+                          hipStream_t s) {
   hipError_t e = hipMemsetAsync(minmax, 0xff, sizeof(unsigned int), s);  // min slot = max uint
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(minmax + 1, 0, sizeof(unsigned int), s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(ea_column_nearest_kernel, dim3((W + 255) / 256), dim3(256), 0, s, mask, H, W, G);
-  hipLaunchKernelGGL(ea_chamfer_row_kernel, dim3(H), dim3(256), (size_t)W * sizeof(int), s, G, H, W, dist_fix, minmax);
+  const int S = (H + kSegRows - 1) / kSegRows;
+  int *end_dn = scratch, *end_up = scratch + (size_t)S * W, *carry_dn = scratch + 2 * (size_t)S * W,
+      *carry_up = scratch + 3 * (size_t)S * W;
+  hipLaunchKernelGGL(ea_column_local_kernel, dim3((W + 63) / 64, S), dim3(64), 0, s, mask, H, W, G, end_dn, end_up);
+  hipLaunchKernelGGL(ea_column_carry_kernel, dim3((W + 63) / 64), dim3(64), 0, s, end_dn, end_up, H, W, S, carry_dn, carry_up);
+  hipLaunchKernelGGL(ea_chamfer_row_kernel, dim3(H), dim3(256), (size_t)W * sizeof(int), s, G, carry_dn, carry_up, H, W,
+                     dist_fix, minmax);
   return hipGetLastError();
 }
 

@@ -1,0 +1,26 @@
+"""Times the GPU frame producers (edge-point extractor, DT producer) on the bundled 640x480 frames and on a
+2048x1536 synthetic frame, next to the numpy restatement on the host."""
+import os, sys, time, numpy as np
+sys.path.insert(0, '.')
+from edge_alignment_amd import capi
+from oracle import preprocess_np as pp
+G = 'tests/golden/rgbd'
+K = (525.0, 525.0, 319.5, 239.5)
+rgb1 = pp.load_rgb_as_bgr(os.path.join(G, 'rgb_1.png')); d1 = pp.load_depth_u16(os.path.join(G, 'depth_1.png')); rgb3 = pp.load_rgb_as_bgr(os.path.join(G, 'rgb_3.png'))
+def timeit(fn, n=20):
+    fn(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    return (time.perf_counter() - t0) / n * 1e3
+P = capi.Problem(*K, dtype=capi.EA_F64)
+print('640x480  set_ref_frame (H2D + kernels + count readback) %.3f ms' % timeit(lambda: P.set_ref_frame(rgb1, d1)))
+print('640x480  set_now_frame (H2D + kernels)                  %.3f ms' % timeit(lambda: P.set_now_frame(rgb3)))
+t0 = time.perf_counter(); pp.get_aX(rgb1, d1, *K); t1 = time.perf_counter(); pp.get_distance_transform(rgb3); t2 = time.perf_counter()
+print('numpy restatement on the host: get_aX %.1f ms, get_distance_transform %.1f ms' % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
+q, t, s = P.solve([1, 0, 0, 0], [0, 0, 0]); print('solve', s['why'], s['num_iterations'], '%.3f ms' % s['total_time_ms'])
+rng = np.random.default_rng(0)
+big = np.kron(rgb3, np.ones((4, 4, 1), np.uint8))[:1536, :2048].copy()
+bigd = np.kron(d1, np.ones((4, 4), np.uint16))[:1536, :2048].copy()
+P2 = capi.Problem(1680., 1680., 1023.5, 767.5, dtype=capi.EA_F32)
+print('2048x1536 set_ref_frame %.3f ms  (n=%d)' % (timeit(lambda: P2.set_ref_frame(big, bigd), 5), P2.num_points))
+print('2048x1536 set_now_frame %.3f ms' % timeit(lambda: P2.set_now_frame(big), 5))
+P.close(); P2.close()
