@@ -24,7 +24,7 @@ hipError_t launch_eval_points(int dtype, const ProblemDesc *probs, int problem, 
 hipError_t launch_reduce(const GroupDesc *groups, int count, const double *partials, EvalOut *out,
                          hipStream_t stream);
 hipError_t launch_lm_step(const GroupDesc *groups, int count, const double *partials, PoseState *poses,
-                          LMState *states, LMTrace *traces, const LMOptions &opt, int *running_flags,
+                          LMState *states, LMCold *cold, LMTrace *traces, const LMOptions &opt, int *running_flags,
                           hipStream_t stream);
 hipError_t launch_pad_image(int dtype, const void *src, int H, int W, void *dst, int pitch, hipStream_t stream);
 hipError_t launch_selftest_reduce(const float *in, float *a, float *b, float *c, float *d, double *o32, double *o64,
@@ -105,6 +105,7 @@ struct ea_batch {
   EvalOut *d_out = nullptr;
   unsigned char *d_lm_block = nullptr;  // [LMState x count | PoseState x count], one upload per solve
   LMState *d_states = nullptr;
+  LMCold *d_cold = nullptr;             // written by the first LM step before anything reads it
   LMTrace *d_traces = nullptr;
   int *d_progress = nullptr;            // device view of h_progress
   // pinned host mirrors
@@ -363,11 +364,11 @@ extern "C" int ea_problem_set_flavour(ea_problem *p, double z_guard, double z_ep
 // ---- batch --------------------------------------------------------------------------------------
 
 static void batch_free_device(ea_batch *b) {
-  (void)hipFree(b->d_probs); (void)hipFree(b->d_groups); (void)hipFree(b->d_lm_block); (void)hipFree(b->d_traces);
+  (void)hipFree(b->d_probs); (void)hipFree(b->d_groups); (void)hipFree(b->d_lm_block); (void)hipFree(b->d_traces); (void)hipFree(b->d_cold);
   (void)hipFree(b->d_partials); (void)hipFree(b->d_out);
   (void)hipHostFree(b->h_lm_block); (void)hipHostFree(b->h_out);
   (void)hipHostFree(b->h_traces); (void)hipHostFree(b->h_progress);
-  b->d_probs = nullptr; b->d_groups = nullptr; b->d_poses = nullptr; b->d_partials = nullptr; b->d_traces = nullptr; b->d_lm_block = nullptr;
+  b->d_probs = nullptr; b->d_groups = nullptr; b->d_poses = nullptr; b->d_partials = nullptr; b->d_traces = nullptr; b->d_cold = nullptr; b->d_lm_block = nullptr;
   b->d_out = nullptr; b->d_states = nullptr; b->d_progress = nullptr;
   b->h_poses = nullptr; b->h_out = nullptr; b->h_states = nullptr; b->h_traces = nullptr; b->h_progress = nullptr;
   b->h_lm_block = nullptr;
@@ -396,6 +397,7 @@ extern "C" int ea_batch_create(ea_batch **out, ea_problem *const *problems, int 
   if (e == hipSuccess) e = hipMalloc(&b->d_lm_block, lm_bytes);
   if (e == hipSuccess) e = hipMalloc(&b->d_out, c * sizeof(EvalOut));
   if (e == hipSuccess) e = hipMalloc(&b->d_traces, c * sizeof(LMTrace));
+  if (e == hipSuccess) e = hipMalloc(&b->d_cold, c * sizeof(LMCold));
   if (e == hipSuccess) e = hipHostMalloc(&b->h_lm_block, lm_bytes);
   if (e == hipSuccess) e = hipHostMalloc(&b->h_out, c * sizeof(EvalOut));
   if (e == hipSuccess) e = hipHostMalloc(&b->h_traces, c * sizeof(LMTrace));
@@ -687,7 +689,7 @@ extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, 
     if (enq < budget && enq - done < ahead) {
       rc = batch_launch_eval(b);
       if (rc != EA_OK) return rc;
-      HIPCHK(launch_lm_step(b->d_groups, count, b->d_partials, b->d_poses, b->d_states, b->d_traces, lo,
+      HIPCHK(launch_lm_step(b->d_groups, count, b->d_partials, b->d_poses, b->d_states, b->d_cold, b->d_traces, lo,
                             b->d_progress, b->stream));
       ++enq;
       spins = 0;
@@ -1055,3 +1057,46 @@ extern "C" int ea_problem_get_dt(ea_problem *p, double *image, int *height, int 
     }
   return EA_OK;
 }
+
+#ifdef EA_STAMPS
+namespace ea { hipError_t set_stamp_buffer(unsigned long long *buf); hipError_t set_lm_stamp_buffer(unsigned long long *buf); }
+static unsigned long long *g_lm_stamps_dev = nullptr;
+// diagnostic library only: stamps of the LM step kernel of problem 0 for the next solve(s); 64 x 8 words
+extern "C" int ea_debug_lm_stamps_begin(void) {
+  if (!g_lm_stamps_dev) HIPCHK(hipMalloc(&g_lm_stamps_dev, 128 * 8 * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(g_lm_stamps_dev, 0, 128 * 8 * sizeof(unsigned long long)));
+  HIPCHK(set_lm_stamp_buffer(g_lm_stamps_dev));
+  return EA_OK;
+}
+extern "C" int ea_debug_lm_stamps_end(unsigned long long *out) {
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(set_lm_stamp_buffer(nullptr));
+  HIPCHK(hipMemcpy(out, g_lm_stamps_dev, 128 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return EA_OK;
+}
+// diagnostic library only: run one fused evaluation and return the s_memtime stamps (8 per workgroup)
+extern "C" int ea_debug_eval_stamps(ea_batch *b, const double *q, const double *t, unsigned long long *stamps,
+                                    int64_t capacity_wgs, int64_t *n_wgs, int gx_gy[2]) {
+  int rc = batch_build(b);
+  if (rc != EA_OK) return rc;
+  rc = batch_upload_poses(b, q, t);
+  if (rc != EA_OK) return rc;
+  const int gx = b->xcd_remap ? ((b->max_chunks + 7) / 8) * 8 : b->max_chunks, gy = b->nterms;
+  const int64_t wgs = (int64_t)gx * gy;
+  if (wgs > capacity_wgs) return fail(EA_ERR_INVALID_ARG, "stamp buffer too small");
+  unsigned long long *d = nullptr;
+  HIPCHK(hipMalloc(&d, wgs * 8 * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(d, 0, wgs * 8 * sizeof(unsigned long long)));
+  for (int i = 0; i < 3; ++i) { rc = batch_launch_eval(b); if (rc != EA_OK) return rc; }
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(set_stamp_buffer(d));
+  rc = batch_launch_eval(b);
+  if (rc != EA_OK) return rc;
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(set_stamp_buffer(nullptr));
+  HIPCHK(hipMemcpy(stamps, d, wgs * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  *n_wgs = wgs; gx_gy[0] = gx; gx_gy[1] = gy;
+  return EA_OK;
+}
+#endif

@@ -19,12 +19,60 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <type_traits>
 
+#if defined(EA_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+namespace ea {
+extern __device__ unsigned long long *g_lm_stamp_buf;
+extern __device__ int g_lm_probe_row;
+}
+#define EA_LM_PROBE(k)                                                                              \
+  do {                                                                                              \
+    if (g_lm_stamp_buf && blockIdx.x == 0) {                                                        \
+      unsigned long long t_;                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                            \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+      __builtin_amdgcn_sched_barrier(0);                                                            \
+      g_lm_stamp_buf[64 * 8 + g_lm_probe_row * 8 + (k)] = t_;                                       \
+    }                                                                                               \
+  } while (0)
+#endif
 #include "ea_lm.h"
 #include "ea_types.h"
 
 namespace ea {
+
+// Diagnostic build only (-DEA_STAMPS, scripts/build_stamps.sh -> lib/libea_hip_stamps.so): wave 0 of every
+// workgroup stamps s_memtime at the phase boundaries into a buffer of its own; no output value depends on it.
+#ifdef EA_STAMPS
+__device__ unsigned long long *g_stamp_buf = nullptr;
+#define EA_STAMP(slot)                                                                              \
+  do {                                                                                              \
+    if (g_stamp_buf && threadIdx.x == 0) {                                                          \
+      unsigned long long t_;                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                            \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+      __builtin_amdgcn_sched_barrier(0);                                                            \
+      g_stamp_buf[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = t_;                 \
+    }                                                                                               \
+  } while (0)
+__device__ unsigned long long *g_lm_stamp_buf = nullptr;  // [64 evaluations][8] kernel + [64][8] state-machine probes, problem 0
+__device__ int g_lm_probe_row = 0;
+#define EA_LM_STAMP(slot, eval)                                                                     \
+  do {                                                                                              \
+    if (g_lm_stamp_buf && threadIdx.x == 0 && blockIdx.x == 0) {                                    \
+      unsigned long long t_;                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                            \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+      __builtin_amdgcn_sched_barrier(0);                                                            \
+      g_lm_stamp_buf[((eval) & 63) * 8 + (slot)] = t_;                                              \
+    }                                                                                               \
+  } while (0)
+#else
+#define EA_STAMP(slot) do {} while (0)
+#define EA_LM_STAMP(slot, eval) do {} while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // arithmetic helpers, T = float | double
@@ -539,6 +587,7 @@ __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
 
   // XCD-aware chunk assignment: workgroups are dealt round-robin over the 8 XCDs, so give each
   // XCD a contiguous run of chunks (neighbouring chunks read neighbouring image rows -> one L2).
+  EA_STAMP(0);
   const int bx = blockIdx.x;
   const int c = xcd_remap ? (bx & 7) * chunks_per_xcd + (bx >> 3) : bx;
   // descriptor and pose by value: every scalar load is issued here, behind one wait, instead of a
@@ -551,6 +600,7 @@ __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
   const long long start = (long long)c * chunk;
   if (start >= pd.n || !active) return;
   const int count = min(chunk, (int)(pd.n - start));
+  EA_STAMP(1);  // descriptor + pose.active arrived
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -578,6 +628,10 @@ __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
     const int jj = min(j, count - 1);
     X[k] = px[jj]; Y[k] = py[jj]; Z[k] = pz[jj];
   }
+#ifdef EA_STAMPS
+  asm volatile("" ::"v"(X[0]), "v"(Y[0]), "v"(Z[0]));
+#endif
+  EA_STAMP(2);  // points arrived
   int bb_u0 = 0x7fffffff, bb_u1 = -0x7fffffff, bb_v0 = 0x7fffffff, bb_v1 = -0x7fffffff;
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
@@ -641,6 +695,7 @@ __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
     }
   }
 
+  EA_STAMP(3);  // projected
   // ---- phase 3: sample, Jacobian, weights, accumulate
   T acc[28];
 #pragma unroll
@@ -682,6 +737,10 @@ __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
 #pragma unroll
   for (int i = 0; i < 28; ++i) v[i] = acc[i];
   v[28] = (T)n_bad; v[29] = T(0); v[30] = T(0); v[31] = T(0);
+#ifdef EA_STAMPS
+  asm volatile("" ::"v"(v[0]), "v"(v[27]));
+#endif
+  EA_STAMP(4);  // sampled + accumulated
   if (USE_LDS) __syncthreads();  // tile readers done before the scratch rows are written
   if constexpr (sizeof(T) == 4) {
     wave_reduce32_f32(v);
@@ -693,13 +752,19 @@ __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
     wave_reduce32<T>(v, lane);
     if (lane < 32) s_red[wave * kAccSlots + butterfly_slot(lane)] = (double)v[0];
   }
+  EA_STAMP(5);  // wave reduced
   __syncthreads();
+  EA_STAMP(6);  // all waves of the workgroup arrived
   if (tid < kAccSlots) {
     double sum = 0.0;
 #pragma unroll
     for (int w = 0; w < NT / 64; ++w) sum += s_red[w * kAccSlots + tid];
     partials[(size_t)(pd.tile_begin + c) * kAccSlots + tid] = sum;
   }
+#ifdef EA_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  EA_STAMP(7);  // row stored
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -775,24 +840,50 @@ constexpr int kFoldThreads = 1024;  // plain fold: 32 slots x 32 strided groups
 constexpr int kLmThreads = 256;     // fold + scalar LM code: 4 waves = one per SIMD, so the scalar code can keep
                                     // its ~300 live registers without spilling to scratch
 
-template <int NTHREADS>
+template <int NTHREADS, int U>
 __device__ __forceinline__ void reduce_tiles(const double *__restrict__ partials, int tile_begin,
                                              int tile_end, double *s_part /* (NTHREADS/32) x 32 */,
                                              double *out /* 32, threads 0..31 write */) {
-  constexpr int kRedGroups = NTHREADS / 32;
+  constexpr int G = NTHREADS / 32;
+  static_assert(U == 8 || U == 16, "pairwise combine below");
   const int tid = threadIdx.x;
   const int id = tid & 31, j = tid >> 5;
-  // fixed summation order for a given tile count; 8 independent loads in flight per thread
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
-  int tI = tile_begin + j;
-  constexpr int G = kRedGroups;
-  for (; tI + 7 * G < tile_end; tI += 8 * G) {
-    const double *p = partials + (size_t)tI * kAccSlots + id;
-    s0 += p[0 * G * kAccSlots]; s1 += p[1 * G * kAccSlots]; s2 += p[2 * G * kAccSlots]; s3 += p[3 * G * kAccSlots];
-    s4 += p[4 * G * kAccSlots]; s5 += p[5 * G * kAccSlots]; s6 += p[6 * G * kAccSlots]; s7 += p[7 * G * kAccSlots];
+  // fixed summation order for a given tile count; U independent loads in flight per thread
+  double s[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) s[u] = 0.0;
+  // A round = U rows per lane.  Rows past the end are loaded from the last row (a valid address) and masked out
+  // of the sum, so a round is U back-to-back loads with no branches; the first two rounds are issued together:
+  // folds of up to 2 U G rows cost one memory round trip.
+  const int last = tile_end - 1;
+  if (tile_begin <= last) {  // uniform
+    auto load_round = [&](int base, double(&v)[U]) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = partials[(size_t)min(base + j + u * G, last) * kAccSlots + id];
+    };
+    auto add_round = [&](int base, const double(&v)[U]) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) s[u] += (base + j + u * G <= last) ? v[u] : 0.0;
+    };
+    double v0[U], v1[U];
+    load_round(tile_begin, v0);
+    if (tile_begin + U * G <= last) {  // uniform
+      load_round(tile_begin + U * G, v1);
+      add_round(tile_begin, v0);
+      add_round(tile_begin + U * G, v1);
+      for (int base = tile_begin + 2 * U * G; base <= last; base += U * G) {
+        load_round(base, v0);
+        add_round(base, v0);
+      }
+    } else {
+      add_round(tile_begin, v0);
+    }
   }
-  for (; tI < tile_end; tI += G) s0 += partials[(size_t)tI * kAccSlots + id];
-  s_part[j * kAccSlots + id] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+#pragma unroll
+  for (int w = 1; w < U; w *= 2)
+#pragma unroll
+    for (int u = 0; u + w < U; u += 2 * w) s[u] += s[u + w];
+  s_part[j * kAccSlots + id] = s[0];
   __syncthreads();
   if (tid < kAccSlots) {
     double tot = 0.0;
@@ -807,50 +898,87 @@ __global__ __launch_bounds__(kFoldThreads) void ea_reduce_kernel(const GroupDesc
                                                                   EvalOut *__restrict__ out) {
   __shared__ double s_part[(kFoldThreads / 32) * kAccSlots];
   const GroupDesc gd = groups[blockIdx.x];
-  reduce_tiles<kFoldThreads>(partials, gd.tile_begin, gd.tile_end, s_part, out[blockIdx.x].acc);
+  reduce_tiles<kFoldThreads, 8>(partials, gd.tile_begin, gd.tile_end, s_part, out[blockIdx.x].acc);
 }
 
 // LM step: fold this problem's partial rows, advance the trust-region state machine, publish the
 // next pose to evaluate.  One workgroup per problem.  The state machine is scalar fp64 work on
-// lane 0; its state is staged in LDS so the dependent field accesses cost LDS, not HBM, latency.
+// lane 0 (pure latency: ~1/3 of an LM iteration), so everything around it is arranged to overlap:
+// the state words travel while the partial rows are fetched (16 loads in flight per lane), the
+// host's progress counter is posted before the arithmetic, lane 0 works on a register copy of the
+// state, and the pose's float mirrors / the write-back are lane-parallel.
 __global__ __launch_bounds__(kLmThreads) void ea_lm_step_kernel(
     const GroupDesc *__restrict__ groups, const double *__restrict__ partials,
-    PoseState *__restrict__ poses, LMState *__restrict__ states, LMTrace *__restrict__ traces,
-    LMOptions opt, int *__restrict__ progress /* pinned host: [running x n | evals x n] */) {
+    PoseState *__restrict__ poses, LMState *__restrict__ states, LMCold *__restrict__ cold,
+    LMTrace *__restrict__ traces, LMOptions opt,
+    int *__restrict__ progress /* pinned host: [running x n | evals x n] */) {
   __shared__ double s_part[(kLmThreads / 32) * kAccSlots];
   __shared__ double s_acc[kAccSlots];
   __shared__ LMState s_st;
   __shared__ PoseState s_ps;
-  static_assert(sizeof(LMState) % 8 == 0 && sizeof(PoseState) % 8 == 0, "8-byte copy granules");
-  const int p = blockIdx.x;
-  if (!states[p].running) return;  // uniform
-  {
-    const double *src = reinterpret_cast<const double *>(states + p);
-    double *dst = reinterpret_cast<double *>(&s_st);
-    for (int i = threadIdx.x; i < (int)(sizeof(LMState) / 8); i += kLmThreads) dst[i] = src[i];
-  }
+  constexpr int kStateWords = (int)(sizeof(LMState) / 8);
+  constexpr int kPoseDoubles = 4 + 3 + 9 + 27, kPoseFloats = 9 + 3 + 27;
+  static_assert(sizeof(LMState) % 8 == 0 && kStateWords <= kLmThreads, "one 8-byte state word per lane");
+  static_assert(offsetof(PoseState, Rf) == kPoseDoubles * 8 && offsetof(PoseState, unit_q) == kPoseDoubles * 8 + kPoseFloats * 4,
+                "PoseState layout");
+  const int p = blockIdx.x, tid = threadIdx.x;
+#ifdef EA_STAMPS
+  const int ev_ = states[p].num_evals;
+#endif
+  EA_LM_STAMP(0, ev_);
+#ifdef EA_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x == 0) g_lm_probe_row = ev_ & 63;
+#endif
   const GroupDesc gd = groups[p];
-  reduce_tiles<kLmThreads>(partials, gd.tile_begin, gd.tile_end, s_part, s_acc);
+  const int running = states[p].running;
+  const double state_word = tid < kStateWords ? reinterpret_cast<const double *>(states + p)[tid] : 0.0;
+  if (!running) return;  // uniform
+  EA_LM_STAMP(1, ev_);
+  reduce_tiles<kLmThreads, 16>(partials, gd.tile_begin, gd.tile_end, s_part, s_acc);
+  if (tid < kStateWords) reinterpret_cast<double *>(&s_st)[tid] = state_word;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double acc[kAccSlots];
+  EA_LM_STAMP(2, ev_);
+  // the host only uses this counter to decide how far ahead to enqueue: posted by another wavefront before the
+  // arithmetic, so the PCIe write is neither the last thing the kernel waits for nor in lane 0's memory counter
+  if (tid == 64)
+    __hip_atomic_store(progress + gridDim.x + p, s_st.num_evals + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  LMPending pend;
+  double acc[kAccSlots];
+  if (tid == 0) {
+    LMState st = s_st;
+#pragma unroll
     for (int i = 0; i < kAccSlots; ++i) acc[i] = s_acc[i];
-    if (s_st.num_evals == 0) lm_begin(&s_st, traces + p, &opt, acc);
-    else lm_advance(&s_st, traces + p, &opt, acc);
-    make_pose_state(s_st.cand, s_st.rot_transposed, s_st.running, &s_ps);
-    // system-scope release: the host polls these two words
-    __hip_atomic_store(progress + gridDim.x + p, s_st.num_evals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(progress + p, s_st.running, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (st.num_evals == 0) lm_begin(&st, cold + p, traces + p, &opt, acc, &pend);
+    else lm_advance(&st, cold + p, traces + p, &opt, acc, &pend);
+    EA_LM_STAMP(3, ev_);
+    make_pose_core(st.cand, st.rot_transposed, st.running, &s_ps, /*zero_unused_G=*/false);
+    s_st = st;
+    EA_LM_STAMP(4, ev_);
   }
   __syncthreads();
+  if (tid < kStateWords) reinterpret_cast<double *>(states + p)[tid] = reinterpret_cast<const double *>(&s_st)[tid];
   {
-    const double *src = reinterpret_cast<const double *>(&s_st);
-    double *dst = reinterpret_cast<double *>(states + p);
-    for (int i = threadIdx.x; i < (int)(sizeof(LMState) / 8); i += kLmThreads) dst[i] = src[i];
-    const double *ps = reinterpret_cast<const double *>(&s_ps);
-    double *pd2 = reinterpret_cast<double *>(poses + p);
-    for (int i = threadIdx.x; i < (int)(sizeof(PoseState) / 8); i += kLmThreads) pd2[i] = ps[i];
+    // pose: doubles copied by lanes 64.., float mirrors converted by lanes 128.., flags by lane 192
+    // (G is never read when unit_q is set; those lanes publish zeros)
+    const double *pd_src = reinterpret_cast<const double *>(&s_ps);
+    const int a = tid - 64, f = tid - 128;
+    const bool skip_g = s_ps.unit_q != 0;
+    if (a >= 0 && a < kPoseDoubles) reinterpret_cast<double *>(poses + p)[a] = (skip_g && a >= 16) ? 0.0 : pd_src[a];
+    if (f >= 0 && f < kPoseFloats) {
+      // Rf | tf | Gf mirror R | t | G
+      const double v = f < 9 ? s_ps.R[f] : (f < 12 ? s_ps.t[f - 9] : (skip_g ? 0.0 : s_ps.G[f - 12]));
+      (&poses[p].Rf[0])[f] = (float)v;
+    }
+    if (tid == 192) { poses[p].unit_q = s_ps.unit_q; poses[p].active = s_ps.active; }
   }
+  if (tid == 0) {
+    lm_flush(&pend, cold + p, traces + p, acc);
+    if (!s_st.running) __hip_atomic_store(progress + p, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+#ifdef EA_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  EA_LM_STAMP(5, ev_);
 }
 
 // pad + convert a row-major [H][W] device image into the replicated-border layout
@@ -922,13 +1050,18 @@ hipError_t launch_reduce(const GroupDesc *groups, int count, const double *parti
 }
 
 hipError_t launch_lm_step(const GroupDesc *groups, int count, const double *partials, PoseState *poses,
-                          LMState *states, LMTrace *traces, const LMOptions &opt, int *progress,
+                          LMState *states, LMCold *cold, LMTrace *traces, const LMOptions &opt, int *progress,
                           hipStream_t stream) {
   if (count <= 0) return hipSuccess;
   hipLaunchKernelGGL(ea_lm_step_kernel, dim3(count), dim3(kLmThreads), 0, stream, groups, partials, poses,
-                     states, traces, opt, progress);
+                     states, cold, traces, opt, progress);
   return hipGetLastError();
 }
+
+#ifdef EA_STAMPS
+hipError_t set_stamp_buffer(unsigned long long *buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)); }
+hipError_t set_lm_stamp_buffer(unsigned long long *buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_lm_stamp_buf), &buf, sizeof(buf)); }
+#endif
 
 hipError_t launch_selftest_reduce(const float *in, float *a, float *b, float *c, float *d, double *o32, double *o64,
                                   hipStream_t stream) {

@@ -16,6 +16,10 @@
 
 #include "ea_types.h"
 
+#ifndef EA_LM_PROBE
+#define EA_LM_PROBE(k) do {} while (0)  // diagnostic build only (scripts/build_stamps.sh)
+#endif
+
 namespace ea {
 
 struct LMOptions {
@@ -30,19 +34,18 @@ struct LMOptions {
 
 constexpr int kTrace = 128;
 
+// Hot state: what every iteration touches.  The LM-step kernel keeps it in registers on lane 0.
 struct LMState {
   double x[7], cand[7];
   double x_norm, cost;
-  double A[36], g[6];  // unscaled JtJ and Jtr at x
   double S[6];         // Jacobi column scaling, fixed at iteration 0
   // LevenbergMarquardtStrategy
   double radius, decrease_factor, diagonal[6];
-  int reuse_diagonal;
-  // DoglegStrategy (traditional)
-  double mu, alpha, dogleg_step_norm, dl_diag[6], dl_grad[6], dl_gn[6];
-  int dl_reuse;
+  // DoglegStrategy (traditional) scalars
+  double mu, alpha, dogleg_step_norm;
   double model_cost_change;
   double gradient_max_norm;
+  int reuse_diagonal, dl_reuse;
   int iteration;
   int running;      // 1 while the solve needs another evaluation
   int termination;  // ea_termination
@@ -52,6 +55,16 @@ struct LMState {
   int rot_transposed;
   int pad_;
 };
+
+// Cold state: written once per accepted step, read back only after a rejected / invalid step (the system at x is
+// then reused with a smaller radius) and by the dogleg strategy.  Lives in device memory, never staged.
+struct LMCold {
+  double A[21], g[6];  // unscaled JtJ (upper triangle, row-major packed like the accumulator slots) and Jtr at x
+  double dl_diag[6], dl_grad[6], dl_gn[6];
+};
+
+// packed upper-triangle index of (a,b), a <= b, 6x6
+EA_HD constexpr int sym6(int a, int b) { return a <= b ? a * 6 - a * (a - 1) / 2 + (b - a) : b * 6 - b * (b - 1) / 2 + (a - b); }
 
 // per-iteration trace (what minimizer_progress_to_stdout would print); written once per
 // iteration, never read back by the state machine
@@ -95,8 +108,8 @@ EA_HD inline void pose_plus(const double x[7], const double delta[6], double out
 // (ref: standalone/utils.h:51-53); G_j = sum_i dR/dq_i P_ij is the exact tangent derivative for
 // any |q| (P = QuaternionParameterization Jacobian); for |q| = 1 it reduces to -2 [R a]x and the
 // kernels take the short form.
-EA_HD inline void make_pose_state(const double x[7], int rot_transposed, int active,
-                                  PoseState *ps) {
+EA_HD inline void make_pose_core(const double x[7], int rot_transposed, int active,
+                                 PoseState *ps, bool zero_unused_G = true) {
   const double w = x[0], qx = x[1], qy = x[2], qz = x[3];
   for (int i = 0; i < 4; ++i) ps->q[i] = x[i];
   for (int i = 0; i < 3; ++i) ps->t[i] = x[4 + i];
@@ -119,7 +132,7 @@ EA_HD inline void make_pose_state(const double x[7], int rot_transposed, int act
         for (int i = 0; i < 4; ++i) s += dR[i][e] * P[3 * i + j];
         ps->G[9 * j + e] = s;
       }
-  } else {
+  } else if (zero_unused_G) {
     for (int e = 0; e < 27; ++e) ps->G[e] = 0.0;  // never read: the kernels take the -2 [R a]x form
   }
   for (int e = 0; e < 9; ++e) ps->R[e] = R[e];
@@ -136,31 +149,50 @@ EA_HD inline void make_pose_state(const double x[7], int rot_transposed, int act
         }
       }
   }
-  for (int e = 0; e < 9; ++e) ps->Rf[e] = (float)ps->R[e];
-  for (int e = 0; e < 27; ++e) ps->Gf[e] = (float)ps->G[e];
-  for (int e = 0; e < 3; ++e) ps->tf[e] = (float)ps->t[e];
   ps->unit_q = unit_q;
   ps->active = active;
 }
 
-// (A + diag(D^2)) y = g, 6x6 Cholesky.  Returns false when not positive definite / not finite.
-// One reciprocal per pivot; the triangular solves reuse them (this runs on a single GPU lane).
-EA_HD inline bool solve_spd6(const double A[36], const double D[6], const double g[6], double y[6]) {
-  double L[36], inv[6];
+// float mirrors for the fp32 kernels (the LM-step kernel computes them lane-parallel instead)
+EA_HD inline void make_pose_state(const double x[7], int rot_transposed, int active,
+                                  PoseState *ps) {
+  make_pose_core(x, rot_transposed, active, ps);
+  for (int e = 0; e < 9; ++e) ps->Rf[e] = (float)ps->R[e];
+  for (int e = 0; e < 27; ++e) ps->Gf[e] = (float)ps->G[e];
+  for (int e = 0; e < 3; ++e) ps->tf[e] = (float)ps->t[e];
+}
+
+// Reciprocal for pivots and radii.  On the device: v_rcp_f64 + two Newton steps (5 dependent instructions instead of
+// the ~14 of an IEEE division; within 1 ulp) -- this code runs on one lane and is pure latency.
+EA_HD inline double ea_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  return __builtin_fma(r, e, r);
+#else
+  return 1.0 / x;
+#endif
+}
+
+// (A + diag(D2)) y = g for the 6x6 normal equations, square-root-free Cholesky (A + D2 = L diag(d) L^T, unit L).
+// Returns false when not positive definite / not finite.  Six dependent reciprocals are the whole serial chain.
+EA_HD inline bool solve_spd6(const double A[21] /* packed upper */, const double D2[6], const double g[6], double y[6]) {
+  double L[36], M[36], inv[6];  // M_ik = L_ik d_k
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    double s = A[6 * j + j] + D[j] * D[j];
+    double d = A[sym6(j, j)] + D2[j];
 #pragma unroll
-    for (int k = 0; k < j; ++k) s -= L[6 * j + k] * L[6 * j + k];
-    if (!(s > 0.0)) return false;
-    const double d = sqrt(s);
-    L[6 * j + j] = d;
-    inv[j] = 1.0 / d;
+    for (int k = 0; k < j; ++k) d -= L[6 * j + k] * M[6 * j + k];
+    if (!(d > 0.0)) return false;
+    inv[j] = ea_rcp(d);
 #pragma unroll
     for (int i = j + 1; i < 6; ++i) {
-      double t = A[6 * i + j];
+      double t = A[sym6(j, i)];
 #pragma unroll
-      for (int k = 0; k < j; ++k) t -= L[6 * i + k] * L[6 * j + k];
+      for (int k = 0; k < j; ++k) t -= M[6 * i + k] * L[6 * j + k];
+      M[6 * i + j] = t;
       L[6 * i + j] = t * inv[j];
     }
   }
@@ -170,14 +202,14 @@ EA_HD inline bool solve_spd6(const double A[36], const double D[6], const double
     double s = g[i];
 #pragma unroll
     for (int k = 0; k < i; ++k) s -= L[6 * i + k] * z[k];
-    z[i] = s * inv[i];
+    z[i] = s;
   }
 #pragma unroll
   for (int i = 5; i >= 0; --i) {
-    double s = z[i];
+    double s = z[i] * inv[i];
 #pragma unroll
     for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * y[k];
-    y[i] = s * inv[i];
+    y[i] = s;
   }
 #pragma unroll
   for (int i = 0; i < 6; ++i)
@@ -198,6 +230,47 @@ EA_HD inline void lm_trace(const LMState *s, LMTrace *tr, int it, double cost_ch
   }
 }
 
+// Global-memory writes of one state-machine call, deferred to its end: on the device every store issued before the
+// arithmetic would sit in the same in-order memory counter the compiler later waits on, and put the store round trip
+// back on the critical path of a single lane.
+struct LMPending {
+  int store_system;  // 1: the cold state takes JtJ / Jtr from the accumulator slots (evaluation accepted at x)
+  int trace_it;      // >= 0: trace row to write
+  int successful;
+  double cost, cost_change, gradient_max_norm, step_norm, rel, radius;
+};
+
+EA_HD inline void lm_pend_trace(const LMState *s, LMPending *p, int it, double cost_change, double step_norm,
+                                double rel, int successful) {
+  p->trace_it = it;
+  p->successful = successful;
+  p->cost = s->cost;
+  p->cost_change = cost_change;
+  p->gradient_max_norm = s->gradient_max_norm;
+  p->step_norm = step_norm;
+  p->rel = rel;
+  p->radius = s->radius;
+}
+
+EA_HD inline void lm_flush(const LMPending *p, LMCold *c, LMTrace *tr, const double acc[kAccSlots]) {
+  if (p->store_system) {
+#pragma unroll
+    for (int k = 0; k < 21; ++k) c->A[k] = acc[kAccJtJ + k];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) c->g[a] = acc[kAccJtr + a];
+  }
+  if (tr && p->trace_it >= 0 && p->trace_it < kTrace) {
+    const int it = p->trace_it;
+    tr->it_cost[it] = p->cost;
+    tr->it_cost_change[it] = p->cost_change;
+    tr->it_gradient_max_norm[it] = p->gradient_max_norm;
+    tr->it_step_norm[it] = p->step_norm;
+    tr->it_relative_decrease[it] = p->rel;
+    tr->it_radius[it] = p->radius;
+    tr->it_successful[it] = p->successful;
+  }
+}
+
 EA_HD inline void lm_finish(LMState *s, int termination, int why) {
   s->running = 0;
   s->termination = termination;
@@ -211,8 +284,7 @@ EA_HD inline void lm_init(LMState *s, const LMOptions *o, const double q[4], con
   for (int i = 0; i < 7; ++i) s->cand[i] = s->x[i];
   s->x_norm = norm_n(s->x, 7);
   s->cost = 0.0;
-  for (int i = 0; i < 36; ++i) s->A[i] = 0.0;
-  for (int i = 0; i < 6; ++i) { s->g[i] = 0.0; s->S[i] = 1.0; s->diagonal[i] = 0.0; }
+  for (int i = 0; i < 6; ++i) { s->S[i] = 1.0; s->diagonal[i] = 0.0; }
   s->radius = o->initial_trust_region_radius;
   s->decrease_factor = 2.0;
   s->reuse_diagonal = 0;
@@ -225,125 +297,161 @@ EA_HD inline void lm_init(LMState *s, const LMOptions *o, const double q[4], con
   s->num_successful = s->num_unsuccessful = s->num_consecutive_invalid = 0;
   s->num_evals = 0;
   s->rot_transposed = rot_transposed;
+  s->pad_ = 0;
 }
 
-// load JtJ/Jtr from the accumulator slots into the state (the evaluation was made at s->x)
-EA_HD inline void lm_take_system(LMState *s, const double acc[kAccSlots]) {
-  int k = 0;
-  for (int a = 0; a < 6; ++a)
-    for (int b = a; b < 6; ++b) {
-      s->A[6 * a + b] = acc[kAccJtJ + k];
-      s->A[6 * b + a] = acc[kAccJtJ + k];
-      ++k;
-    }
-  for (int a = 0; a < 6; ++a) s->g[a] = acc[kAccJtr + a];
+// The evaluation at s->x delivered `acc`: take the cost and
+// gradient_max_norm = || x - Plus(x, -gradient) ||_inf  (ambient space); the unscaled system itself goes to the
+// cold state in lm_flush.
+EA_HD inline void lm_take_system(LMState *s, LMPending *pend, const double acc[kAccSlots]) {
+  pend->store_system = 1;
   s->cost = acc[kAccCost];
-  // gradient_max_norm = || x - Plus(x, -gradient) ||_inf  (ambient space)
   double neg[6], xp[7], m = 0.0;
-  for (int i = 0; i < 6; ++i) neg[i] = -s->g[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) neg[i] = -acc[kAccJtr + i];
   pose_plus(s->x, neg, xp);
+#pragma unroll
   for (int i = 0; i < 7; ++i) m = fmax(m, fabs(s->x[i] - xp[i]));
   s->gradient_max_norm = m;
 }
 
-// scaled-space step from the current strategy; false = linear solve failed
-EA_HD inline bool lm_strategy_step(LMState *s, const LMOptions *o, const double As[36],
+// scaled-space step from the current strategy; false = linear solve failed.  As: packed upper triangle.
+EA_HD inline bool lm_strategy_step(LMState *s, LMCold *c, const LMOptions *o, const double As[21],
                                    const double gs[6], double step[6]) {
   if (o->strategy == 0) {
-    if (!s->reuse_diagonal)
+    if (!s->reuse_diagonal) {
+#pragma unroll
       for (int i = 0; i < 6; ++i)
-        s->diagonal[i] = fmin(fmax(As[6 * i + i], o->min_lm_diagonal), o->max_lm_diagonal);
-    double D[6], y[6];
-    const double inv_radius = 1.0 / s->radius;
-    for (int i = 0; i < 6; ++i) D[i] = sqrt(s->diagonal[i] * inv_radius);
+        s->diagonal[i] = fmin(fmax(As[sym6(i, i)], o->min_lm_diagonal), o->max_lm_diagonal);
+    }
+    // Ceres hands the solver D = sqrt(diagonal / radius) and the solver squares it again; D^2 is used directly
+    double D2[6], y[6];
+    const double inv_radius = ea_rcp(s->radius);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) D2[i] = s->diagonal[i] * inv_radius;
     s->reuse_diagonal = 1;
-    if (!solve_spd6(As, D, gs, y)) return false;
+    if (!solve_spd6(As, D2, gs, y)) return false;
+#pragma unroll
     for (int i = 0; i < 6; ++i) step[i] = -y[i];
     return true;
   }
   // traditional dogleg
   if (!s->dl_reuse) {
+    double diag[6], grad[6], gn[6];
     for (int i = 0; i < 6; ++i)
-      s->dl_diag[i] = sqrt(fmin(fmax(As[6 * i + i], o->min_lm_diagonal), o->max_lm_diagonal));
-    for (int i = 0; i < 6; ++i) s->dl_grad[i] = gs[i] / s->dl_diag[i];
+      diag[i] = sqrt(fmin(fmax(As[sym6(i, i)], o->min_lm_diagonal), o->max_lm_diagonal));
+    for (int i = 0; i < 6; ++i) grad[i] = gs[i] / diag[i];
     double v[6], qf = 0.0, g2 = 0.0;
-    for (int i = 0; i < 6; ++i) v[i] = s->dl_grad[i] / s->dl_diag[i];
+    for (int i = 0; i < 6; ++i) v[i] = grad[i] / diag[i];
     for (int a = 0; a < 6; ++a)
-      for (int b = 0; b < 6; ++b) qf += v[a] * As[6 * a + b] * v[b];
-    for (int i = 0; i < 6; ++i) g2 += s->dl_grad[i] * s->dl_grad[i];
+      for (int b = 0; b < 6; ++b) qf += v[a] * As[sym6(a, b)] * v[b];
+    for (int i = 0; i < 6; ++i) g2 += grad[i] * grad[i];
     s->alpha = g2 / qf;
     bool ok = false;
     while (s->mu < 1.0) {
-      double D[6], y[6];
-      for (int i = 0; i < 6; ++i) D[i] = s->dl_diag[i] * sqrt(s->mu);
-      ok = solve_spd6(As, D, gs, y);
+      double D2[6], y[6];
+      for (int i = 0; i < 6; ++i) D2[i] = diag[i] * diag[i] * s->mu;
+      ok = solve_spd6(As, D2, gs, y);
       if (ok) {
-        for (int i = 0; i < 6; ++i) s->dl_gn[i] = y[i];
+        for (int i = 0; i < 6; ++i) gn[i] = y[i];
         break;
       }
       s->mu *= 10.0;
     }
     if (!ok) return false;
     s->mu = fmax(1e-8, 2.0 * s->mu / 10.0);
-    for (int i = 0; i < 6; ++i) s->dl_gn[i] *= -s->dl_diag[i];
+    for (int i = 0; i < 6; ++i) gn[i] *= -diag[i];
+    for (int i = 0; i < 6; ++i) { c->dl_diag[i] = diag[i]; c->dl_grad[i] = grad[i]; c->dl_gn[i] = gn[i]; }
   }
-  const double gn_norm = norm_n(s->dl_gn, 6);
+  double dl_diag[6], dl_grad[6], dl_gn[6];
+  for (int i = 0; i < 6; ++i) { dl_diag[i] = c->dl_diag[i]; dl_grad[i] = c->dl_grad[i]; dl_gn[i] = c->dl_gn[i]; }
+  const double gn_norm = norm_n(dl_gn, 6);
   if (gn_norm <= s->radius) {
-    for (int i = 0; i < 6; ++i) step[i] = s->dl_gn[i] / s->dl_diag[i];
+    for (int i = 0; i < 6; ++i) step[i] = dl_gn[i] / dl_diag[i];
     s->dogleg_step_norm = gn_norm;
     return true;
   }
-  const double gradient_norm = norm_n(s->dl_grad, 6);
+  const double gradient_norm = norm_n(dl_grad, 6);
   if (gradient_norm * s->alpha >= s->radius) {
     for (int i = 0; i < 6; ++i)
-      step[i] = -(s->radius / gradient_norm) * s->dl_grad[i] / s->dl_diag[i];
+      step[i] = -(s->radius / gradient_norm) * dl_grad[i] / dl_diag[i];
     s->dogleg_step_norm = s->radius;
     return true;
   }
   double b_dot_a = 0.0;
-  for (int i = 0; i < 6; ++i) b_dot_a += -s->alpha * s->dl_grad[i] * s->dl_gn[i];
+  for (int i = 0; i < 6; ++i) b_dot_a += -s->alpha * dl_grad[i] * dl_gn[i];
   const double a_sq = (s->alpha * gradient_norm) * (s->alpha * gradient_norm);
   const double bma_sq = a_sq - 2.0 * b_dot_a + gn_norm * gn_norm;
-  const double c = b_dot_a - a_sq;
-  const double d = sqrt(c * c + bma_sq * (s->radius * s->radius - a_sq));
-  const double beta = (c <= 0) ? (d - c) / bma_sq : (s->radius * s->radius - a_sq) / (d + c);
+  const double cc = b_dot_a - a_sq;
+  const double d = sqrt(cc * cc + bma_sq * (s->radius * s->radius - a_sq));
+  const double beta = (cc <= 0) ? (d - cc) / bma_sq : (s->radius * s->radius - a_sq) / (d + cc);
   double dl[6];
-  for (int i = 0; i < 6; ++i) dl[i] = (-s->alpha * (1.0 - beta)) * s->dl_grad[i] + beta * s->dl_gn[i];
+  for (int i = 0; i < 6; ++i) dl[i] = (-s->alpha * (1.0 - beta)) * dl_grad[i] + beta * dl_gn[i];
   s->dogleg_step_norm = norm_n(dl, 6);
-  for (int i = 0; i < 6; ++i) step[i] = dl[i] / s->dl_diag[i];
+  for (int i = 0; i < 6; ++i) step[i] = dl[i] / dl_diag[i];
   return true;
 }
 
 // Top of TrustRegionMinimizer's loop: convergence checks, then a trust-region step and the
 // candidate pose.  Loops over invalid steps (they need no new evaluation).  On return either
 // s->running == 0 or s->cand holds the pose to evaluate next.
-EA_HD inline void lm_prepare_next(LMState *s, LMTrace *tr, const LMOptions *o) {
+// `fresh`: acc holds the evaluation at s->x (accepted step, first iteration) and is used from registers; otherwise
+// the system is re-read from the cold state (after a rejected step).
+EA_HD inline void lm_prepare_next(LMState *s, LMCold *c, LMTrace *tr, const LMOptions *o,
+                                  const double acc[kAccSlots], bool fresh) {
+  double As[21], gs[6];
+  bool have_system = false;
   for (;;) {
     if (s->iteration >= o->max_num_iterations) { lm_finish(s, 1, 4); return; }
     if (s->gradient_max_norm <= o->gradient_tolerance) { lm_finish(s, 0, 2); return; }
     if (s->radius <= o->min_trust_region_radius) { lm_finish(s, 0, 5); return; }
     s->iteration += 1;
-    double As[36], gs[6], step[6];
-    for (int a = 0; a < 6; ++a) {
-      gs[a] = s->g[a] * s->S[a];
-      for (int b = 0; b < 6; ++b) As[6 * a + b] = s->A[6 * a + b] * s->S[a] * s->S[b];
+    if (!have_system) {
+      double A[21], g[6];
+      if (fresh) {
+#pragma unroll
+        for (int k = 0; k < 21; ++k) A[k] = acc[kAccJtJ + k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g[k] = acc[kAccJtr + k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 21; ++k) A[k] = c->A[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g[k] = c->g[k];
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        gs[a] = g[a] * s->S[a];
+#pragma unroll
+        for (int b = a; b < 6; ++b) As[sym6(a, b)] = A[sym6(a, b)] * s->S[a] * s->S[b];
+      }
+      have_system = true;
     }
-    bool ok = lm_strategy_step(s, o, As, gs, step);
+    EA_LM_PROBE(2);
+    double step[6];
+    bool ok = lm_strategy_step(s, c, o, As, gs, step);
+    EA_LM_PROBE(3);
     if (ok) {
       // model_cost_change = -(Js s)^T (r + Js s / 2) = -(g^T s + s^T A s / 2)
-      double gts = 0.0, sAs = 0.0;
+      double gts = 0.0, diag = 0.0, off = 0.0;
+#pragma unroll
       for (int a = 0; a < 6; ++a) {
         gts += gs[a] * step[a];
-        for (int b = 0; b < 6; ++b) sAs += step[a] * As[6 * a + b] * step[b];
+        diag += step[a] * As[sym6(a, a)] * step[a];
+#pragma unroll
+        for (int b = a + 1; b < 6; ++b) off += step[a] * As[sym6(a, b)] * step[b];
       }
-      s->model_cost_change = -(gts + 0.5 * sAs);
+      s->model_cost_change = -(gts + 0.5 * (diag + 2.0 * off));
       if (!(s->model_cost_change > 0.0)) ok = false;
     }
+    EA_LM_PROBE(4);
     if (ok) {
       double delta[6];
+#pragma unroll
       for (int i = 0; i < 6; ++i) delta[i] = step[i] * s->S[i];
       pose_plus(s->x, delta, s->cand);
       s->num_consecutive_invalid = 0;
+      EA_LM_PROBE(5);
       return;
     }
     // HandleInvalidStep
@@ -359,40 +467,52 @@ EA_HD inline void lm_prepare_next(LMState *s, LMTrace *tr, const LMOptions *o) {
 }
 
 // after the evaluation at the initial pose
-EA_HD inline void lm_begin(LMState *s, LMTrace *tr, const LMOptions *o, const double acc[kAccSlots]) {
+EA_HD inline void lm_begin(LMState *s, LMCold *c, LMTrace *tr, const LMOptions *o, const double acc[kAccSlots],
+                           LMPending *pend) {
+  pend->store_system = 0;
+  pend->trace_it = -1;
   s->num_evals += 1;
   if (acc[kAccInvalid] > 0.0) { lm_finish(s, 2, 6); return; }
-  lm_take_system(s, acc);
+  lm_take_system(s, pend, acc);
   if (o->jacobi_scaling)
-    for (int i = 0; i < 6; ++i) s->S[i] = 1.0 / (1.0 + sqrt(s->A[6 * i + i]));
-  lm_trace(s, tr, 0, 0.0, 0.0, 0.0, 1);
-  lm_prepare_next(s, tr, o);
+    for (int i = 0; i < 6; ++i) s->S[i] = 1.0 / (1.0 + sqrt(acc[kAccJtJ + sym6(i, i)]));
+  lm_pend_trace(s, pend, 0, 0.0, 0.0, 0.0, 1);
+  lm_prepare_next(s, c, tr, o, acc, true);
 }
 
 // after the evaluation at s->cand
-EA_HD inline void lm_advance(LMState *s, LMTrace *tr, const LMOptions *o, const double acc[kAccSlots]) {
+EA_HD inline void lm_advance(LMState *s, LMCold *c, LMTrace *tr, const LMOptions *o, const double acc[kAccSlots],
+                             LMPending *pend) {
+  pend->store_system = 0;
+  pend->trace_it = -1;
   s->num_evals += 1;
   const bool eval_ok = !(acc[kAccInvalid] > 0.0);
   const double cand_cost = eval_ok ? acc[kAccCost] : DBL_MAX;
   double dx[7];
+#pragma unroll
   for (int i = 0; i < 7; ++i) dx[i] = s->x[i] - s->cand[i];
   const double step_norm = norm_n(dx, 7);
   if (step_norm <= o->parameter_tolerance * (s->x_norm + o->parameter_tolerance)) {
-    lm_trace(s, tr, s->iteration, 0.0, step_norm, 0.0, 0);
+    lm_pend_trace(s, pend, s->iteration, 0.0, step_norm, 0.0, 0);
     lm_finish(s, 0, 3);
     return;
   }
   const double cost_change = s->cost - cand_cost;
   if (fabs(cost_change) <= o->function_tolerance * s->cost) {
-    lm_trace(s, tr, s->iteration, cost_change, step_norm, 0.0, 0);
+    lm_pend_trace(s, pend, s->iteration, cost_change, step_norm, 0.0, 0);
     lm_finish(s, 0, 1);
     return;
   }
   const double rel = cost_change / s->model_cost_change;
+  EA_LM_PROBE(0);
+  bool fresh = false;
   if (rel > o->min_relative_decrease) {
+#pragma unroll
     for (int i = 0; i < 7; ++i) s->x[i] = s->cand[i];
     s->x_norm = norm_n(s->x, 7);
-    lm_take_system(s, acc);
+    lm_take_system(s, pend, acc);
+    fresh = true;
+    EA_LM_PROBE(1);
     s->num_successful += 1;
     if (o->strategy == 0) {
       const double f = 2.0 * rel - 1.0;
@@ -406,7 +526,8 @@ EA_HD inline void lm_advance(LMState *s, LMTrace *tr, const LMOptions *o, const 
       s->radius = fmin(s->radius, o->max_trust_region_radius);
       s->dl_reuse = 0;
     }
-    lm_trace(s, tr, s->iteration, cost_change, step_norm, rel, 1);
+    EA_LM_PROBE(6);
+    lm_pend_trace(s, pend, s->iteration, cost_change, step_norm, rel, 1);
   } else {
     s->num_unsuccessful += 1;
     if (o->strategy == 0) {
@@ -417,9 +538,10 @@ EA_HD inline void lm_advance(LMState *s, LMTrace *tr, const LMOptions *o, const 
       s->radius *= 0.5;
       s->dl_reuse = 1;
     }
-    lm_trace(s, tr, s->iteration, cost_change, step_norm, rel, 0);
+    lm_pend_trace(s, pend, s->iteration, cost_change, step_norm, rel, 0);
   }
-  lm_prepare_next(s, tr, o);
+  EA_LM_PROBE(7);
+  lm_prepare_next(s, c, tr, o, acc, fresh);
 }
 
 }  // namespace ea

@@ -21,6 +21,7 @@ struct ShimOut {
 int ea_lm_host_solve(const ea::LMOptions *o, const double q[4], const double t[3], int rot_transposed,
                      ea_eval_cb cb, void *user, ShimOut *out) {
   ea::LMState s;
+  ea::LMCold c;
   ea::LMTrace tr;
   std::memset(&tr, 0, sizeof(tr));
   ea::lm_init(&s, o, q, t, rot_transposed);
@@ -28,8 +29,10 @@ int ea_lm_host_solve(const ea::LMOptions *o, const double q[4], const double t[3
   int guard = o->max_num_iterations + 4;
   while (s.running && guard-- > 0) {
     cb(s.num_evals == 0 ? s.x : s.cand, acc, user);
-    if (s.num_evals == 0) ea::lm_begin(&s, &tr, o, acc);
-    else ea::lm_advance(&s, &tr, o, acc);
+    ea::LMPending pend;
+    if (s.num_evals == 0) ea::lm_begin(&s, &c, &tr, o, acc, &pend);
+    else ea::lm_advance(&s, &c, &tr, o, acc, &pend);
+    ea::lm_flush(&pend, &c, &tr, acc);
   }
   std::memcpy(out->x, s.x, sizeof(out->x));
   out->iteration = s.iteration; out->termination = s.termination; out->why = s.why;
