@@ -316,9 +316,12 @@ EA_HD inline void lm_take_system(LMState *s, LMPending *pend, const double acc[k
 }
 
 // scaled-space step from the current strategy; false = linear solve failed.  As: packed upper triangle.
+// STRAT: trust-region strategy as a compile-time constant (0 LM, 1 traditional dogleg) -- the device kernels are
+// instantiated per strategy so that the code of the other one does not weigh on the register allocation.
+template <int STRAT>
 EA_HD inline bool lm_strategy_step(LMState *s, LMCold *c, const LMOptions *o, const double As[21],
                                    const double gs[6], double step[6]) {
-  if (o->strategy == 0) {
+  if constexpr (STRAT == 0) {
     if (!s->reuse_diagonal) {
 #pragma unroll
       for (int i = 0; i < 6; ++i)
@@ -334,7 +337,7 @@ EA_HD inline bool lm_strategy_step(LMState *s, LMCold *c, const LMOptions *o, co
 #pragma unroll
     for (int i = 0; i < 6; ++i) step[i] = -y[i];
     return true;
-  }
+  } else {
   // traditional dogleg
   if (!s->dl_reuse) {
     double diag[6], grad[6], gn[6];
@@ -390,6 +393,7 @@ EA_HD inline bool lm_strategy_step(LMState *s, LMCold *c, const LMOptions *o, co
   s->dogleg_step_norm = norm_n(dl, 6);
   for (int i = 0; i < 6; ++i) step[i] = dl[i] / dl_diag[i];
   return true;
+  }
 }
 
 // Top of TrustRegionMinimizer's loop: convergence checks, then a trust-region step and the
@@ -397,6 +401,7 @@ EA_HD inline bool lm_strategy_step(LMState *s, LMCold *c, const LMOptions *o, co
 // s->running == 0 or s->cand holds the pose to evaluate next.
 // `fresh`: acc holds the evaluation at s->x (accepted step, first iteration) and is used from registers; otherwise
 // the system is re-read from the cold state (after a rejected step).
+template <int STRAT>
 EA_HD inline void lm_prepare_next(LMState *s, LMCold *c, LMTrace *tr, const LMOptions *o,
                                   const double acc[kAccSlots], bool fresh) {
   double As[21], gs[6];
@@ -429,7 +434,7 @@ EA_HD inline void lm_prepare_next(LMState *s, LMCold *c, LMTrace *tr, const LMOp
     }
     EA_LM_PROBE(2);
     double step[6];
-    bool ok = lm_strategy_step(s, c, o, As, gs, step);
+    bool ok = lm_strategy_step<STRAT>(s, c, o, As, gs, step);
     EA_LM_PROBE(3);
     if (ok) {
       // model_cost_change = -(Js s)^T (r + Js s / 2) = -(g^T s + s^T A s / 2)
@@ -461,12 +466,13 @@ EA_HD inline void lm_prepare_next(LMState *s, LMCold *c, LMTrace *tr, const LMOp
       lm_finish(s, 2, 7);
       return;
     }
-    if (o->strategy == 0) { s->radius *= 0.5; s->reuse_diagonal = 1; }
+    if constexpr (STRAT == 0) { s->radius *= 0.5; s->reuse_diagonal = 1; }
     else { s->mu *= 10.0; s->dl_reuse = 0; }
   }
 }
 
 // after the evaluation at the initial pose
+template <int STRAT>
 EA_HD inline void lm_begin(LMState *s, LMCold *c, LMTrace *tr, const LMOptions *o, const double acc[kAccSlots],
                            LMPending *pend) {
   pend->store_system = 0;
@@ -477,10 +483,11 @@ EA_HD inline void lm_begin(LMState *s, LMCold *c, LMTrace *tr, const LMOptions *
   if (o->jacobi_scaling)
     for (int i = 0; i < 6; ++i) s->S[i] = 1.0 / (1.0 + sqrt(acc[kAccJtJ + sym6(i, i)]));
   lm_pend_trace(s, pend, 0, 0.0, 0.0, 0.0, 1);
-  lm_prepare_next(s, c, tr, o, acc, true);
+  lm_prepare_next<STRAT>(s, c, tr, o, acc, true);
 }
 
 // after the evaluation at s->cand
+template <int STRAT>
 EA_HD inline void lm_advance(LMState *s, LMCold *c, LMTrace *tr, const LMOptions *o, const double acc[kAccSlots],
                              LMPending *pend) {
   pend->store_system = 0;
@@ -514,7 +521,7 @@ EA_HD inline void lm_advance(LMState *s, LMCold *c, LMTrace *tr, const LMOptions
     fresh = true;
     EA_LM_PROBE(1);
     s->num_successful += 1;
-    if (o->strategy == 0) {
+    if constexpr (STRAT == 0) {
       const double f = 2.0 * rel - 1.0;
       s->radius = s->radius / fmax(1.0 / 3.0, 1.0 - f * f * f);
       s->radius = fmin(o->max_trust_region_radius, s->radius);
@@ -530,7 +537,7 @@ EA_HD inline void lm_advance(LMState *s, LMCold *c, LMTrace *tr, const LMOptions
     lm_pend_trace(s, pend, s->iteration, cost_change, step_norm, rel, 1);
   } else {
     s->num_unsuccessful += 1;
-    if (o->strategy == 0) {
+    if constexpr (STRAT == 0) {
       s->radius = s->radius / s->decrease_factor;
       s->decrease_factor *= 2.0;
       s->reuse_diagonal = 1;
@@ -541,7 +548,17 @@ EA_HD inline void lm_advance(LMState *s, LMCold *c, LMTrace *tr, const LMOptions
     lm_pend_trace(s, pend, s->iteration, cost_change, step_norm, rel, 0);
   }
   EA_LM_PROBE(7);
-  lm_prepare_next(s, c, tr, o, acc, fresh);
+  lm_prepare_next<STRAT>(s, c, tr, o, acc, fresh);
+}
+
+// run-time strategy (host shim)
+EA_HD inline void lm_begin_rt(LMState *s, LMCold *c, LMTrace *tr, const LMOptions *o, const double acc[kAccSlots],
+                              LMPending *pend) {
+  if (o->strategy == 0) lm_begin<0>(s, c, tr, o, acc, pend); else lm_begin<1>(s, c, tr, o, acc, pend);
+}
+EA_HD inline void lm_advance_rt(LMState *s, LMCold *c, LMTrace *tr, const LMOptions *o, const double acc[kAccSlots],
+                                LMPending *pend) {
+  if (o->strategy == 0) lm_advance<0>(s, c, tr, o, acc, pend); else lm_advance<1>(s, c, tr, o, acc, pend);
 }
 
 }  // namespace ea

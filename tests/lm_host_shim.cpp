@@ -30,8 +30,8 @@ int ea_lm_host_solve(const ea::LMOptions *o, const double q[4], const double t[3
   while (s.running && guard-- > 0) {
     cb(s.num_evals == 0 ? s.x : s.cand, acc, user);
     ea::LMPending pend;
-    if (s.num_evals == 0) ea::lm_begin(&s, &c, &tr, o, acc, &pend);
-    else ea::lm_advance(&s, &c, &tr, o, acc, &pend);
+    if (s.num_evals == 0) ea::lm_begin_rt(&s, &c, &tr, o, acc, &pend);
+    else ea::lm_advance_rt(&s, &c, &tr, o, acc, &pend);
     ea::lm_flush(&pend, &c, &tr, acc);
   }
   std::memcpy(out->x, s.x, sizeof(out->x));
