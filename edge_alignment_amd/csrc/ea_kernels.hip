@@ -576,10 +576,12 @@ constexpr int kHdrBytes = kRedBytes + kMaxWaves * 16;  // + bbox words, keeps th
 // One workgroup's share of an evaluation: NT lanes x PPT points -> the workgroup's partial row.
 // X/Y/Z hold the lane's points (lanes past `count` carry a copy of the chunk's last point); the return value is
 // slot `my_slot` of the row (0 when my_slot < 0).  `ps` may live in global memory (scalar loads) or LDS.
-template <typename T, int PPT, bool USE_LDS, int NT, bool VAR>
+template <typename T, int PPT, int MODE, int NT, bool VAR>
 __device__ __forceinline__ double fused_chunk(const ProblemDesc &pd, const PoseState &ps, const T (&X)[PPT],
                                               const T (&Y)[PPT], const T (&Z)[PPT], int count, double *s_red,
                                               int *s_box, T *s_tile, int lds_texels, int my_slot) {
+  // MODE 0: stencil rows from L2.  1: DT footprint staged in LDS.
+  constexpr bool USE_LDS = MODE == 1;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -588,12 +590,13 @@ __device__ __forceinline__ double fused_chunk(const ProblemDesc &pd, const PoseS
   const int loss_kind = pd.loss_kind;
   const T loss_a = Uni<T>::loss_a(pd);
 
+  T acc[28];
+  int n_bad = 0;
   // ---- phase 1: warp + projection.  Lanes past the end of the chunk and lanes whose functor fails are moved
   // to a harmless sample; both get weight 0 below, so the arithmetic needs no divergent branch.
   using ProjT = typename std::conditional<VAR, ProjV<T>, Proj<T>>::type;
   ProjT pr[PPT];
   bool valid[PPT];
-  int n_bad = 0;
   int bb_u0 = 0x7fffffff, bb_u1 = -0x7fffffff, bb_v0 = 0x7fffffff, bb_v1 = -0x7fffffff;
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
@@ -659,7 +662,6 @@ __device__ __forceinline__ double fused_chunk(const ProblemDesc &pd, const PoseS
 
   EA_STAMP(3);  // projected
   // ---- phase 3: sample, Jacobian, weights, accumulate
-  T acc[28];
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
     T f, Fu, Fv;
@@ -727,7 +729,7 @@ __device__ __forceinline__ double fused_chunk(const ProblemDesc &pd, const PoseS
 
 // NT = workgroup size (256 or 1024).  1024 = one workgroup per CU: four times fewer partial rows
 // to fold afterwards at the same points-per-lane latency.
-template <typename T, int PPT, bool USE_LDS, int NT, bool VAR>
+template <typename T, int PPT, int MODE, int NT, bool VAR>
 __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
     const ProblemDesc *__restrict__ probs, const PoseState *__restrict__ poses,
     double *__restrict__ partials, int chunk, int chunks_per_xcd, int xcd_remap, int lds_texels,
@@ -770,7 +772,7 @@ __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
   asm volatile("" ::"v"(X[0]), "v"(Y[0]), "v"(Z[0]));
 #endif
   EA_STAMP(2);  // points arrived
-  const double sum = fused_chunk<T, PPT, USE_LDS, NT, VAR>(pd, ps, X, Y, Z, count, s_red, s_box, s_tile, lds_texels,
+  const double sum = fused_chunk<T, PPT, MODE, NT, VAR>(pd, ps, X, Y, Z, count, s_red, s_box, s_tile, lds_texels,
                                                            tid < kAccSlots ? tid : -1);
   if (tid < kAccSlots) partials[(size_t)(pd.tile_begin + c) * kAccSlots + tid] = sum;
 #ifdef EA_STAMPS
@@ -1172,7 +1174,7 @@ __global__ __launch_bounds__(kPersistThreads) void ea_lm_persistent_kernel(
     EA_PSTAMP(0, 1);  // pose arrived
 
     // ---- 2. evaluate; 3. row message (wave 0, one store instruction)
-    const double sum = fused_chunk<T, PPT, false, NT, VAR>(pd, s_pose, X, Y, Z, count, s_red, nullptr, nullptr, 0, row_slot);
+    const double sum = fused_chunk<T, PPT, 0, NT, VAR>(pd, s_pose, X, Y, Z, count, s_red, nullptr, nullptr, 0, row_slot);
     EA_PSTAMP(0, 2);  // evaluated
     if (wave == 0 && lane < kRowMsgWords)
       msg_store(row_msg + lane, m_w == 7 ? tag : __builtin_bit_cast(unsigned long long, sum));
@@ -1278,13 +1280,13 @@ hipError_t launch_eval_fused(int dtype, int ppt, int nt, int variant, const Prob
 #define EA_LAUNCH(T, P, L, N, V)                                                                \
   hipLaunchKernelGGL((ea_eval_fused_kernel<T, P, L, N, V>), grid, dim3(N), shmem, stream, probs, \
                      poses, partials, chunk, chunks_per_xcd, xcd_remap, lds_texels, terms_are_groups)
-#define EA_LAUNCH_L(T, P, N)                                                                  \
-  do {                                                                                        \
-    if (lds_texels > 0) EA_LAUNCH(T, P, true, N, false); else EA_LAUNCH(T, P, false, N, false); \
+#define EA_LAUNCH_L(T, P, N)                                                          \
+  do {                                                                                \
+    if (lds_texels > 0) EA_LAUNCH(T, P, 1, N, false); else EA_LAUNCH(T, P, 0, N, false); \
   } while (0)
   if (variant) {  // distortion / second-camera terms: 256-thread workgroups, L2 path, 1-2 points per lane
-    if (dtype == 1) { if (ppt == 1) EA_LAUNCH(float, 1, false, 256, true); else EA_LAUNCH(float, 2, false, 256, true); }
-    else { if (ppt == 1) EA_LAUNCH(double, 1, false, 256, true); else EA_LAUNCH(double, 2, false, 256, true); }
+    if (dtype == 1) { if (ppt == 1) EA_LAUNCH(float, 1, 0, 256, true); else EA_LAUNCH(float, 2, 0, 256, true); }
+    else { if (ppt == 1) EA_LAUNCH(double, 1, 0, 256, true); else EA_LAUNCH(double, 2, 0, 256, true); }
   } else if (dtype == 1) {
     if (nt == 1024) { if (ppt == 1) EA_LAUNCH_L(float, 1, 1024); else if (ppt == 2) EA_LAUNCH_L(float, 2, 1024); else EA_LAUNCH_L(float, 4, 1024); }
     else if (ppt == 1) EA_LAUNCH_L(float, 1, 256);
