@@ -26,11 +26,6 @@ hipError_t launch_reduce(const GroupDesc *groups, int count, const double *parti
 hipError_t launch_lm_step(const GroupDesc *groups, int count, const double *partials, PoseState *poses,
                           LMState *states, LMCold *cold, LMTrace *traces, const LMOptions &opt, int *running_flags,
                           hipStream_t stream);
-hipError_t persistent_blocks_per_cu(int dtype, int ppt, int variant, int *blocks);
-hipError_t launch_lm_persistent(int dtype, int ppt, int variant, const ProblemDesc *probs, const GroupDesc *groups,
-                                int nterms, int chunk, int max_chunks, int xcd_remap, unsigned long long *pose_msgs,
-                                unsigned long long *row_msgs, LMState *states, LMTrace *traces, const LMOptions &opt,
-                                unsigned epoch, int *abort_flag, int terms_are_groups, hipStream_t stream);
 hipError_t launch_pad_image(int dtype, const void *src, int H, int W, void *dst, int pitch, hipStream_t stream);
 hipError_t launch_selftest_reduce(const float *in, float *a, float *b, float *c, float *d, double *o32, double *o64,
                                   hipStream_t stream);
@@ -111,13 +106,6 @@ struct ea_batch {
   unsigned char *d_lm_block = nullptr;  // [LMState x count | PoseState x count], one upload per solve
   LMState *d_states = nullptr;
   LMCold *d_cold = nullptr;             // written by the first LM step before anything reads it
-  // persistent solve: tagged messages (ea_types.h).  [pose message x count | abort word], one row message per tile
-  unsigned long long *d_pose_msgs = nullptr, *h_pose_msgs = nullptr, *d_row_msgs = nullptr;
-  unsigned epoch = 0;                   // names the solve inside every message tag
-  int min_group_rows = 0;               // fewest partial rows of any problem (0: an empty problem is present)
-  int max_group_rows = 0;
-  int persistent_capacity = -1;         // workgroups the device keeps resident for the current kernel shape
-  int last_solve_persistent = 0;
   LMTrace *d_traces = nullptr;
   int *d_progress = nullptr;            // device view of h_progress
   // pinned host mirrors
@@ -128,7 +116,7 @@ struct ea_batch {
   LMTrace *h_traces = nullptr;
   int *h_progress = nullptr;            // pinned, device-visible: [running x count | evaluations done x count]
   // tuning (-1 = heuristic)
-  int t_lds_bytes = -1, t_ppt = -1, t_use_lds = -1, t_xcd = -1, t_nt = -1, t_persistent = -1;
+  int t_lds_bytes = -1, t_ppt = -1, t_use_lds = -1, t_xcd = -1, t_nt = -1;
   int ppt = 1, nt = 256, lds_bytes = 0, xcd_remap = 1;
   bool built = false;
 };
@@ -376,11 +364,11 @@ extern "C" int ea_problem_set_flavour(ea_problem *p, double z_guard, double z_ep
 // ---- batch --------------------------------------------------------------------------------------
 
 static void batch_free_device(ea_batch *b) {
-  (void)hipFree(b->d_probs); (void)hipFree(b->d_groups); (void)hipFree(b->d_lm_block); (void)hipFree(b->d_traces); (void)hipFree(b->d_cold); (void)hipFree(b->d_pose_msgs); (void)hipFree(b->d_row_msgs); (void)hipHostFree(b->h_pose_msgs);
+  (void)hipFree(b->d_probs); (void)hipFree(b->d_groups); (void)hipFree(b->d_lm_block); (void)hipFree(b->d_traces); (void)hipFree(b->d_cold);
   (void)hipFree(b->d_partials); (void)hipFree(b->d_out);
   (void)hipHostFree(b->h_lm_block); (void)hipHostFree(b->h_out);
   (void)hipHostFree(b->h_traces); (void)hipHostFree(b->h_progress);
-  b->d_probs = nullptr; b->d_groups = nullptr; b->d_poses = nullptr; b->d_partials = nullptr; b->d_traces = nullptr; b->d_cold = nullptr; b->d_pose_msgs = nullptr; b->d_row_msgs = nullptr; b->h_pose_msgs = nullptr; b->d_lm_block = nullptr;
+  b->d_probs = nullptr; b->d_groups = nullptr; b->d_poses = nullptr; b->d_partials = nullptr; b->d_traces = nullptr; b->d_cold = nullptr; b->d_lm_block = nullptr;
   b->d_out = nullptr; b->d_states = nullptr; b->d_progress = nullptr;
   b->h_poses = nullptr; b->h_out = nullptr; b->h_states = nullptr; b->h_traces = nullptr; b->h_progress = nullptr;
   b->h_lm_block = nullptr;
@@ -410,9 +398,6 @@ extern "C" int ea_batch_create(ea_batch **out, ea_problem *const *problems, int 
   if (e == hipSuccess) e = hipMalloc(&b->d_out, c * sizeof(EvalOut));
   if (e == hipSuccess) e = hipMalloc(&b->d_traces, c * sizeof(LMTrace));
   if (e == hipSuccess) e = hipMalloc(&b->d_cold, c * sizeof(LMCold));
-  if (e == hipSuccess) e = hipMalloc(&b->d_pose_msgs, (c * kPoseMsgWords + 8) * sizeof(unsigned long long));
-  if (e == hipSuccess) e = hipMemset(b->d_pose_msgs, 0, (c * kPoseMsgWords + 8) * sizeof(unsigned long long));
-  if (e == hipSuccess) e = hipHostMalloc(&b->h_pose_msgs, (c * kPoseMsgWords + 8) * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipHostMalloc(&b->h_lm_block, lm_bytes);
   if (e == hipSuccess) e = hipHostMalloc(&b->h_out, c * sizeof(EvalOut));
   if (e == hipSuccess) e = hipHostMalloc(&b->h_traces, c * sizeof(LMTrace));
@@ -553,13 +538,6 @@ static int batch_build(ea_batch *b) {
   b->nterms = (int)terms.size();
   b->ntiles = rows;
   b->max_chunks = max_chunks;
-  b->min_group_rows = rows;
-  b->max_group_rows = 0;
-  for (const GroupDesc &g : groups) {
-    b->min_group_rows = std::min(b->min_group_rows, g.tile_end - g.tile_begin);
-    b->max_group_rows = std::max(b->max_group_rows, g.tile_end - g.tile_begin);
-  }
-  b->persistent_capacity = -1;
   if (b->nterms > b->terms_cap) {
     (void)hipFree(b->d_probs);
     b->d_probs = nullptr;
@@ -572,10 +550,6 @@ static int batch_build(ea_batch *b) {
     b->tiles_cap = b->ntiles + b->ntiles / 4 + 16;
     HIPCHK(hipMalloc(&b->d_partials, (size_t)b->tiles_cap * kAccSlots * sizeof(double)));
     HIPCHK(hipMemset(b->d_partials, 0, (size_t)b->tiles_cap * kAccSlots * sizeof(double)));
-    (void)hipFree(b->d_row_msgs);
-    b->d_row_msgs = nullptr;
-    HIPCHK(hipMalloc(&b->d_row_msgs, (size_t)b->tiles_cap * kRowMsgWords * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(b->d_row_msgs, 0, (size_t)b->tiles_cap * kRowMsgWords * sizeof(unsigned long long)));
   }
   HIPCHK(hipMemcpy(b->d_probs, descs.data(), descs.size() * sizeof(ProblemDesc), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(b->d_groups, groups.data(), groups.size() * sizeof(GroupDesc), hipMemcpyHostToDevice));
@@ -696,49 +670,6 @@ extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, 
   }
   HIPCHK(hipMemcpyAsync(b->d_lm_block, b->h_lm_block, (size_t)count * (sizeof(LMState) + sizeof(PoseState)),
                         hipMemcpyHostToDevice, b->stream));
-  // Persistent solve (opt-in: ea_batch_set_tuning("persistent", 1)): when every workgroup of the batch fits on the
-  // device at once (strategy LM, 256-lane kernel shape, no empty problem) the whole loop is one launch -- see
-  // ea_lm_persistent_kernel.  Measured on MI355X it is on par with the launch pairs below (a message hop between
-  // XCDs costs about as much as a kernel boundary), so it is not the default.
-  b->last_solve_persistent = 0;
-  if (b->t_persistent > 0 && o.strategy == EA_STRATEGY_LM && b->nt == 256 && b->min_group_rows >= 1 &&
-      b->max_group_rows <= 256 /* kFoldMaxRows */ && !b->lds_bytes) {
-    if (b->persistent_capacity < 0) {
-      int per_cu = 0, cus = 0;
-      HIPCHK(persistent_blocks_per_cu(b->dtype, b->ppt, b->any_variant, &per_cu));
-      HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device));
-      b->persistent_capacity = per_cu * cus;
-    }
-    const long long grid = (long long)(b->xcd_remap ? ((b->max_chunks + 7) / 8) * 8 : b->max_chunks) * b->nterms;
-    if (grid <= b->persistent_capacity) {
-      // pose #0 as a message; the abort word follows the messages
-      b->epoch += 1;
-      if (b->epoch == 0) b->epoch = 1;
-      const size_t words = (size_t)count * kPoseMsgWords;
-      for (int i = 0; i < count; ++i) {
-        unsigned long long *m = b->h_pose_msgs + (size_t)i * kPoseMsgWords;
-        const PoseState &ps = b->h_poses[i];
-        double payload[7 * kPoseMsgSegs] = {0};
-        for (int k = 0; k < 9; ++k) payload[k] = ps.R[k];
-        for (int k = 0; k < 3; ++k) payload[9 + k] = ps.t[k];
-        for (int k = 0; k < 27; ++k) payload[12 + k] = ps.G[k];
-        for (int sgm = 0; sgm < kPoseMsgSegs; ++sgm) {
-          for (int w = 0; w < 7; ++w) std::memcpy(&m[8 * sgm + w], &payload[7 * sgm + w], 8);
-          m[8 * sgm + 7] = msg_tag(b->epoch, 1u);
-        }
-        m[8 * (kPoseMsgFlags / 7) + kPoseMsgFlags % 7] = (unsigned long long)(1 | (ps.unit_q ? 2 : 0));
-      }
-      b->h_pose_msgs[words] = 0;  // abort word
-      HIPCHK(hipMemcpyAsync(b->d_pose_msgs, b->h_pose_msgs, (words + 1) * sizeof(unsigned long long),
-                            hipMemcpyHostToDevice, b->stream));
-      int *d_abort = reinterpret_cast<int *>(b->d_pose_msgs + words);
-      HIPCHK(launch_lm_persistent(b->dtype, b->ppt, b->any_variant, b->d_probs, b->d_groups, b->nterms, b->chunk,
-                                  b->max_chunks, b->xcd_remap, b->d_pose_msgs, b->d_row_msgs, b->d_states,
-                                  b->d_traces, lo, b->epoch, d_abort, b->terms_are_groups, b->stream));
-      HIPCHK(hipMemcpyAsync(&b->h_progress[0], d_abort, sizeof(int), hipMemcpyDeviceToHost, b->stream));
-      b->last_solve_persistent = 1;
-    }
-  }
   // The loop runs on the device: each (evaluate, LM step) pair reads the pose the previous step
   // published.  The step kernel reports progress into pinned host memory; the host only keeps a few
   // pairs queued ahead of it and stops enqueueing when every problem has terminated (pairs that are
@@ -747,7 +678,7 @@ extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, 
   const int budget = o.max_num_iterations + 2;  // every pair consumes at least one iteration
   int enq = 0;
   unsigned spins = 0;
-  while (!b->last_solve_persistent) {
+  for (;;) {
     bool any = false;
     int done = 0;
     for (int i = 0; i < count; ++i) {
@@ -775,11 +706,6 @@ extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, 
   if (summaries || o.minimizer_progress_to_stdout)
     HIPCHK(hipMemcpyAsync(b->h_traces, b->d_traces, count * sizeof(LMTrace), hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
-  if (b->last_solve_persistent && b->h_progress[0] != 0)
-    return fail(EA_ERR_HIP, "persistent solve aborted: a workgroup exceeded its wait bound");
-  if (b->last_solve_persistent)
-    for (int i = 0; i < count; ++i)
-      if (b->h_states[i].running) return fail(EA_ERR_HIP, "persistent solve ended with a problem still running");
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   for (int i = 0; i < count; ++i) {
     const LMState &s = b->h_states[i];
@@ -860,7 +786,6 @@ extern "C" int ea_batch_set_tuning(ea_batch *b, const char *key, int value) {
   else if (k == "use_lds") b->t_use_lds = value;
   else if (k == "xcd_remap") b->t_xcd = value;
   else if (k == "threads") b->t_nt = value;
-  else if (k == "persistent") b->t_persistent = value;
   else return fail(EA_ERR_INVALID_ARG, "unknown tuning key: " + k);
   b->built = false;
   return EA_OK;
@@ -875,7 +800,6 @@ extern "C" int ea_batch_get_info(const ea_batch *b, const char *key, int64_t *va
   else if (k == "xcd_remap") *value = b->xcd_remap;
   else if (k == "chunk") *value = b->chunk;
   else if (k == "threads") *value = b->nt;
-  else if (k == "last_solve_persistent") *value = b->last_solve_persistent;
   else if (k == "num_points") { int64_t s = 0; for (auto *p : b->probs) s += p->n; *value = s; }
   else return fail(EA_ERR_INVALID_ARG, "unknown info key: " + k);
   return EA_OK;

@@ -996,264 +996,6 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_step_kernel(
   EA_LM_STAMP(5, ev_);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Persistent solve: the whole trust-region loop of every problem in ONE launch.
-//
-// Grid as for ea_eval_fused_kernel, every workgroup resident at once (the host checks the grid against the
-// device's capacity).  A workgroup loads its points once and keeps them in registers; per LM iteration it
-//   1. polls its group's pose message until every segment carries this iteration's tag,
-//   2. evaluates its chunk (fused_chunk, the same code as the one-shot kernel),
-//   3. stores its partial row as a tagged row message.
-// The group's last workgroup is also its solver: after its own row it polls all row messages of the group (the
-// poll that finds every tag valid *is* the load of the fold), runs the state machine of ea_lm.h on lane 0 with
-// the solver state resident in LDS for the whole solve, and stores the next pose message.
-// No kernel boundary, no descriptor / point reloads, no atomics, no fences: per iteration two message hops.
-// Messages travel through agent-scope (L2-bypassing) accesses; a 64-byte segment is written by one store
-// instruction and validated by its own tag (ea_types.h).  Every poll loop is bounded (kMaxSpins, then the launch
-// aborts through `abort_flag` and the host reports it); a finished group's pose message says active = 0 and its
-// workgroups leave.
-constexpr unsigned kMaxSpins = 1u << 19;
-constexpr int kPersistThreads = 256;
-
-__device__ __forceinline__ unsigned long long msg_load(const unsigned long long *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void msg_store(unsigned long long *p, unsigned long long v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Fold of a group's tagged row messages.  The messages of a group are contiguous, so lane t reads words
-// t, t + NT, t + 2 NT, ... of the run: every load instruction covers 512 contiguous bytes (agent-scope loads are
-// not cached, 8-byte gathers would cost one memory request each).  NT = 256 = 6 * 40 + 16, so a lane's k-th word
-// sits at position (t + 16 k) mod 40 of its row: five positions per lane, one accumulator each, summed in k
-// order; the 32 lane-partials of every position are then added in a fixed order.  Tag words are compared with
-// `tag`.  Returns (uniformly) whether every tag matched; `out` (the 32 slots) is only meaningful then.
-constexpr int kFoldMaxRows = 256;  // capacity of the persistent launch: one workgroup per row
-template <int NT>
-__device__ __forceinline__ bool fold_row_msgs(const unsigned long long *msgs, int tile_begin, int tile_end,
-                                              unsigned long long tag, double *s_fold /* 5 x NT */, double *out) {
-  static_assert(NT == 256 && kRowMsgWords == 40, "lane/word arithmetic below");
-  constexpr int K = kFoldMaxRows * kRowMsgWords / NT;  // 40 words per lane at most
-  const int tid = threadIdx.x;
-  const unsigned long long *run = msgs + (size_t)tile_begin * kRowMsgWords;
-  const int words = (tile_end - tile_begin) * kRowMsgWords;
-  const int r0 = tid % kRowMsgWords;
-  double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  bool ok = true;
-  // rounds of 8 loads in flight per lane; rounds past the end of the run are skipped (uniform)
-#pragma unroll
-  for (int k0 = 0; k0 < K; k0 += 8) {
-    if (k0 * NT >= words) break;
-    unsigned long long v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = msg_load(run + min(tid + (k0 + i) * NT, words - 1));
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int k = k0 + i;
-      const bool in = tid + k * NT < words;
-      const int wr = (r0 + 16 * k) % kRowMsgWords;
-      const bool is_tag = (wr & 7) == 7;
-      ok = ok && (!in || !is_tag || v[i] == tag);
-      a[k % 5] += (in && !is_tag) ? __builtin_bit_cast(double, v[i]) : 0.0;
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 5; ++j) s_fold[j * NT + tid] = a[j];
-  const bool all_ok = __syncthreads_and(ok) != 0;
-  if (tid < kRowMsgWords && (tid & 7) != 7) {
-    // position tid of the row: lane t holds it in accumulator j when (t + 16 j) mod 40 == tid
-    double tot = 0.0;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const int r = (tid + kRowMsgWords * 2 - 16 * j) % kRowMsgWords;
-      for (int t = r; t < NT; t += kRowMsgWords) tot += s_fold[j * NT + t];
-    }
-    const int slot = 7 * (tid >> 3) + (tid & 7);
-    if (slot < kAccSlots) out[slot] = tot;
-  }
-  return all_ok;
-}
-
-template <typename T, int PPT, bool VAR>
-__global__ __launch_bounds__(kPersistThreads) void ea_lm_persistent_kernel(
-    const ProblemDesc *__restrict__ probs, const GroupDesc *__restrict__ groups, unsigned long long *pose_msgs,
-    unsigned long long *row_msgs, LMState *states, LMTrace *traces, LMOptions opt, unsigned epoch,
-    int *abort_flag, int chunk, int chunks_per_xcd, int xcd_remap, int terms_are_groups) {
-  constexpr int NT = kPersistThreads;
-  __shared__ double s_red[(NT / 64) * kAccSlots];
-  __shared__ double s_fold[5 * NT];
-  __shared__ double s_acc[kAccSlots];
-  __shared__ PoseState s_pose;  // the pose being evaluated
-  __shared__ PoseState s_next;  // the pose the state machine produced
-  __shared__ LMState s_st;      // solver state: lives here for the whole solve (solver workgroup only)
-  __shared__ LMCold s_cold;
-  __shared__ LMPending s_pend;
-  __shared__ int s_ctrl;
-  constexpr int kStateWords = (int)(sizeof(LMState) / 8);
-  static_assert(sizeof(LMState) % 8 == 0 && kStateWords <= NT, "one 8-byte state word per lane");
-  static_assert(kPoseMsgWords <= 64 && kRowMsgWords <= 64, "one message word per lane of wave 0");
-  static_assert(7 * kRowMsgSegs >= kAccInvalid + 1 && 7 * kPoseMsgSegs > kPoseMsgFlags, "message payload");
-
-  const int bx = blockIdx.x;
-  const int c = xcd_remap ? (bx & 7) * chunks_per_xcd + (bx >> 3) : bx;
-  const ProblemDesc pd = probs[blockIdx.y];
-  const int g = terms_are_groups ? (int)blockIdx.y : pd.group;
-  const long long start = (long long)c * chunk;
-  if (start >= pd.n) return;
-  const int count = min(chunk, (int)(pd.n - start));
-  const GroupDesc gd = groups[g];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int my_row = pd.tile_begin + c;
-  const bool solver = my_row == gd.tile_end - 1;  // uniform: the group's last workgroup also runs the state machine
-
-  T X[PPT], Y[PPT], Z[PPT];
-  {
-    const GPtr<T> px = (GPtr<T>)(static_cast<const T *>(pd.x) + start);
-    const GPtr<T> py = (GPtr<T>)(static_cast<const T *>(pd.y) + start);
-    const GPtr<T> pz = (GPtr<T>)(static_cast<const T *>(pd.z) + start);
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-      const int jj = min(tid + k * NT, count - 1);
-      X[k] = px[jj]; Y[k] = py[jj]; Z[k] = pz[jj];
-    }
-  }
-  if (solver && tid < kStateWords) reinterpret_cast<double *>(&s_st)[tid] = reinterpret_cast<const double *>(states + g)[tid];
-  const unsigned long long *pose_msg = pose_msgs + (size_t)g * kPoseMsgWords;
-  unsigned long long *row_msg = row_msgs + (size_t)my_row * kRowMsgWords;
-  const unsigned max_it = (unsigned)opt.max_num_iterations + 8u;  // the state machine stops earlier by itself
-  // message lane roles of wave 0: lane l <-> word l = 8 seg + w; w == 7 is the tag word
-  const int m_w = lane & 7, m_p = 7 * (lane >> 3) + m_w;  // payload index of this lane's word
-  const int row_slot = (wave == 0 && lane < kRowMsgWords && m_w < 7 && m_p < kAccSlots) ? m_p : -1;
-
-#ifdef EA_STAMPS
-#define EA_PSTAMP(area, slot)                                                                        \
-  do {                                                                                               \
-    if (g_lm_stamp_buf && tid == 0 && ((area) == 1 ? solver : (blockIdx.x == 0 && blockIdx.y == 0))) { \
-      unsigned long long t_;                                                                         \
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                     \
-      g_lm_stamp_buf[(area) * 64 * 8 + (it & 63) * 8 + (slot)] = t_;                                 \
-    }                                                                                                \
-  } while (0)
-#else
-#define EA_PSTAMP(area, slot) do {} while (0)
-#endif
-  for (unsigned it = 0;; ++it) {
-    EA_PSTAMP(0, 0);
-    const unsigned long long tag = msg_tag(epoch, it + 1u);
-    // ---- 1. pose #it: poll until all six segments carry the tag, then unpack into LDS (+ float mirrors)
-    if (wave == 0) {
-      int ctrl = it > max_it ? 2 : 0;
-      unsigned spins = 0;
-      unsigned long long word = 0;
-      while (ctrl == 0) {
-        word = lane < kPoseMsgWords ? msg_load(pose_msg + lane) : tag;
-        const bool bad = lane < kPoseMsgWords && m_w == 7 && word != tag;
-        if (__ballot(bad) == 0) break;
-        ++spins;
-        if (spins > kMaxSpins) ctrl = 2;
-        else if ((spins & 63u) == 0 &&
-                 __builtin_amdgcn_readfirstlane(__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
-          ctrl = 2;
-        else __builtin_amdgcn_s_sleep(2);
-      }
-      if (ctrl == 0) {
-        if (lane < kPoseMsgWords && m_w < 7) {
-          const double v = __builtin_bit_cast(double, word);
-          if (m_p < 9) { s_pose.R[m_p] = v; s_pose.Rf[m_p] = (float)v; }
-          else if (m_p < 12) { s_pose.t[m_p - 9] = v; s_pose.tf[m_p - 9] = (float)v; }
-          else if (m_p < 39) { s_pose.G[m_p - 12] = v; s_pose.Gf[m_p - 12] = (float)v; }
-          else if (m_p == kPoseMsgFlags) { s_pose.active = (int)(word & 1u); s_pose.unit_q = (int)((word >> 1) & 1u); }
-        }
-      } else if (lane == 0) {
-        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if (lane == 0) s_ctrl = ctrl;
-    }
-    __syncthreads();
-    if (s_ctrl != 0 || !s_pose.active) break;  // uniform: aborted, or this group's solve has finished
-    EA_PSTAMP(0, 1);  // pose arrived
-
-    // ---- 2. evaluate; 3. row message (wave 0, one store instruction)
-    const double sum = fused_chunk<T, PPT, 0, NT, VAR>(pd, s_pose, X, Y, Z, count, s_red, nullptr, nullptr, 0, row_slot);
-    EA_PSTAMP(0, 2);  // evaluated
-    if (wave == 0 && lane < kRowMsgWords)
-      msg_store(row_msg + lane, m_w == 7 ? tag : __builtin_bit_cast(unsigned long long, sum));
-    EA_PSTAMP(0, 3);  // row sent
-    if (!solver) continue;  // uniform
-
-    // ---- solver workgroup: fold (poll) + state machine + next pose message
-    EA_PSTAMP(1, 0);
-    {
-      unsigned spins = 0;
-      int ctrl = 0;
-      for (;;) {
-        // (opaque copies keep the row addresses of the fold from being hoisted out of the iteration loop)
-        const unsigned long long *src = row_msgs;
-        int fold_begin = gd.tile_begin, fold_end = gd.tile_end;
-        asm volatile("" : "+s"(src), "+s"(fold_begin), "+s"(fold_end));
-        if (fold_row_msgs<NT>(src, fold_begin, fold_end, tag, s_fold, s_acc)) break;
-        ++spins;
-        if (spins > kMaxSpins ||
-            ((spins & 63u) == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-          ctrl = 2;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      if (ctrl != 0) {  // uniform
-        if (tid == 0) __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-    }
-    __syncthreads();
-    EA_PSTAMP(1, 1);  // folded
-    if (tid == 0) {
-      LMState st = s_st;
-      LMPending pend;
-      double acc[kAccSlots];
-#pragma unroll
-      for (int i = 0; i < kAccSlots; ++i) acc[i] = s_acc[i];
-      if (st.num_evals == 0) lm_begin<0>(&st, &s_cold, traces + g, &opt, acc, &pend);
-      else lm_advance<0>(&st, &s_cold, traces + g, &opt, acc, &pend);
-      make_pose_core(st.cand, st.rot_transposed, st.running, &s_next, /*zero_unused_G=*/false);
-      s_st = st;
-      s_pend = pend;
-    }
-    __syncthreads();
-    EA_PSTAMP(1, 2);  // state machine done
-    if (wave == 0 && lane < kPoseMsgWords) {
-      unsigned long long w = msg_tag(epoch, it + 2u);
-      if (m_w < 7) {
-        const bool skip_g = s_next.unit_q != 0;
-        double v = 0.0;
-        if (m_p < 9) v = s_next.R[m_p];
-        else if (m_p < 12) v = s_next.t[m_p - 9];
-        else if (m_p < 39) v = skip_g ? 0.0 : s_next.G[m_p - 12];
-        w = __builtin_bit_cast(unsigned long long, v);
-        if (m_p >= 39) w = m_p == kPoseMsgFlags ? (unsigned long long)((s_next.active ? 1 : 0) | (s_next.unit_q ? 2 : 0)) : 0ull;
-      }
-      msg_store(pose_msgs + (size_t)g * kPoseMsgWords + lane, w);
-    }
-    EA_PSTAMP(1, 3);  // pose sent
-    if (tid == 0) {
-      // cold state stays in LDS; only the trace row goes to memory
-      LMPending pend = s_pend;
-      pend.store_system = 0;
-      if (s_pend.store_system) {
-#pragma unroll
-        for (int k = 0; k < 21; ++k) s_cold.A[k] = s_acc[kAccJtJ + k];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) s_cold.g[a] = s_acc[kAccJtr + a];
-      }
-      lm_flush(&pend, &s_cold, traces + g, s_acc);
-    }
-    __syncthreads();
-  }
-  // the solver hands the final state back (also after an abort: the host then reports the failure)
-  if (solver && tid < kStateWords)
-    reinterpret_cast<double *>(states + g)[tid] = reinterpret_cast<const double *>(&s_st)[tid];
-}
-
 // pad + convert a row-major [H][W] device image into the replicated-border layout
 template <typename T>
 __global__ void ea_pad_image_kernel(const T *__restrict__ src, int H, int W, T *__restrict__ dst, int pitch) {
@@ -1332,37 +1074,6 @@ hipError_t launch_lm_step(const GroupDesc *groups, int count, const double *part
   else
     hipLaunchKernelGGL(ea_lm_step_kernel<1>, dim3(count), dim3(kLmThreads), 0, stream, groups, partials, poses,
                        states, cold, traces, opt, progress);
-  return hipGetLastError();
-}
-
-// occupancy-limited capacity (workgroups resident at once per CU) of the persistent kernel
-hipError_t persistent_blocks_per_cu(int dtype, int ppt, int variant, int *blocks) {
-  const void *fn = nullptr;
-#define EA_PK(T, P, V) fn = reinterpret_cast<const void *>(&ea_lm_persistent_kernel<T, P, V>)
-  if (variant) { if (dtype == 1) { if (ppt == 1) EA_PK(float, 1, true); else EA_PK(float, 2, true); }
-                 else { if (ppt == 1) EA_PK(double, 1, true); else EA_PK(double, 2, true); } }
-  else if (dtype == 1) { if (ppt == 1) EA_PK(float, 1, false); else if (ppt == 2) EA_PK(float, 2, false); else EA_PK(float, 4, false); }
-  else { if (ppt == 1) EA_PK(double, 1, false); else EA_PK(double, 2, false); }
-#undef EA_PK
-  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, fn, kPersistThreads, 0);
-}
-
-hipError_t launch_lm_persistent(int dtype, int ppt, int variant, const ProblemDesc *probs, const GroupDesc *groups,
-                                int nterms, int chunk, int max_chunks, int xcd_remap, unsigned long long *pose_msgs,
-                                unsigned long long *row_msgs, LMState *states, LMTrace *traces, const LMOptions &opt,
-                                unsigned epoch, int *abort_flag, int terms_are_groups, hipStream_t stream) {
-  if (nterms <= 0 || max_chunks <= 0) return hipSuccess;
-  const int chunks_per_xcd = (max_chunks + 7) / 8;
-  const dim3 grid(xcd_remap ? chunks_per_xcd * 8 : max_chunks, nterms);
-#define EA_LAUNCH_P(T, P, V)                                                                                  \
-  hipLaunchKernelGGL((ea_lm_persistent_kernel<T, P, V>), grid, dim3(kPersistThreads), 0, stream, probs, groups, \
-                     pose_msgs, row_msgs, states, traces, opt, epoch, abort_flag, chunk, chunks_per_xcd,        \
-                     xcd_remap, terms_are_groups)
-  if (variant) { if (dtype == 1) { if (ppt == 1) EA_LAUNCH_P(float, 1, true); else EA_LAUNCH_P(float, 2, true); }
-                 else { if (ppt == 1) EA_LAUNCH_P(double, 1, true); else EA_LAUNCH_P(double, 2, true); } }
-  else if (dtype == 1) { if (ppt == 1) EA_LAUNCH_P(float, 1, false); else if (ppt == 2) EA_LAUNCH_P(float, 2, false); else EA_LAUNCH_P(float, 4, false); }
-  else { if (ppt == 1) EA_LAUNCH_P(double, 1, false); else EA_LAUNCH_P(double, 2, false); }
-#undef EA_LAUNCH_P
   return hipGetLastError();
 }
 

@@ -70,17 +70,6 @@ struct PoseState {
   int32_t pad_[2];
 };
 
-// Persistent solve: workgroups talk through tagged messages.  A message is a run of 64-byte segments, each
-// 7 payload words + 1 tag word written by one store instruction; the tag names the solve (epoch) and the
-// iteration, so a reader that polls a message knows segment by segment whether it holds this iteration's data --
-// no counters, no fences.  Row message: 29 accumulator slots in 5 segments; pose message: R, t, G, flags in 6.
-constexpr int kRowMsgSegs = 5, kRowMsgWords = 8 * kRowMsgSegs;     // slot s -> word 8 (s / 7) + s % 7
-constexpr int kPoseMsgSegs = 6, kPoseMsgWords = 8 * kPoseMsgSegs;  // payload: R[9] t[3] G[27] flags
-constexpr int kPoseMsgFlags = 39;                                  // payload index of (active | unit_q << 1)
-EA_HD inline unsigned long long msg_tag(unsigned epoch, unsigned seq) {
-  return ((unsigned long long)epoch << 32) | (unsigned long long)seq;
-}
-
 // Result of one reduced evaluation
 struct EvalOut {
   double acc[kAccSlots];

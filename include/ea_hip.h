@@ -204,10 +204,8 @@ int ea_batch_solve(ea_batch *b, const ea_options *opt, double *q, double *t,
  * dominant per-point kernel alone (events around each launch in a second pass). */
 int ea_batch_bench_eval(ea_batch *b, const double *q, const double *t, int warmup, int steps,
                         double *ms_total, double *ms_eval_kernel);
-/* tuning knobs: key in {"lds_bytes", "points_per_thread", "use_lds", "xcd_remap", "threads", "persistent"};
- * value < 0 restores the default.  "persistent" = 1 lets ea_batch_solve run the whole trust-region loop in one
- * launch when every workgroup of the batch is resident at once (default 0: one evaluate + one step launch per
- * iteration); the info key "last_solve_persistent" tells which path the last solve took. */
+/* tuning knobs: key in {"lds_bytes", "points_per_thread", "use_lds", "xcd_remap", "threads"};
+ * value < 0 restores the default */
 int ea_batch_set_tuning(ea_batch *b, const char *key, int value);
 int ea_batch_get_info(const ea_batch *b, const char *key, int64_t *value);
 

@@ -31,7 +31,7 @@ run('c5 f32', synth.config_c5(), capi.EA_F32, (capi.LOSS_TRIVIAL, 1.0))
 
 def run_lm(name, cfg):
     P = capi.Problem(*cfg['K'], dtype=capi.EA_F64); P.set_points(cfg['xyz']); P.set_dt_grid(cfg['grid']); P.set_loss(capi.LOSS_CAUCHY, 1.0)
-    B = capi.Batch([P]); B.set_tuning('persistent', 0)
+    B = capi.Batch([P])
     q, t, summ = B.solve(q0, t0)   # warm
     assert L.ea_debug_lm_stamps_begin() == 0
     q, t, summ = B.solve(q0, t0)
@@ -52,28 +52,3 @@ def run_lm(name, cfg):
     print('   total median %.0f; eval-to-eval period median %.0f' % (np.median(st[:, 5] - st[:, 0]), np.median(np.diff(np.sort(st[:, 0])))))
     P.close()
 run_lm('lm1e5 f64', synth.config_c2_twin(seed=7, n_points=100000))
-
-def run_persistent(name, cfg):
-    P = capi.Problem(*cfg['K'], dtype=capi.EA_F64); P.set_points(cfg['xyz']); P.set_dt_grid(cfg['grid']); P.set_loss(capi.LOSS_CAUCHY, 1.0)
-    B = capi.Batch([P]); B.set_tuning('persistent', 1)
-    B.solve(q0, t0)
-    assert L.ea_debug_lm_stamps_begin() == 0
-    q, t, summ = B.solve(q0, t0)
-    st = np.zeros((128, 8), dtype=np.uint64)
-    assert L.ea_debug_lm_stamps_end(st.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
-    assert B.info('last_solve_persistent') == 1
-    st = st.astype(np.int64); wg = st[:64]; ld = st[64:]
-    n = summ[0]['num_iterations']
-    wg = wg[:n]; ld = ld[:n]
-    d = np.diff(wg[:, :4], axis=1)
-    print('%s persistent solve, %d iterations; workgroup (0,0), ticks median / max:' % (name, n))
-    for i, nm in enumerate(['wait for pose', 'evaluate', 'row message']):
-        print('   %-20s %7.0f %7.0f' % (nm, np.median(d[:, i]), d[:, i].max()))
-    print('   iteration period     %7.0f' % np.median(np.diff(wg[:, 0])))
-    d = np.diff(ld[:, :4], axis=1)
-    print(' solver workgroup:')
-    for i, nm in enumerate(['poll + fold rows', 'state machine', 'pose message']):
-        print('   %-20s %7.0f %7.0f' % (nm, np.median(d[:, i]), d[:, i].max()))
-    B.close(); P.close()
-run_persistent('lm1e5 f64', synth.config_c2_twin(seed=7, n_points=100000))
-run_persistent('lm3000 f64', synth.config_c2_twin(seed=7, n_points=3000))

@@ -404,54 +404,3 @@ def test_wave_reduce_primitives(hip):
     lanes = np.arange(64)
     a = np.array([np.where(lanes & 8, V[i + 16] + V[i + 16][lanes ^ 15], V[i] + V[i][lanes ^ 15]) for i in range(16)])
     assert np.array_equal(stages[:16], a)
-
-
-@pytest.mark.gpu
-def test_persistent_solve_matches_launch_pairs(hip):
-    """ea_batch_set_tuning("persistent", 1): the one-launch solve (tagged messages between workgroups, solver state
-    resident in LDS) must take the same decisions and land on the same pose as the per-iteration launch pairs;
-    only the order of the cross-workgroup fold differs (1e-12)."""
-    capi = hip
-    q0 = np.array([1.0, 0, 0, 0]); t0 = np.zeros(3)
-    cases = [(100000, capi.EA_F64, capi.LOSS_CAUCHY), (30000, capi.EA_F32, capi.LOSS_HUBER), (700, capi.EA_F64, capi.LOSS_TRIVIAL)]
-    for n, dtype, loss in cases:
-        cfg = synth.config_c2_twin(seed=21, n_points=n)
-        P = capi.Problem(*cfg["K"], dtype=dtype)
-        P.set_points(cfg["xyz"]); P.set_dt_grid(cfg["grid"]); P.set_loss(loss, 0.7)
-        res = []
-        for mode in (0, 1):
-            B = capi.Batch([P]); B.set_tuning("persistent", mode)
-            q, t, s = B.solve(q0, t0)
-            assert B.info("last_solve_persistent") == mode
-            res.append((q, t, s[0]))
-            # a second solve on the same batch reuses the message buffers under a new epoch
-            q2, t2, s2 = B.solve(q0, t0)
-            assert np.array_equal(q, q2) and np.array_equal(t, t2)
-            B.close()
-        (qa, ta, sa), (qb, tb, sb) = res
-        tol = 1e-12 if dtype == capi.EA_F64 else 1e-6
-        assert sa["num_iterations"] == sb["num_iterations"] and sa["why"] == sb["why"]
-        assert np.abs(qa - qb).max() < tol and np.abs(ta - tb).max() < tol
-        assert np.allclose(sa["it_cost"], sb["it_cost"], rtol=max(tol, 1e-12))
-        P.close()
-    # a batch small enough to be resident at once, uneven problems, dogleg falls back to the launch pairs
-    Ps = []
-    for i, n in enumerate((6000, 900, 2500)):
-        cfg = synth.config_c2_twin(seed=30 + i, n_points=n)
-        P = capi.Problem(*cfg["K"], dtype=capi.EA_F64)
-        P.set_points(cfg["xyz"]); P.set_dt_grid(cfg["grid"]); P.set_loss(capi.LOSS_CAUCHY, 1.0)
-        Ps.append(P)
-    out = []
-    for mode in (0, 1):
-        B = capi.Batch(Ps); B.set_tuning("persistent", mode)
-        q, t, s = B.solve(np.tile(q0, (3, 1)), np.tile(t0, (3, 1)))
-        assert B.info("last_solve_persistent") == mode
-        out.append((q, t, [x["num_iterations"] for x in s]))
-        if mode == 1:
-            B.solve(np.tile(q0, (3, 1)), np.tile(t0, (3, 1)), strategy=capi.STRATEGY_DOGLEG)
-            assert B.info("last_solve_persistent") == 0
-        B.close()
-    assert out[0][2] == out[1][2]
-    assert np.abs(out[0][0] - out[1][0]).max() < 1e-12 and np.abs(out[0][1] - out[1][1]).max() < 1e-12
-    for P in Ps:
-        P.close()
