@@ -24,7 +24,7 @@ def build_library(force=False, verbose=False):
             and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps)):
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function", "-o", LIB] + srcs
     if verbose:
         print(" ".join(cmd))

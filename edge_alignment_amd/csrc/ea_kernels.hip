@@ -270,6 +270,9 @@ __device__ __forceinline__ void jacobian_row_var(const ProblemDesc &pd, const Po
     J[1] = T(2) * t_fma<T>(pr.cz_, gx, -(pr.cx_ * gz));
     J[2] = T(2) * t_fma<T>(pr.cx_, gy, -(pr.cy_ * gx));
   } else {
+    // (the empty asm keeps this uniform branch a branch: left alone, the compiler computes the 30 extra FMAs of the
+    // general path for every point and selects afterwards)
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const T *G = Uni<T>::G(ps) + 9 * j;
@@ -342,6 +345,9 @@ __device__ __forceinline__ void jacobian_row(const ProblemDesc &pd, const PoseSt
     J[1] = T(2) * t_fma<T>(pr.cz_, gx, -(pr.cx_ * gz));
     J[2] = T(2) * t_fma<T>(pr.cx_, gy, -(pr.cy_ * gx));
   } else {
+    // (the empty asm keeps this uniform branch a branch: left alone, the compiler computes the 30 extra FMAs of the
+    // general path for every point and selects afterwards)
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const T *G = Uni<T>::G(ps) + 9 * j;

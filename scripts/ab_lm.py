@@ -27,6 +27,14 @@ P5 = capi.Problem(*c5['K'], dtype=capi.EA_F32); P5.set_points(c5['xyz']); P5.set
 B5 = capi.Batch([P5])
 ms = min(B5.bench_eval(q0, t0, 20, 200, kernel_pass=False)[0] for _ in range(3))
 out['c5_step_us'] = ms / 200 * 1e3
+Ps = []
+for i in range(32):
+    cb = synth.config_c2_twin(seed=100 + i)
+    Pb = capi.Problem(*cb['K'], dtype=capi.EA_F32); Pb.set_points(cb['xyz']); Pb.set_dt_grid(cb['grid']); Pb.set_loss(capi.LOSS_CAUCHY, 1.0)
+    Ps.append(Pb)
+Bb = capi.Batch(Ps)
+ms = min(Bb.bench_eval(np.tile(q0, (32, 1)), np.tile(t0, (32, 1)), 10, 100, kernel_pass=False)[0] for _ in range(3))
+out['batch32_f32_step_us'] = ms / 100 * 1e3
 print(json.dumps(out))
 '''
 libs = sys.argv[1:3]

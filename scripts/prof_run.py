@@ -1,6 +1,6 @@
 """Workload for rocprofv3 runs: a few fused evaluations + LM solves on C2, LM-1e5 and C5."""
 import sys, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from edge_alignment_amd import capi, synth
 q0 = np.array([1.,0,0,0]); t0 = np.zeros(3)
 which = sys.argv[1] if len(sys.argv) > 1 else 'all'
@@ -20,3 +20,15 @@ if which in ('all', 'lm'):
     run(synth.config_c2_twin(seed=7, n_points=100000), capi.EA_F64, (capi.LOSS_CAUCHY, 1.0), 50)
 if which in ('all', 'c5'):
     run(synth.config_c5(), capi.EA_F32, (capi.LOSS_TRIVIAL, 1.0), 50)
+if which in ('batch32f32', 'batch32f64'):
+    dtype = capi.EA_F32 if which.endswith('f32') else capi.EA_F64
+    Ps = []
+    for i in range(32):
+        cfg = synth.config_c2_twin(seed=100 + i)
+        P = capi.Problem(*cfg['K'], dtype=dtype); P.set_points(cfg['xyz']); P.set_dt_grid(cfg['grid']); P.set_loss(capi.LOSS_CAUCHY, 1.0)
+        Ps.append(P)
+    B = capi.Batch(Ps)
+    for kv in sys.argv[2:]:
+        k, v = kv.split('='); B.set_tuning(k, int(v))
+    ms, _ = B.bench_eval(np.tile(q0, (32, 1)), np.tile(t0, (32, 1)), 5, 30, kernel_pass=False)
+    print('ms/step', ms / 30, 'tiles', B.info('num_tiles'), 'ppt', B.info('points_per_thread'), 'threads', B.info('threads'))
