@@ -30,6 +30,7 @@ EXPORTED = [
     "ea_batch_create", "ea_batch_destroy", "ea_batch_count", "ea_batch_eval", "ea_batch_solve",
     "ea_batch_bench_eval", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
     "ea_problem_set_ref_frame", "ea_problem_set_now_frame", "ea_problem_debug_now_frame",
+    "ea_problem_set_ref_frame_canny", "ea_problem_set_now_frame_canny", "ea_problem_debug_now_frame_canny",
     "ea_problem_get_points", "ea_problem_get_dt",
     "ea_problem_set_distortion", "ea_problem_set_second_camera", "ea_problem_add_term", "ea_problem_clear_terms",
 ]
@@ -117,6 +118,10 @@ def load():
     u8p, u16p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint16)
     L.ea_problem_set_ref_frame.argtypes = [vp, u8p, u16p, C.c_int, C.c_int, C.c_double, C.c_int]
     L.ea_problem_set_now_frame.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.ea_problem_set_ref_frame_canny.argtypes = [vp, u8p, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
+    L.ea_problem_set_now_frame_canny.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double]
+    L.ea_problem_debug_now_frame_canny.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double,
+                                                   C.c_double, u8p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.ea_problem_debug_now_frame.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u8p, u8p,
                                              C.POINTER(C.c_int32), C.POINTER(C.c_float)]
     L.ea_problem_get_points.argtypes = [vp, dp, C.c_int64]
@@ -239,6 +244,36 @@ class Problem:
                                                  lap.ctypes.data_as(u8), mask.ctypes.data_as(u8),
                                                  cham.ctypes.data_as(C.POINTER(C.c_int32)), dt.ctypes.data_as(C.POINTER(C.c_float))))
         return dict(lap=lap, mask=mask, chamfer=cham, dt=dt)
+
+    def set_ref_frame_canny(self, bgr, depth_u16, z_scaling=5000.0, low=30.0, high=90.0):
+        """get_aX_canny on the GPU (ref: utils.cpp:371-462)"""
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        depth_u16 = np.ascontiguousarray(depth_u16, dtype=np.uint16)
+        H, W = depth_u16.shape
+        assert bgr.shape == (H, W, 3)
+        _check(load().ea_problem_set_ref_frame_canny(self._h, bgr.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                     depth_u16.ctypes.data_as(C.POINTER(C.c_uint16)), H, W, z_scaling, low, high))
+
+    def set_now_frame_canny(self, bgr, mask=None, low=30.0, high=90.0, normalize=(0.0, 1.0), debug=False):
+        """get_distance_transform2[_masked][_NoNormalize] on the GPU (ref: utils.cpp:85-199); normalize: None or (lo, hi)"""
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        H, W = bgr.shape[:2]
+        u8 = C.POINTER(C.c_uint8)
+        mk = None
+        if mask is not None:
+            mk = np.ascontiguousarray(mask, dtype=np.uint8)
+            assert mk.shape == (H, W)
+        mp = mk.ctypes.data_as(u8) if mk is not None else None
+        do_norm, (lo, hi) = (0, (0.0, 1.0)) if normalize is None else (1, normalize)
+        if not debug:
+            _check(load().ea_problem_set_now_frame_canny(self._h, bgr.ctypes.data_as(u8), mp, H, W, low, high, do_norm, lo, hi))
+            return None
+        edges = np.zeros((H, W), np.uint8); cham = np.zeros((H, W), np.int32); dt = np.zeros((H, W), np.float32)
+        rounds = C.c_int()
+        _check(load().ea_problem_debug_now_frame_canny(self._h, bgr.ctypes.data_as(u8), mp, H, W, low, high, do_norm, lo, hi,
+                                                       edges.ctypes.data_as(u8), cham.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                       dt.ctypes.data_as(C.POINTER(C.c_float)), C.byref(rounds)))
+        return dict(edges=edges, chamfer=cham, dt=dt, hysteresis_launches=rounds.value)
 
     def get_points(self):
         n = self.num_points

@@ -34,8 +34,11 @@ hipError_t launch_edge_strength(const uint8_t *bgr, int H, int W, uint8_t *gray,
 hipError_t launch_threshold_median(const uint8_t *lap, int H, int W, int thr, int median, uint8_t *mask, hipStream_t s);
 hipError_t launch_chamfer(const uint8_t *mask, int H, int W, int *G, int *scratch, int *dist_fix, unsigned int *minmax,
                           hipStream_t s);
+hipError_t launch_canny(const uint8_t *bgr, int H, int W, int low, int high, const uint8_t *keep, uint8_t *gray, int *mag,
+                        uint8_t *dir, uint8_t *label, uint8_t *edges, uint8_t *inv, int *changed, int *rounds_out,
+                        hipStream_t s);
 hipError_t launch_dt_store(int dtype, const int *dist_fix, int H, int W, const unsigned int *minmax, int normalize,
-                           void *dst, int pitch, float *plain, hipStream_t s);
+                           double lo, double hi, void *dst, int pitch, float *plain, hipStream_t s);
 hipError_t launch_edge_count_scan(const uint8_t *lap, const uint16_t *depth, int H, int W, int thr, int *block_counts,
                                   int *total, hipStream_t s);
 hipError_t launch_edge_scatter(int dtype, const uint8_t *lap, const uint16_t *depth, int H, int W, int thr,
@@ -911,6 +914,7 @@ static int ensure_ws(ea_problem *p, size_t bytes) {
 static size_t frame_ws_bytes(int H, int W) {
   const size_t np = (size_t)H * W;
   return np * 3 + np * 2 + np * 3 /*gray, lap, mask*/ + np * 4 * 2 /*G, dist*/ + np * 4 /*plain float*/ +
+         np * 4 + np * 4 + np /*Canny: magnitudes, direction / label / edge / keep bytes, mask*/ + 16 * 256 +
          16 * (size_t)((H + 31) / 32 + 1) * W /*segment ends + carries*/ +
          ((np + 1023) / 1024 + 8) * 4 + 64 * 256;
 }
@@ -953,18 +957,15 @@ extern "C" int ea_problem_set_ref_frame(ea_problem *p, const uint8_t *bgr, const
   return EA_OK;
 }
 
-static int run_dt(ea_problem *p, WsCarver &ws, const uint8_t *d_bgr, int height, int width, int threshold, int median,
-                  int normalize, uint8_t **lap_out, uint8_t **mask_out, int **dist_out, float **plain_out) {
+// mask (0 = edge / DT source) -> chamfer DT -> [normalise to [lo, hi]] -> the problem's padded DT image
+static int dt_from_mask(ea_problem *p, WsCarver &ws, const uint8_t *d_mask, int height, int width, int normalize,
+                        double lo, double hi, int **dist_out, float **plain_out) {
   const size_t np = (size_t)height * width;
-  uint8_t *d_gray = ws.take<uint8_t>(np), *d_lap = ws.take<uint8_t>(np), *d_mask = ws.take<uint8_t>(np);
   int *d_G = ws.take<int>(np), *d_dist = ws.take<int>(np);
   int *d_scan = ws.take<int>(4 * (size_t)((height + 31) / 32) * width);
   float *d_plain = ws.take<float>(np);
   unsigned int *d_minmax = ws.take<unsigned int>(2);
-  HIPCHK(launch_edge_strength(d_bgr, height, width, d_gray, d_lap, nullptr));
-  HIPCHK(launch_threshold_median(d_lap, height, width, threshold, median, d_mask, nullptr));
   HIPCHK(launch_chamfer(d_mask, height, width, d_G, d_scan, d_dist, d_minmax, nullptr));
-  int rc = EA_OK;
   {
     if (p->d_dt) { (void)hipFree(p->d_dt); p->d_dt = nullptr; }
     p->W = width; p->H = height;
@@ -972,14 +973,135 @@ static int run_dt(ea_problem *p, WsCarver &ws, const uint8_t *d_bgr, int height,
     const size_t esz = p->dtype == EA_F32 ? 4 : 8;
     HIPCHK(hipMalloc(&p->d_dt, (size_t)p->pitch * (size_t)(height + 2 * kImagePad) * esz));
   }
-  HIPCHK(launch_dt_store(p->dtype, d_dist, height, width, d_minmax, normalize, p->d_dt, p->pitch, d_plain, nullptr));
+  HIPCHK(launch_dt_store(p->dtype, d_dist, height, width, d_minmax, normalize, lo, hi, p->d_dt, p->pitch, d_plain, nullptr));
   HIPCHK(hipDeviceSynchronize());
   p->version++;
-  if (lap_out) *lap_out = d_lap;
-  if (mask_out) *mask_out = d_mask;
   if (dist_out) *dist_out = d_dist;
   if (plain_out) *plain_out = d_plain;
-  return rc;
+  return EA_OK;
+}
+
+static int run_dt(ea_problem *p, WsCarver &ws, const uint8_t *d_bgr, int height, int width, int threshold, int median,
+                  int normalize, uint8_t **lap_out, uint8_t **mask_out, int **dist_out, float **plain_out) {
+  const size_t np = (size_t)height * width;
+  uint8_t *d_gray = ws.take<uint8_t>(np), *d_lap = ws.take<uint8_t>(np), *d_mask = ws.take<uint8_t>(np);
+  HIPCHK(launch_edge_strength(d_bgr, height, width, d_gray, d_lap, nullptr));
+  HIPCHK(launch_threshold_median(d_lap, height, width, threshold, median, d_mask, nullptr));
+  if (lap_out) *lap_out = d_lap;
+  if (mask_out) *mask_out = d_mask;
+  return dt_from_mask(p, ws, d_mask, height, width, normalize, 0.0, 1.0, dist_out, plain_out);
+}
+
+// blur 3x3 -> gray -> Canny(low, high) [-> AND (keep > 1)]: edge map and its inverse in the workspace
+static int run_canny(WsCarver &ws, const uint8_t *d_bgr, const uint8_t *d_keep, int height, int width, int low, int high,
+                     uint8_t **edges_out, uint8_t **inv_out, int *rounds_out) {
+  const size_t np = (size_t)height * width;
+  uint8_t *d_gray = ws.take<uint8_t>(np);
+  int *d_mag = ws.take<int>(np);
+  uint8_t *d_dir = ws.take<uint8_t>(np), *d_label = ws.take<uint8_t>(np);
+  uint8_t *d_edges = ws.take<uint8_t>(np), *d_inv = ws.take<uint8_t>(np);
+  int *d_changed = ws.take<int>(1);
+  HIPCHK(launch_canny(d_bgr, height, width, low, high, d_keep, d_gray, d_mag, d_dir, d_label, d_edges, d_inv, d_changed,
+                      rounds_out, nullptr));
+  *edges_out = d_edges;
+  *inv_out = d_inv;
+  return EA_OK;
+}
+
+static int check_frame_args(const ea_problem *p, const void *bgr, int height, int width) {
+  if (!p || !bgr) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  if (height < 3 || width < 3 || height > 32768 || width > 32768 || (int64_t)height * width > 0x3fffffff)
+    return fail(EA_ERR_INVALID_ARG, "image extent out of range");
+  return EA_OK;
+}
+
+// Canny flavour of the reference frame: get_aX_canny (ref: utils.cpp:371-462)
+extern "C" int ea_problem_set_ref_frame_canny(ea_problem *p, const uint8_t *bgr, const uint16_t *depth, int height,
+                                              int width, double z_scaling, double low_threshold, double high_threshold) {
+  int rc = check_frame_args(p, bgr, height, width);
+  if (rc != EA_OK) return rc;
+  if (!depth) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  if (!(z_scaling > 0.0)) return fail(EA_ERR_INVALID_ARG, "z_scaling must be > 0");
+  HIPCHK(hipSetDevice(p->device));
+  rc = ensure_ws(p, frame_ws_bytes(height, width));
+  if (rc != EA_OK) return rc;
+  const size_t np = (size_t)height * width;
+  WsCarver ws{p->ws};
+  uint8_t *d_bgr = ws.take<uint8_t>(np * 3);
+  uint16_t *d_depth = ws.take<uint16_t>(np);
+  const int nblocks = (int)((np + 1023) / 1024);
+  int *d_counts = ws.take<int>(nblocks + 1);
+  int *d_total = d_counts + nblocks;
+  HIPCHK(hipMemcpyAsync(d_bgr, bgr, np * 3, hipMemcpyHostToDevice, nullptr));
+  HIPCHK(hipMemcpyAsync(d_depth, depth, np * 2, hipMemcpyHostToDevice, nullptr));
+  const int lo = (int)std::floor(std::min(low_threshold, high_threshold)), hi = (int)std::floor(std::max(low_threshold, high_threshold));
+  uint8_t *d_edges, *d_inv;
+  rc = run_canny(ws, d_bgr, nullptr, height, width, lo, hi, &d_edges, &d_inv, nullptr);
+  if (rc != EA_OK) return rc;
+  // ref: utils.cpp:441 -- all_grad(i) > 0 && Z > 0 on the 0/255 edge map
+  HIPCHK(launch_edge_count_scan(d_edges, d_depth, height, width, 0, d_counts, d_total, nullptr));
+  int total = 0;
+  HIPCHK(hipMemcpy(&total, d_total, sizeof(int), hipMemcpyDeviceToHost));
+  free_points(p);
+  p->version++;
+  if (total > 0) {
+    const size_t esz = p->dtype == EA_F32 ? 4 : 8;
+    HIPCHK(hipMalloc(&p->d_x, (size_t)total * esz));
+    HIPCHK(hipMalloc(&p->d_y, (size_t)total * esz));
+    HIPCHK(hipMalloc(&p->d_z, (size_t)total * esz));
+    p->own_points = true;
+    HIPCHK(launch_edge_scatter(p->dtype, d_edges, d_depth, height, width, 0, d_counts, p->cam.fx, p->cam.fy, p->cam.cx,
+                               p->cam.cy, z_scaling, p->d_x, p->d_y, p->d_z, total, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+  }
+  p->n = total;
+  return EA_OK;
+}
+
+// Canny flavour of the current frame: get_distance_transform2 / _masked / _NoNormalize / _masked_NoNormalize
+// (ref: utils.cpp:85-199).  mask (nullable): H x W bytes, edges survive where mask > 1.  normalize != 0: min-max to
+// [norm_lo, norm_hi] ((0,1) at :103, (0,255) at :138).  The debug outputs may be NULL.
+static int now_frame_canny(ea_problem *p, const uint8_t *bgr, const uint8_t *mask, int height, int width, double low_threshold,
+                           double high_threshold, int normalize, double norm_lo, double norm_hi, uint8_t *edges_out,
+                           int32_t *chamfer_fix_out, float *dt_out, int *rounds_out) {
+  int rc = check_frame_args(p, bgr, height, width);
+  if (rc != EA_OK) return rc;
+  HIPCHK(hipSetDevice(p->device));
+  rc = ensure_ws(p, frame_ws_bytes(height, width));
+  if (rc != EA_OK) return rc;
+  const size_t np = (size_t)height * width;
+  WsCarver ws{p->ws};
+  uint8_t *d_bgr = ws.take<uint8_t>(np * 3);
+  uint8_t *d_keep = mask ? ws.take<uint8_t>(np) : nullptr;
+  HIPCHK(hipMemcpyAsync(d_bgr, bgr, np * 3, hipMemcpyHostToDevice, nullptr));
+  if (mask) HIPCHK(hipMemcpyAsync(d_keep, mask, np, hipMemcpyHostToDevice, nullptr));
+  const int lo = (int)std::floor(std::min(low_threshold, high_threshold)), hi = (int)std::floor(std::max(low_threshold, high_threshold));
+  uint8_t *d_edges, *d_inv;
+  rc = run_canny(ws, d_bgr, d_keep, height, width, lo, hi, &d_edges, &d_inv, rounds_out);
+  if (rc != EA_OK) return rc;
+  int *d_dist;
+  float *d_plain;
+  rc = dt_from_mask(p, ws, d_inv, height, width, normalize, norm_lo, norm_hi, &d_dist, &d_plain);
+  if (rc != EA_OK) return rc;
+  if (edges_out) HIPCHK(hipMemcpy(edges_out, d_edges, np, hipMemcpyDeviceToHost));
+  if (chamfer_fix_out) HIPCHK(hipMemcpy(chamfer_fix_out, d_dist, np * 4, hipMemcpyDeviceToHost));
+  if (dt_out) HIPCHK(hipMemcpy(dt_out, d_plain, np * 4, hipMemcpyDeviceToHost));
+  return EA_OK;
+}
+
+extern "C" int ea_problem_set_now_frame_canny(ea_problem *p, const uint8_t *bgr, const uint8_t *mask, int height, int width,
+                                              double low_threshold, double high_threshold, int normalize, double norm_lo,
+                                              double norm_hi) {
+  return now_frame_canny(p, bgr, mask, height, width, low_threshold, high_threshold, normalize, norm_lo, norm_hi, nullptr,
+                         nullptr, nullptr, nullptr);
+}
+
+extern "C" int ea_problem_debug_now_frame_canny(ea_problem *p, const uint8_t *bgr, const uint8_t *mask, int height,
+                                                int width, double low_threshold, double high_threshold, int normalize,
+                                                double norm_lo, double norm_hi, uint8_t *edges_out,
+                                                int32_t *chamfer_fix_out, float *dt_out, int *hysteresis_launches) {
+  return now_frame_canny(p, bgr, mask, height, width, low_threshold, high_threshold, normalize, norm_lo, norm_hi, edges_out,
+                         chamfer_fix_out, dt_out, hysteresis_launches);
 }
 
 extern "C" int ea_problem_set_now_frame(ea_problem *p, const uint8_t *bgr, int height, int width, int threshold,

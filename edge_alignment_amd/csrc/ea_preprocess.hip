@@ -1,6 +1,7 @@
 // ea_preprocess.hip — the producers either side of the hot path, on the GPU:
 //   edge-point extractor  = get_aX                  ref: standalone/utils.cpp:201-281
 //   DT image producer     = get_distance_transform  ref: standalone/utils.cpp:38-83
+//   Canny flavour         = get_distance_transform2* / get_aX_canny   ref: utils.cpp:85-199, :371-462
 // so that a frame pair goes from raw images to a solved pose without the CPU touching a pixel.
 //
 // All of it is 8/16/32-bit integer work plus one float scaling — bit-exact against
@@ -10,7 +11,12 @@
 //   Laplacian CV_16S ksize 3:        [[2,0,2],[0,-8,0],[2,0,2]], reflect-101; convertScaleAbs = min(|x|,255)
 //   medianBlur 3 on a {0,255} image: majority of the 3x3 window, replicate border
 //   distanceTransform(DIST_L2, 3):   3x3 chamfer, a = 0.955, b = 1.3693 in 16.16 fixed point
-//   normalize(NORM_MINMAX, 0, 1):    float32  src * scale + shift
+//   normalize(NORM_MINMAX, lo, hi):  float32  src * scale + shift
+//   blur 3x3 (8-bit):                (sum of nine + 4) / 9, reflect-101 border
+//   Canny(gray, t1, t2), aperture 3, L1 gradient: Sobel CV_16S with replicated border, |dx| + |dy|,
+//                                    non-maximum suppression by the fixed-point tan(22.5 deg) test
+//                                    (TG22 = 13573, shift 15; magnitudes outside the image are 0),
+//                                    hysteresis over the 8-neighbourhood
 //
 // The two-pass raster chamfer of OpenCV is inherently sequential; what it computes is the exact
 // shortest 8-connected path length, which has the closed form  a*max(dx,dy) + (b-a)*min(dx,dy).
@@ -88,6 +94,128 @@ __global__ void ea_threshold_median_kernel(const uint8_t *__restrict__ lap, int 
     }
   }
   mask[(size_t)v * W + u] = bg >= 5 ? 255 : 0;
+}
+
+// ---- Canny flavour (ref: utils.cpp:87-94 / :397-404: blur 3x3 -> CV_RGB2GRAY -> Canny(30, 90)) ----------------
+
+// box blur (3 channels) + gray in one pass
+__global__ void ea_boxblur_gray_kernel(const uint8_t *__restrict__ bgr, int H, int W, uint8_t *__restrict__ gray) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
+  if (u >= W) return;
+  int acc[3] = {0, 0, 0};
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy) {
+    const int yy = reflect101(v + dy, H);
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int xx = reflect101(u + dx, W);
+      const uint8_t *p = bgr + ((size_t)yy * W + xx) * 3;
+      acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2];
+    }
+  }
+  const int c0 = (acc[0] + 4) / 9, c1 = (acc[1] + 4) / 9, c2 = (acc[2] + 4) / 9;
+  gray[(size_t)v * W + u] = (uint8_t)((4899 * c0 + 9617 * c1 + 1868 * c2 + 8192) >> 14);
+}
+
+// Sobel 3x3 (replicated border) -> L1 magnitude (int16 range) and the packed direction class needed by the
+// suppression test: bits 0-1 = 0 horizontal / 1 vertical / 2 diagonal, bit 2 = sign s of the diagonal (1: s = -1)
+__global__ void ea_sobel_mag_kernel(const uint8_t *__restrict__ gray, int H, int W, int *__restrict__ mag,
+                                    uint8_t *__restrict__ dir) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
+  if (u >= W) return;
+  const int ym = max(v - 1, 0), yp = min(v + 1, H - 1), xm = max(u - 1, 0), xp = min(u + 1, W - 1);
+  const int a00 = gray[(size_t)ym * W + xm], a01 = gray[(size_t)ym * W + u], a02 = gray[(size_t)ym * W + xp];
+  const int a10 = gray[(size_t)v * W + xm], a12 = gray[(size_t)v * W + xp];
+  const int a20 = gray[(size_t)yp * W + xm], a21 = gray[(size_t)yp * W + u], a22 = gray[(size_t)yp * W + xp];
+  const int dx = (a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20);
+  const int dy = (a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02);
+  mag[(size_t)v * W + u] = abs(dx) + abs(dy);
+  const long long x = abs(dx), y = (long long)abs(dy) << 15;
+  const long long tg22x = x * 13573;
+  int cls;
+  if (y < tg22x) cls = 0;
+  else if (y > tg22x + (x << 16)) cls = 1;
+  else cls = 2 | (((dx ^ dy) < 0) ? 4 : 0);
+  dir[(size_t)v * W + u] = (uint8_t)cls;
+}
+
+// non-maximum suppression + double threshold: label 2 = strong, 0 = candidate, 1 = no edge
+__global__ void ea_canny_nms_kernel(const int *__restrict__ mag, const uint8_t *__restrict__ dir, int H, int W, int low,
+                                    int high, uint8_t *__restrict__ label) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
+  if (u >= W) return;
+  auto M = [&](int yy, int xx) { return (yy < 0 || yy >= H || xx < 0 || xx >= W) ? 0 : mag[(size_t)yy * W + xx]; };
+  const int m = mag[(size_t)v * W + u];
+  uint8_t out = 1;
+  if (m > low) {
+    const int cls = dir[(size_t)v * W + u];
+    bool is_max;
+    if ((cls & 3) == 0) is_max = m > M(v, u - 1) && m >= M(v, u + 1);
+    else if ((cls & 3) == 1) is_max = m > M(v - 1, u) && m >= M(v + 1, u);
+    else {
+      const int s = (cls & 4) ? -1 : 1;
+      is_max = m > M(v - 1, u - s) && m > M(v + 1, u + s);
+    }
+    if (is_max) out = m > high ? 2 : 0;
+  }
+  label[(size_t)v * W + u] = out;
+}
+
+// hysteresis: candidates 8-connected to a strong pixel become strong.  One workgroup owns a 32 x 32 tile (+ halo)
+// in LDS and iterates until the tile is stable; tiles exchange through global memory between launches, the host
+// repeats the launch until no tile reports a change.
+constexpr int kHystTile = 32;
+__global__ __launch_bounds__(256) void ea_canny_hysteresis_kernel(uint8_t *__restrict__ label, int H, int W,
+                                                                  int *__restrict__ changed) {
+  __shared__ uint8_t s_l[(kHystTile + 2) * (kHystTile + 2)];
+  const int x0 = blockIdx.x * kHystTile - 1, y0 = blockIdx.y * kHystTile - 1;
+  for (int i = threadIdx.x; i < (kHystTile + 2) * (kHystTile + 2); i += 256) {
+    const int ly = i / (kHystTile + 2), lx = i - ly * (kHystTile + 2);
+    const int y = y0 + ly, x = x0 + lx;
+    s_l[i] = (y >= 0 && y < H && x >= 0 && x < W) ? label[(size_t)y * W + x] : 1;
+  }
+  __syncthreads();
+  bool any = false;
+  for (;;) {
+    bool ch = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      const int ly = 1 + i / kHystTile, lx = 1 + (i & (kHystTile - 1));
+      const int c = ly * (kHystTile + 2) + lx;
+      if (s_l[c] == 0) {
+        const int r = kHystTile + 2;
+        if (s_l[c - r - 1] == 2 || s_l[c - r] == 2 || s_l[c - r + 1] == 2 || s_l[c - 1] == 2 || s_l[c + 1] == 2 ||
+            s_l[c + r - 1] == 2 || s_l[c + r] == 2 || s_l[c + r + 1] == 2) {
+          s_l[c] = 2;
+          ch = true;
+        }
+      }
+    }
+    any = any || ch;
+    if (!__syncthreads_or(ch)) break;
+  }
+  if (__syncthreads_or(any)) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      const int ly = 1 + i / kHystTile, lx = 1 + (i & (kHystTile - 1));
+      const int y = y0 + ly, x = x0 + lx;
+      if (y < H && x < W) label[(size_t)y * W + x] = s_l[ly * (kHystTile + 2) + lx];
+    }
+    if (threadIdx.x == 0) atomicOr(changed, 1);
+  }
+}
+
+// labels -> the CV_8U edge map (255 on edges) [AND the optional mask: inputmask > 1] and the DT source mask
+// (0 on edges, 255 elsewhere = `255 - edges`)
+__global__ void ea_canny_finish_kernel(const uint8_t *__restrict__ label, const uint8_t *__restrict__ keep /*nullable*/,
+                                       int npix, uint8_t *__restrict__ edges, uint8_t *__restrict__ inv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix) return;
+  const bool e = label[i] == 2 && (!keep || keep[i] > 1);
+  edges[i] = e ? 255 : 0;
+  inv[i] = e ? 0 : 255;
 }
 
 // G(x,y) = |y - y'| to the nearest feature pixel (mask == 0) of column x; kNoFeature if none.
@@ -201,16 +329,17 @@ __global__ void ea_chamfer_row_kernel(const int *__restrict__ G, const int *__re
 // dist (16.16 fixed) -> float32 [-> min-max normalised] -> padded image of the problem dtype
 template <typename T>
 __global__ void ea_dt_store_kernel(const int *__restrict__ dist_fix, int H, int W, const unsigned int *__restrict__ minmax,
-                                   int normalize, T *__restrict__ dst, int pitch, float *__restrict__ plain /*nullable HxW*/) {
+                                   int normalize, double lo, double hi, T *__restrict__ dst, int pitch,
+                                   float *__restrict__ plain /*nullable HxW*/) {
   const int pu = blockIdx.x * blockDim.x + threadIdx.x, pv = blockIdx.y;  // padded coordinates
   if (pu >= W + 2 * kImagePad) return;
   const int u = min(max(pu - kImagePad, 0), W - 1), v = min(max(pv - kImagePad, 0), H - 1);
   float f = (float)((double)dist_fix[(size_t)v * W + u] * (1.0 / 65536.0));
   if (normalize) {
-    // cv::normalize(NORM_MINMAX, 0, 1) on CV_32F: scale/shift in double, applied in float
+    // cv::normalize(NORM_MINMAX, lo, hi) on CV_32F: scale/shift in double, applied in float
     const double smin = (double)__uint_as_float(minmax[0]), smax = (double)__uint_as_float(minmax[1]);
-    const double scale = (smax - smin) > 2.220446049250313e-16 ? 1.0 / (smax - smin) : 0.0;
-    const double shift = 0.0 - smin * scale;
+    const double scale = (hi - lo) * ((smax - smin) > 2.220446049250313e-16 ? 1.0 / (smax - smin) : 0.0);
+    const double shift = lo - smin * scale;
     f = __fadd_rn(__fmul_rn(f, (float)scale), (float)shift);
   }
   dst[(size_t)pv * pitch + pu] = (T)f;
@@ -326,12 +455,45 @@ hipError_t launch_chamfer(const uint8_t *mask, int H, int W, int *G, int *scratc
 }
 
 hipError_t launch_dt_store(int dtype, const int *dist_fix, int H, int W, const unsigned int *minmax, int normalize,
-                           void *dst, int pitch, float *plain, hipStream_t s) {
+                           double lo, double hi, void *dst, int pitch, float *plain, hipStream_t s) {
   dim3 block(256), grid((W + 2 * kImagePad + 255) / 256, H + 2 * kImagePad);
   if (dtype == 1)
-    hipLaunchKernelGGL((ea_dt_store_kernel<float>), grid, block, 0, s, dist_fix, H, W, minmax, normalize, (float *)dst, pitch, plain);
+    hipLaunchKernelGGL((ea_dt_store_kernel<float>), grid, block, 0, s, dist_fix, H, W, minmax, normalize, lo, hi, (float *)dst, pitch, plain);
   else
-    hipLaunchKernelGGL((ea_dt_store_kernel<double>), grid, block, 0, s, dist_fix, H, W, minmax, normalize, (double *)dst, pitch, plain);
+    hipLaunchKernelGGL((ea_dt_store_kernel<double>), grid, block, 0, s, dist_fix, H, W, minmax, normalize, lo, hi, (double *)dst, pitch, plain);
+  return hipGetLastError();
+}
+
+// blur 3x3 -> gray -> Canny(low, high): labels are left in `label` (2 = edge after the hysteresis), `edges` is the
+// CV_8U edge map [AND keep > 1], `inv` = 255 - edges.  mag: H*W ints, dir/label/edges/inv: H*W bytes,
+// changed: one int in device memory, h_changed: its pinned host mirror (polled between hysteresis rounds).
+hipError_t launch_canny(const uint8_t *bgr, int H, int W, int low, int high, const uint8_t *keep, uint8_t *gray, int *mag,
+                        uint8_t *dir, uint8_t *label, uint8_t *edges, uint8_t *inv, int *changed, int *rounds_out,
+                        hipStream_t s) {
+  dim3 block(256), grid((W + 255) / 256, H);
+  hipLaunchKernelGGL(ea_boxblur_gray_kernel, grid, block, 0, s, bgr, H, W, gray);
+  hipLaunchKernelGGL(ea_sobel_mag_kernel, grid, block, 0, s, gray, H, W, mag, dir);
+  hipLaunchKernelGGL(ea_canny_nms_kernel, grid, block, 0, s, mag, dir, H, W, low, high, label);
+  // hysteresis rounds: four launches per check of the change flag (a launch that changes nothing is ~3 us, a
+  // flag read-back is a stream synchronisation)
+  const dim3 tgrid((W + kHystTile - 1) / kHystTile, (H + kHystTile - 1) / kHystTile);
+  int rounds = 0;
+  for (;;) {
+    hipError_t e = hipMemsetAsync(changed, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+    for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(ea_canny_hysteresis_kernel, tgrid, dim3(256), 0, s, label, H, W, changed);
+    int h = 0;
+    e = hipMemcpyAsync(&h, changed, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return e;
+    rounds += 4;
+    // the flag is the OR over the four launches: it can only be clear when the last one changed nothing either
+    if (!h) break;
+    if (rounds > 4 * (H + W)) return hipErrorUnknown;  // cannot happen: every launch that reports a change grows the edge set
+  }
+  if (rounds_out) *rounds_out = rounds;
+  const int npix = H * W;
+  hipLaunchKernelGGL(ea_canny_finish_kernel, dim3((npix + 255) / 256), block, 0, s, label, keep, npix, edges, inv);
   return hipGetLastError();
 }
 

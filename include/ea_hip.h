@@ -226,6 +226,23 @@ int ea_problem_set_now_frame(ea_problem *p, const uint8_t *bgr, int height, int 
 int ea_problem_debug_now_frame(ea_problem *p, const uint8_t *bgr, int height, int width, int threshold, int median,
                                int normalize, uint8_t *lap_out, uint8_t *mask_out, int32_t *chamfer_fix_out,
                                float *dt_out);
+/* Canny flavour of the two producers -- what every standalone test after edge_align_test1 uses:
+ * blur 3x3 -> CV_RGB2GRAY -> Canny(low, high) (aperture 3, L1 gradient; the reference passes 30, 90).
+ * Reference frame: get_aX_canny (utils.cpp:371-462): edge pixel && depth > 0 -> back-projection, raster order. */
+int ea_problem_set_ref_frame_canny(ea_problem *p, const uint8_t *bgr, const uint16_t *depth, int height, int width,
+                                   double z_scaling, double low_threshold, double high_threshold);
+/* Current frame: get_distance_transform2 (utils.cpp:85-106), _masked (:108-141; mask: H x W bytes, edges survive where
+ * mask > 1), _NoNormalize (:142-165), _masked_NoNormalize (:166-199): edges -> 3x3 chamfer DT -> [min-max normalise to
+ * [norm_lo, norm_hi]: (0,1) at :103, (0,255) at :138] written into the problem's DT image.  mask may be NULL. */
+int ea_problem_set_now_frame_canny(ea_problem *p, const uint8_t *bgr, const uint8_t *mask, int height, int width,
+                                   double low_threshold, double high_threshold, int normalize, double norm_lo,
+                                   double norm_hi);
+/* same, and copies the stages back (any may be NULL): edge map (0/255), chamfer distance in 16.16 fixed point,
+ * final float32 DT, number of hysteresis launches */
+int ea_problem_debug_now_frame_canny(ea_problem *p, const uint8_t *bgr, const uint8_t *mask, int height, int width,
+                                     double low_threshold, double high_threshold, int normalize, double norm_lo,
+                                     double norm_hi, uint8_t *edges_out, int32_t *chamfer_fix_out, float *dt_out,
+                                     int *hysteresis_launches);
 /* read back what the problem holds in HBM: points (n x 3 doubles), DT image (H x W doubles, [v][u]) */
 int ea_problem_get_points(ea_problem *p, double *xyz, int64_t capacity);
 int ea_problem_get_dt(ea_problem *p, double *image, int *height, int *width);

@@ -8,7 +8,13 @@ that check.
 Follows (ref = /root/reference):
   get_aX                  ref: standalone/utils.cpp:201-281
   get_distance_transform  ref: standalone/utils.cpp:38-83
+  get_distance_transform2 / _masked / _NoNormalize / _masked_NoNormalize   ref: standalone/utils.cpp:85-199
+  get_aX_canny            ref: standalone/utils.cpp:371-462
 and the published OpenCV 3 algorithms those call (OpenCV is absent from this image):
+  blur 3x3 on 8-bit                  -> box sum / 9 rounded to nearest, reflect-101
+  Canny(gray, 30, 90) (aperture 3, L1 gradient) -> Sobel 3x3 CV_16S with replicated border, |dx|+|dy|,
+                                        non-maximum suppression with the tan(22.5 deg) fixed-point test
+                                        (TG22 = 13573, shift 15), hysteresis over 8-neighbours
   GaussianBlur 3x3 sigma=0 on 8-bit  -> [1 2 1]x[1 2 1]/16, fixed point, round-half-up, reflect-101
   cvtColor CV_RGB2GRAY on 8-bit      -> (4899*c0 + 9617*c1 + 1868*c2 + 8192) >> 14  (c0 is really
                                         blue: imread returns BGR, the code says RGB — utils.cpp:51,216)
@@ -146,6 +152,109 @@ def get_distance_transform(img_bgr, threshold=35, normalize=True):
     Bf = median_blur3_u8(B)
     dist = distance_transform_l2_3(Bf)
     return normalize_minmax_f32(dist) if normalize else dist
+
+
+def box_blur3_u8(img):
+    """cv::blur(img, Size(3,3)) on CV_8UC3 / CV_8UC1: normalised box filter, BORDER_DEFAULT (reflect-101);
+    the 8-bit result is the sum of nine divided by 9, rounded to nearest (9 is odd: no ties)."""
+    a = _pad_reflect101(img.astype(np.int32))
+    H, W = img.shape[:2]
+    sm = sum(a[i:i + H, j:j + W] for i in range(3) for j in range(3))
+    return ((sm + 4) // 9).astype(np.uint8)
+
+
+def sobel3_s16_replicate(gray):
+    """cv::Sobel(gray, CV_16S, 1, 0, 3) and (0, 1, 3) with BORDER_REPLICATE, as cv::Canny computes them."""
+    a = np.pad(gray.astype(np.int32), 1, mode="edge")
+    H, W = gray.shape
+    p = lambda di, dj: a[1 + di:1 + di + H, 1 + dj:1 + dj + W]
+    dx = (p(-1, 1) + 2 * p(0, 1) + p(1, 1)) - (p(-1, -1) + 2 * p(0, -1) + p(1, -1))
+    dy = (p(1, -1) + 2 * p(1, 0) + p(1, 1)) - (p(-1, -1) + 2 * p(-1, 0) + p(-1, 1))
+    return dx, dy
+
+
+CANNY_SHIFT = 15
+TG22 = int(0.4142135623730950488016887242097 * (1 << CANNY_SHIFT) + 0.5)  # 13573
+
+
+def canny_nms_labels(gray, low_thresh, high_thresh):
+    """Stages 1-2 of cv::Canny(gray, edges, t1, t2, 3, false): per-pixel label 2 = strong edge (local maximum
+    above `high`), 0 = candidate (local maximum above `low`), 1 = not an edge.  Magnitudes outside the image are 0."""
+    low, high = sorted((int(np.floor(low_thresh)), int(np.floor(high_thresh))))
+    dx, dy = sobel3_s16_replicate(gray)
+    mag = np.abs(dx) + np.abs(dy)
+    H, W = gray.shape
+    m = np.pad(mag, 1)  # zero border
+    c = m[1:-1, 1:-1]
+    left, right = m[1:-1, :-2], m[1:-1, 2:]
+    up, down = m[:-2, 1:-1], m[2:, 1:-1]
+    x = np.abs(dx).astype(np.int64)
+    y = np.abs(dy).astype(np.int64) << CANNY_SHIFT
+    tg22x = x * TG22
+    tg67x = tg22x + (x << (CANNY_SHIFT + 1))
+    horiz = y < tg22x
+    vert = (~horiz) & (y > tg67x)
+    diag = ~(horiz | vert)
+    s = np.where((dx ^ dy) < 0, -1, 1)
+    # diagonal neighbours: row above at column j - s, row below at column j + s
+    jj = np.arange(W)[None, :] + np.zeros((H, 1), dtype=np.int64)
+    ii = np.arange(H)[:, None] + np.zeros((1, W), dtype=np.int64)
+    up_d = m[ii, jj + 1 - s]       # m is padded by one: (i-1)+1 = ii, (j - s)+1
+    down_d = m[ii + 2, jj + 1 + s]
+    is_max = np.where(horiz, (c > left) & (c >= right), np.where(vert, (c > up) & (c >= down), (c > up_d) & (c > down_d)))
+    is_max &= c > low
+    labels = np.ones((H, W), dtype=np.uint8)
+    labels[is_max] = 0
+    labels[is_max & (c > high)] = 2
+    return labels
+
+
+def canny_hysteresis(labels):
+    """Stage 3: candidates (0) 8-connected to a strong pixel (2) become edges.  Returns the CV_8U edge map."""
+    from scipy import ndimage
+    cand = labels != 1
+    comp, n = ndimage.label(cand, structure=np.ones((3, 3), dtype=bool))
+    keep = np.zeros(n + 1, dtype=bool)
+    keep[np.unique(comp[labels == 2])] = True
+    keep[0] = False
+    return np.where(keep[comp], 255, 0).astype(np.uint8)
+
+
+def canny_u8(gray, low_thresh, high_thresh):
+    """cv::Canny(gray, edges, low_thresh, high_thresh) (apertureSize 3, L2gradient false) on CV_8UC1."""
+    return canny_hysteresis(canny_nms_labels(gray, low_thresh, high_thresh))
+
+
+def canny_edges_of_frame(img_bgr, low=30, high=90):
+    """blur 3x3 -> CV_RGB2GRAY -> Canny(30, 90): the edge map shared by get_distance_transform2* and get_aX_canny
+    (ref: utils.cpp:87-94, :397-404)."""
+    return canny_u8(rgb2gray_u8(box_blur3_u8(img_bgr)), low, high)
+
+
+def get_distance_transform2(img_bgr, mask_u8=None, normalize=(0.0, 1.0)):
+    """ref: utils.cpp:85-199.  `mask_u8` None: get_distance_transform2 (normalize (0,1), :85-106) or
+    get_distance_transform2_NoNormalize (normalize None, :142-165); with a mask: the _masked variants
+    (:108-141 normalises to (0,255), :166-199 does not): edges survive where inputmask > 1."""
+    edges = canny_edges_of_frame(img_bgr)
+    if mask_u8 is not None:
+        edges = np.where(mask_u8 > 1, edges, 0).astype(np.uint8)
+    dist = distance_transform_l2_3(255 - edges)
+    return normalize_minmax_f32(dist, *normalize) if normalize is not None else dist
+
+
+def get_aX_canny(img_bgr, depth_u16, fx, fy, cx, cy, z_scaling=5000.0):
+    """ref: utils.cpp:371-462.  Returns (a_X 4xN float64 in raster order, (v,u) index arrays)."""
+    edges = canny_edges_of_frame(img_bgr)
+    H, W = edges.shape
+    Z = depth_u16.astype(np.float64) / float(z_scaling)
+    u = np.arange(W, dtype=np.float64)[None, :]
+    v = np.arange(H, dtype=np.float64)[:, None]
+    X = (u - cx) * Z / fx
+    Y = (v - cy) * Z / fy
+    keep = (edges > 0) & (Z > 0)
+    vv, uu = np.nonzero(keep)
+    a_X = np.stack([X[vv, uu], Y[vv, uu], Z[vv, uu], np.ones(vv.size)], axis=0)
+    return a_X, (vv, uu)
 
 
 def grid_view_of_image(dt_hw):

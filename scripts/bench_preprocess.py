@@ -17,10 +17,17 @@ print('640x480  set_now_frame (H2D + kernels)                  %.3f ms' % timeit
 t0 = time.perf_counter(); pp.get_aX(rgb1, d1, *K); t1 = time.perf_counter(); pp.get_distance_transform(rgb3); t2 = time.perf_counter()
 print('numpy restatement on the host: get_aX %.1f ms, get_distance_transform %.1f ms' % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
 q, t, s = P.solve([1, 0, 0, 0], [0, 0, 0]); print('solve', s['why'], s['num_iterations'], '%.3f ms' % s['total_time_ms'])
+print('640x480  set_ref_frame_canny (blur, gray, Canny 30/90, compaction)   %.3f ms  (n=%d)' % (timeit(lambda: P.set_ref_frame_canny(rgb1, d1)), P.num_points))
+print('640x480  set_now_frame_canny (... + chamfer DT + normalise)          %.3f ms  (hysteresis launches: %d)' % (timeit(lambda: P.set_now_frame_canny(rgb3)), P.set_now_frame_canny(rgb3, debug=True)['hysteresis_launches']))
+t0 = time.perf_counter(); pp.get_aX_canny(rgb1, d1, *K); t1 = time.perf_counter(); pp.get_distance_transform2(rgb3); t2 = time.perf_counter()
+print('numpy/scipy restatement on the host: get_aX_canny %.1f ms, get_distance_transform2 %.1f ms' % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
+q, t, s = P.solve([1, 0, 0, 0], [0, 0, 0]); print('solve (Canny inputs)', s['why'], s['num_iterations'], '%.3f ms' % s['total_time_ms'])
 rng = np.random.default_rng(0)
 big = np.kron(rgb3, np.ones((4, 4, 1), np.uint8))[:1536, :2048].copy()
 bigd = np.kron(d1, np.ones((4, 4), np.uint16))[:1536, :2048].copy()
 P2 = capi.Problem(1680., 1680., 1023.5, 767.5, dtype=capi.EA_F32)
 print('2048x1536 set_ref_frame %.3f ms  (n=%d)' % (timeit(lambda: P2.set_ref_frame(big, bigd), 5), P2.num_points))
 print('2048x1536 set_now_frame %.3f ms' % timeit(lambda: P2.set_now_frame(big), 5))
+print('2048x1536 set_ref_frame_canny %.3f ms  (n=%d)' % (timeit(lambda: P2.set_ref_frame_canny(big, bigd), 5), P2.num_points))
+print('2048x1536 set_now_frame_canny %.3f ms  (hysteresis launches: %d)' % (timeit(lambda: P2.set_now_frame_canny(big), 5), P2.set_now_frame_canny(big, debug=True)['hysteresis_launches']))
 P.close(); P2.close()

@@ -2,10 +2,14 @@
 tests/golden/make_golden.py from the reference's bundled frames) and the one number the
 reference itself records for this path: 1482 residual blocks = ceil(44457 / 30)
 (standalone/README.md:34, standalone_edge_align.cpp:267)."""
+import os
+
 import numpy as np
 import pytest
 
 from edge_alignment_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_edge_point_count_matches_reference_log(bundled_pair, golden):
@@ -87,3 +91,86 @@ def test_reference_log_is_frame_1_to_5_indicative_only(oracle, bundled_pair):
     roll = np.degrees(np.arctan2(R[2, 1], R[2, 2]))
     assert abs(yaw - (-0.32)) < 0.15 and abs(pitch - 1.52) < 0.15 and abs(roll - 2.50) < 0.15
     assert np.abs(t - np.array([-0.01, 0.00, -0.05])).max() < 0.006
+
+
+# ---- Canny flavour of the producers (ref: utils.cpp:85-199, :371-462): the restatement against a literal,
+# loop-by-loop transcription of the published algorithm on crops small enough for pure Python
+
+def _canny_reference_loops(gray, low, high):
+    H, W = gray.shape
+    a = np.pad(gray.astype(int), 1, mode="edge")
+    dx = np.zeros((H, W), int); dy = np.zeros((H, W), int)
+    for i in range(H):
+        for j in range(W):
+            w = a[i:i + 3, j:j + 3]
+            dx[i, j] = (w[0, 2] + 2 * w[1, 2] + w[2, 2]) - (w[0, 0] + 2 * w[1, 0] + w[2, 0])
+            dy[i, j] = (w[2, 0] + 2 * w[2, 1] + w[2, 2]) - (w[0, 0] + 2 * w[0, 1] + w[0, 2])
+    m = np.pad(np.abs(dx) + np.abs(dy), 1)
+    lab = np.ones((H, W), np.uint8)
+    for i in range(H):
+        for j in range(W):
+            mm = m[i + 1, j + 1]
+            if mm <= low:
+                continue
+            xs, ys = int(dx[i, j]), int(dy[i, j])
+            x, y = abs(xs), abs(ys) << 15
+            tg22x = x * 13573
+            if y < tg22x:
+                ok = mm > m[i + 1, j] and mm >= m[i + 1, j + 2]
+            elif y > tg22x + (x << 16):
+                ok = mm > m[i, j + 1] and mm >= m[i + 2, j + 1]
+            else:
+                s = -1 if (xs ^ ys) < 0 else 1
+                ok = mm > m[i, j + 1 - s] and mm > m[i + 2, j + 1 + s]
+            if ok:
+                lab[i, j] = 2 if mm > high else 0
+    out = np.zeros((H, W), np.uint8)
+    stack = [(i, j) for i in range(H) for j in range(W) if lab[i, j] == 2]
+    for p in stack:
+        out[p] = 255
+    while stack:
+        i, j = stack.pop()
+        for di in (-1, 0, 1):
+            for dj in (-1, 0, 1):
+                ii, jj = i + di, j + dj
+                if 0 <= ii < H and 0 <= jj < W and lab[ii, jj] == 0 and out[ii, jj] == 0:
+                    out[ii, jj] = 255
+                    stack.append((ii, jj))
+    return out
+
+
+def test_canny_restatement_matches_the_literal_loops():
+    from oracle import preprocess_np as pp
+    bgr = pp.load_rgb_as_bgr(os.path.join(ROOT, "tests", "golden", "rgbd", "rgb_3.png"))
+    gray = pp.rgb2gray_u8(pp.box_blur3_u8(bgr))
+    rng = np.random.default_rng(5)
+    crops = [gray[100:170, 200:290], gray[0:40, 0:64], gray[440:480, 560:640],
+             rng.integers(0, 256, (33, 47)).astype(np.uint8)]
+    for g in crops:
+        for low, high in ((30, 90), (90, 30), (10, 300), (0, 0)):
+            lo, hi = sorted((low, high))
+            assert np.array_equal(pp.canny_u8(g, low, high), _canny_reference_loops(g, lo, hi))
+
+
+def test_box_blur_and_canny_pipeline_on_the_bundled_frames():
+    from oracle import preprocess_np as pp
+    G = os.path.join(ROOT, "tests", "golden", "rgbd")
+    bgr = pp.load_rgb_as_bgr(os.path.join(G, "rgb_1.png"))
+    depth = pp.load_depth_u16(os.path.join(G, "depth_1.png"))
+    # box blur: literal 3x3 mean with reflect-101 borders at a few pixels, corners included
+    b = pp.box_blur3_u8(bgr)
+    H, W = bgr.shape[:2]
+    refl = lambda i, n: -i if i < 0 else (2 * n - 2 - i if i >= n else i)
+    for (v, u) in ((0, 0), (0, W - 1), (H - 1, 0), (H - 1, W - 1), (17, 33), (240, 320)):
+        for c in range(3):
+            sm = sum(int(bgr[refl(v + dv, H), refl(u + du, W), c]) for dv in (-1, 0, 1) for du in (-1, 0, 1))
+            assert b[v, u, c] == int(round(sm / 9.0))
+    edges = pp.canny_edges_of_frame(bgr)
+    assert set(np.unique(edges)) == {0, 255}
+    aX, (vv, uu) = pp.get_aX_canny(bgr, depth, 525.0, 525.0, 319.5, 239.5)
+    assert aX.shape[1] == int(((edges > 0) & (depth > 0)).sum()) > 10000
+    assert np.all(np.diff(vv * W + uu) > 0)          # raster order
+    dt = pp.get_distance_transform2(bgr)
+    assert dt.dtype == np.float32 and dt.min() == 0.0 and dt.max() == 1.0 and np.all(dt[edges > 0] == 0.0)
+    raw = pp.get_distance_transform2(bgr, normalize=None)
+    assert raw.max() > 1.0 and np.all(raw[edges > 0] == 0.0)

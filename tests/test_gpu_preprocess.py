@@ -152,3 +152,94 @@ def test_c4_batch_of_frame_pairs(hip, oracle):
     B.close()
     for P in Ps:
         P.close()
+
+
+# ---- Canny flavour (get_distance_transform2* / get_aX_canny, ref: utils.cpp:85-199, :371-462) ----------------
+
+def _random_frame(seed, H=97, W=131):
+    """smooth blobs + sharp steps + noise: plenty of weak/strong Canny candidates and long thin chains"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    img = np.zeros((H, W, 3))
+    for c in range(3):
+        a = 60 * np.sin(xx / (5 + 3 * c) + rng.random() * 6) + 60 * np.cos(yy / (7 + c) + rng.random() * 6)
+        a += 80 * ((xx - W * rng.random()) ** 2 + (yy - H * rng.random()) ** 2 < (15 + 10 * c) ** 2)
+        a += 50 * (xx > W * rng.random()) + rng.normal(0, 6, (H, W))
+        img[:, :, c] = a
+    img -= img.min()
+    return (img * (255.0 / img.max())).astype(np.uint8)
+
+
+def test_canny_edges_and_dt2_bit_exact(hip, frames):
+    """Every stage of the Canny flavour against the OpenCV-semantics restatement: edge map (blur 3x3, gray, Sobel,
+    non-maximum suppression, hysteresis) and chamfer distance as integers, the float DT bit for bit."""
+    pp = frames["pp"]
+    for k, bgr in enumerate([frames["rgb3"], frames["rgb1"], _random_frame(1), _random_frame(2, 40, 500), _random_frame(3, 333, 35)]):
+        P = hip.Problem(525.0, 525.0, 319.5, 239.5, dtype=hip.EA_F64)
+        got = P.set_now_frame_canny(bgr, debug=True)
+        edges = pp.canny_edges_of_frame(bgr)
+        assert np.array_equal(got["edges"], edges), k
+        assert np.array_equal(got["chamfer"], pp.chamfer3x3_fixed(edges != 0)), k
+        want = pp.get_distance_transform2(bgr)
+        assert np.array_equal(got["dt"], want), k
+        assert np.array_equal(P.get_dt().astype(np.float32), want), k
+        # other thresholds (swapped on purpose: cv::Canny orders them itself)
+        got = P.set_now_frame_canny(bgr, low=120.0, high=45.5, debug=True)
+        assert np.array_equal(got["edges"], pp.canny_u8(pp.rgb2gray_u8(pp.box_blur3_u8(bgr)), 120.0, 45.5)), k
+        P.close()
+
+
+def test_canny_dt2_variants(hip, frames):
+    """_NoNormalize, _masked (normalised to [0, 255]) and _masked_NoNormalize (ref: utils.cpp:108-199)."""
+    pp = frames["pp"]
+    bgr = frames["rgb3"]
+    H, W = bgr.shape[:2]
+    rng = np.random.default_rng(9)
+    mask = np.zeros((H, W), np.uint8)
+    mask[60:400, 100:560] = 255
+    mask[rng.random((H, W)) < 0.05] = 1     # 1 is NOT kept: the reference thresholds at > 1
+    mask[200:230, 300:340] = 0
+    P = hip.Problem(525.0, 525.0, 319.5, 239.5, dtype=hip.EA_F32)
+    got = P.set_now_frame_canny(bgr, normalize=None, debug=True)
+    assert np.array_equal(got["dt"], pp.get_distance_transform2(bgr, normalize=None))
+    got = P.set_now_frame_canny(bgr, mask=mask, normalize=(0.0, 255.0), debug=True)
+    assert np.array_equal(got["dt"], pp.get_distance_transform2(bgr, mask_u8=mask, normalize=(0.0, 255.0)))
+    assert np.array_equal(P.get_dt().astype(np.float32), got["dt"])
+    got = P.set_now_frame_canny(bgr, mask=mask, normalize=None, debug=True)
+    assert np.array_equal(got["dt"], pp.get_distance_transform2(bgr, mask_u8=mask, normalize=None))
+    # an image without a single edge: every distance saturates alike, the normalised DT is constant
+    flat = np.full((64, 80, 3), 117, np.uint8)
+    got = P.set_now_frame_canny(flat, debug=True)
+    assert got["edges"].max() == 0 and np.array_equal(got["dt"], pp.get_distance_transform2(flat))
+    P.close()
+
+
+def test_canny_edge_points_bit_exact(hip, frames):
+    """get_aX_canny: Canny edge && depth > 0, raster order, fp64 back-projection."""
+    pp = frames["pp"]
+    for bgr, depth in ((frames["rgb1"], frames["depth1"]),):
+        aX, _ = pp.get_aX_canny(bgr, depth, *K)
+        P = hip.Problem(*K, dtype=hip.EA_F64)
+        P.set_ref_frame_canny(bgr, depth)
+        assert P.num_points == aX.shape[1] > 10000
+        assert np.array_equal(P.get_points(), aX[:3].T)
+        P.close()
+
+
+def test_canny_frames_to_pose_end_to_end(hip, oracle, frames):
+    """The compute of the reference's later tests (standalone_edge_align.cpp:372-490: get_aX_canny-style points,
+    get_distance_transform2, CauchyLoss, LM) from raw frames, against the oracle's solve on the restated inputs."""
+    pp = frames["pp"]
+    aX, _ = pp.get_aX_canny(frames["rgb1"], frames["depth1"], *K)
+    dt = pp.get_distance_transform2(frames["rgb3"])
+    O = oracle.OracleProblem(pp.grid_view_of_image(dt), *K, loss=oracle.LOSS_CAUCHY, loss_a=1.0)
+    qo, to, so = O.solve(aX[:3].T.copy(), np.array([1.0, 0, 0, 0]), np.zeros(3))
+    P = hip.Problem(*K, dtype=hip.EA_F64)
+    P.set_loss(hip.LOSS_CAUCHY, 1.0)
+    P.set_ref_frame_canny(frames["rgb1"], frames["depth1"])
+    P.set_now_frame_canny(frames["rgb3"])
+    q, t, s = P.solve(np.array([1.0, 0, 0, 0]), np.zeros(3))
+    assert s["num_iterations"] == so["num_iterations"] and s["why"] == so["why"]
+    assert np.abs(q - qo).max() < 1e-9 and np.abs(t - to).max() < 1e-9
+    assert s["final_cost"] == pytest.approx(so["final_cost"], rel=1e-10)
+    P.close()
