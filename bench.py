@@ -145,8 +145,12 @@ def main():
         elapsed = float(tt.item())
     value = world * n_pts * args.steps / elapsed
 
-    # per-launch duration of the dominant kernel (HIP events on the library's stream)
-    _, ms_kernel = B.bench_eval(q0, t0, 2, min(args.steps, 64))
+    # Duration of the dominant kernel, HIP events on the library's stream.  kernel_ms: one event pair around a run of
+    # back-to-back launches / their number -- the execution window, the figure rocprofv3 --kernel-trace reports
+    # (profiles/); kernel_ms_isolated: an event pair around every single launch of the timed pattern, which also
+    # contains the command processor's dispatch (~2.6 us) because nothing is in flight to hide it.
+    _, ms_kernel_isolated = B.bench_eval(q0, t0, 2, min(args.steps, 64))
+    ms_kernel = B.bench_kernel(q0, t0, 10, max(args.steps, 100))
     bytes_launch = algorithmic_bytes(n_pts, H, W, esize)
     achieved = bytes_launch / (ms_kernel * 1e-3) / 1e9
     traffic = None
@@ -159,7 +163,8 @@ def main():
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": "ea_eval_fused_kernel<%s>" % ("double" if esize == 8 else "float"),
-                "kernel_ms": ms_kernel, "algorithmic_bytes_per_launch": bytes_launch}
+                "kernel_ms": ms_kernel, "kernel_ms_isolated": ms_kernel_isolated,
+                "algorithmic_bytes_per_launch": bytes_launch}
 
     extras = {}
     if not args.no_extras:
@@ -170,7 +175,7 @@ def main():
         P2.solve(q0, t0)
         barrier_sync()
         ts = time.perf_counter()
-        reps, its = 5, 0
+        reps, its = 40, 0
         for _ in range(reps):
             q, t, s = P2.solve(q0, t0)
             its += s["num_iterations"]
@@ -210,7 +215,8 @@ def main():
             Bx = capi.Batch(Ps)
             m = len(Ps)
             Q = np.tile(q0, (m, 1)); T = np.zeros((m, 3))
-            ms, msk = Bx.bench_eval(Q, T, 10, 100)
+            ms, _ = Bx.bench_eval(Q, T, 10, 100, kernel_pass=False)
+            msk = Bx.bench_kernel(Q, T, 5, 100)
             npts = sum(Px.num_points for Px in Ps)
             by = sum(algorithmic_bytes(Px.num_points, cfgx["image"].shape[0], cfgx["image"].shape[1], esz)
                      for Px, cfgx in zip(Ps, problems))

@@ -28,7 +28,7 @@ EXPORTED = [
     "ea_problem_set_loss", "ea_problem_set_flavour", "ea_problem_num_points",
     "ea_eval", "ea_eval_points", "ea_cost", "ea_solve",
     "ea_batch_create", "ea_batch_destroy", "ea_batch_count", "ea_batch_eval", "ea_batch_solve",
-    "ea_batch_bench_eval", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
+    "ea_batch_bench_eval", "ea_batch_bench_kernel", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
     "ea_problem_set_ref_frame", "ea_problem_set_now_frame", "ea_problem_debug_now_frame",
     "ea_problem_set_ref_frame_canny", "ea_problem_set_now_frame_canny", "ea_problem_debug_now_frame_canny",
     "ea_problem_get_points", "ea_problem_get_dt",
@@ -112,6 +112,7 @@ def load():
     L.ea_batch_eval.argtypes = [vp, dp, dp, dp, dp, dp, i64p]
     L.ea_batch_solve.argtypes = [vp, C.POINTER(Options), dp, dp, C.POINTER(Summary)]
     L.ea_batch_bench_eval.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp, dp]
+    L.ea_batch_bench_kernel.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp]
     L.ea_batch_set_tuning.argtypes = [vp, C.c_char_p, C.c_int]
     L.ea_batch_get_info.argtypes = [vp, C.c_char_p, i64p]
     L.ea_selftest_wave_reduce.argtypes = [C.c_int, C.POINTER(C.c_float), dp, dp, C.POINTER(C.c_float)]
@@ -387,6 +388,13 @@ class Batch:
         _check(load().ea_batch_bench_eval(self._h, _dp(q), _dp(t), warmup, steps, C.byref(ms_total),
                                           C.byref(ms_kernel) if kernel_pass else None))
         return ms_total.value, (ms_kernel.value if kernel_pass else None)
+
+    def bench_kernel(self, q, t, warmup, launches):
+        """mean ms of the per-point kernel over `launches` back-to-back launches (one event pair)"""
+        q, t = _f64(q).reshape(-1, 4), _f64(t).reshape(-1, 3)
+        ms = C.c_double()
+        _check(load().ea_batch_bench_kernel(self._h, _dp(q), _dp(t), warmup, launches, C.byref(ms)))
+        return ms.value
 
     def set_tuning(self, key, value):
         _check(load().ea_batch_set_tuning(self._h, key.encode(), int(value)))

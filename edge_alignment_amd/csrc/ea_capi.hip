@@ -781,6 +781,33 @@ extern "C" int ea_batch_bench_eval(ea_batch *b, const double *q, const double *t
   return EA_OK;
 }
 
+// Average duration of the per-point kernel when `launches` of them are queued back to back between one event pair:
+// the command processor dispatches launch i+1 while launch i executes, so the figure is the kernel's execution
+// window (what rocprofv3 --kernel-trace reports), not execution + dispatch as an event pair around a lone launch.
+extern "C" int ea_batch_bench_kernel(ea_batch *b, const double *q, const double *t, int warmup, int launches,
+                                     double *ms_per_launch) {
+  if (!b || !q || !t || !ms_per_launch || launches < 1 || warmup < 0) return fail(EA_ERR_INVALID_ARG, "bad argument");
+  int rc = batch_build(b);
+  if (rc != EA_OK) return rc;
+  rc = batch_upload_poses(b, q, t);
+  if (rc != EA_OK) return rc;
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  for (int i = 0; i < warmup; ++i) if ((rc = batch_launch_eval(b)) != EA_OK) return rc;
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipEventRecord(e0, b->stream));
+  for (int i = 0; i < launches; ++i) if ((rc = batch_launch_eval(b)) != EA_OK) return rc;
+  HIPCHK(hipEventRecord(e1, b->stream));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  *ms_per_launch = (double)ms / launches;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return EA_OK;
+}
+
 extern "C" int ea_batch_set_tuning(ea_batch *b, const char *key, int value) {
   if (!b || !key) return fail(EA_ERR_INVALID_ARG, "NULL argument");
   const std::string k(key);

@@ -204,6 +204,10 @@ int ea_batch_solve(ea_batch *b, const ea_options *opt, double *q, double *t,
  * dominant per-point kernel alone (events around each launch in a second pass). */
 int ea_batch_bench_eval(ea_batch *b, const double *q, const double *t, int warmup, int steps,
                         double *ms_total, double *ms_eval_kernel);
+/* `launches` of the per-point kernel queued back to back between ONE event pair: average execution window per
+ * launch (dispatch of the next launch overlaps the running one) -- the figure rocprofv3 --kernel-trace reports. */
+int ea_batch_bench_kernel(ea_batch *b, const double *q, const double *t, int warmup, int launches,
+                          double *ms_per_launch);
 /* tuning knobs: key in {"lds_bytes", "points_per_thread", "use_lds", "xcd_remap", "threads"};
  * value < 0 restores the default */
 int ea_batch_set_tuning(ea_batch *b, const char *key, int value);

@@ -1,10 +1,10 @@
 """Times the GPU frame producers (edge-point extractor, DT producer) on the bundled 640x480 frames and on a
 2048x1536 synthetic frame, next to the numpy restatement on the host."""
 import os, sys, time, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from edge_alignment_amd import capi
 from oracle import preprocess_np as pp
-G = 'tests/golden/rgbd'
+G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests/golden/rgbd')
 K = (525.0, 525.0, 319.5, 239.5)
 rgb1 = pp.load_rgb_as_bgr(os.path.join(G, 'rgb_1.png')); d1 = pp.load_depth_u16(os.path.join(G, 'depth_1.png')); rgb3 = pp.load_rgb_as_bgr(os.path.join(G, 'rgb_3.png'))
 def timeit(fn, n=20):

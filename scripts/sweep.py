@@ -1,6 +1,6 @@
 """Tuning sweep of the fused evaluation kernel (timing via the C-ABI measurement hook)."""
 import sys, itertools, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from edge_alignment_amd import capi, synth
 q0 = np.array([1.,0,0,0]); t0 = np.zeros(3)
 def sweep(name, cfgs, dtype, loss, grid, steps=100):
