@@ -228,6 +228,26 @@ def main():
             return res
         if args.workload != "c5":
             others["c5_fp32_1e6pts_2048x1536"] = measure([synth.config_c5()], capi.EA_F32, 4, (capi.LOSS_TRIVIAL, 1.0))
+        # C3: 3-level pyramid (1280x960 / 640x480 / 320x240, 2.0e5 points in total), fp32, coarse-to-fine solve
+        lv = synth.config_c3_levels()
+        Pl = []
+        for cfgx in lv:
+            Px = capi.Problem(*cfgx["K"], dtype=capi.EA_F32, device=local_rank)
+            Px.set_points(cfgx["xyz"]); Px.set_dt_grid(cfgx["grid"])
+            Pl.append(Px)
+        capi.solve_pyramid(Pl, q0, t0)
+        t3 = time.perf_counter()
+        for _ in range(10):
+            q3, tt3, ss3 = capi.solve_pyramid(Pl, q0, t0)
+        el3 = (time.perf_counter() - t3) / 10
+        its3 = [x["num_iterations"] for x in ss3]
+        evals3 = sum(x["num_point_evals"] for x in ss3)
+        others["c3_pyramid_fp32_2e5pts"] = {"solve_ms": el3 * 1e3, "iterations_per_level_fine_to_coarse": its3,
+                                            "evals_per_s": evals3 / el3, "lm_iters_per_s": sum(its3) / el3,
+                                            "pose_err_vs_planted": {"rad": synth.rotation_angle_between(q3, lv[0]["q_true"]),
+                                                                    "m": float(np.linalg.norm(tt3 - lv[0]["t_true"]))}}
+        for Px in Pl:
+            Px.close()
         batch = [synth.config_c2_twin(seed=100 + i) for i in range(32)]
         others["batch32_c2_fp64"] = measure(batch, capi.EA_F64, 8, (capi.LOSS_CAUCHY, 1.0))
         others["batch32_c2_fp32"] = measure(batch, capi.EA_F32, 4, (capi.LOSS_CAUCHY, 1.0))

@@ -28,8 +28,8 @@ EXPORTED = [
     "ea_problem_set_loss", "ea_problem_set_flavour", "ea_problem_num_points",
     "ea_eval", "ea_eval_points", "ea_cost", "ea_solve",
     "ea_batch_create", "ea_batch_destroy", "ea_batch_count", "ea_batch_eval", "ea_batch_solve",
-    "ea_batch_bench_eval", "ea_batch_bench_kernel", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
-    "ea_problem_set_ref_frame", "ea_problem_set_now_frame", "ea_problem_debug_now_frame",
+    "ea_solve_pyramid", "ea_batch_bench_eval", "ea_batch_bench_kernel", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
+    "ea_problem_set_ref_frame", "ea_problem_set_ref_frame_masked", "ea_problem_set_now_frame", "ea_problem_debug_now_frame",
     "ea_problem_set_ref_frame_canny", "ea_problem_set_now_frame_canny", "ea_problem_debug_now_frame_canny",
     "ea_problem_get_points", "ea_problem_get_dt",
     "ea_problem_set_distortion", "ea_problem_set_second_camera", "ea_problem_add_term", "ea_problem_clear_terms",
@@ -113,12 +113,14 @@ def load():
     L.ea_batch_solve.argtypes = [vp, C.POINTER(Options), dp, dp, C.POINTER(Summary)]
     L.ea_batch_bench_eval.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp, dp]
     L.ea_batch_bench_kernel.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp]
+    L.ea_solve_pyramid.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Options), dp, dp, C.POINTER(Summary)]
     L.ea_batch_set_tuning.argtypes = [vp, C.c_char_p, C.c_int]
     L.ea_batch_get_info.argtypes = [vp, C.c_char_p, i64p]
     L.ea_selftest_wave_reduce.argtypes = [C.c_int, C.POINTER(C.c_float), dp, dp, C.POINTER(C.c_float)]
     u8p, u16p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint16)
     L.ea_problem_set_ref_frame.argtypes = [vp, u8p, u16p, C.c_int, C.c_int, C.c_double, C.c_int]
     L.ea_problem_set_now_frame.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.ea_problem_set_ref_frame_masked.argtypes = [vp, u8p, u8p, u16p, C.c_int, C.c_int, C.c_double, C.c_int]
     L.ea_problem_set_ref_frame_canny.argtypes = [vp, u8p, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
     L.ea_problem_set_now_frame_canny.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double]
     L.ea_problem_debug_now_frame_canny.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double,
@@ -222,12 +224,19 @@ class Problem:
     def set_dt_image_device(self, ptr, height, width):
         _check(load().ea_problem_set_dt_image_device(self._h, ptr, height, width))
 
-    def set_ref_frame(self, bgr, depth_u16, z_scaling=5000.0, threshold=35):
-        """get_aX on the GPU: bgr (H,W,3) uint8 as cv::imread returns it, depth (H,W) uint16"""
+    def set_ref_frame(self, bgr, depth_u16, z_scaling=5000.0, threshold=35, mask=None):
+        """get_aX (get_aX_mask with a mask) on the GPU: bgr (H,W,3) uint8 as cv::imread returns it, depth (H,W) uint16"""
         bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
         depth_u16 = np.ascontiguousarray(depth_u16, dtype=np.uint16)
         H, W = depth_u16.shape
         assert bgr.shape == (H, W, 3)
+        if mask is not None:
+            mk = np.ascontiguousarray(mask, dtype=np.uint8)
+            assert mk.shape == (H, W)
+            _check(load().ea_problem_set_ref_frame_masked(self._h, bgr.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                          mk.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                          depth_u16.ctypes.data_as(C.POINTER(C.c_uint16)), H, W, z_scaling, threshold))
+            return
         _check(load().ea_problem_set_ref_frame(self._h, bgr.ctypes.data_as(C.POINTER(C.c_uint8)),
                                                depth_u16.ctypes.data_as(C.POINTER(C.c_uint16)), H, W, z_scaling, threshold))
 
@@ -339,6 +348,16 @@ class Problem:
         s = Summary()
         _check(load().ea_solve(self._h, C.byref(o), _dp(q), _dp(t), C.byref(s)))
         return q, t, summary_to_dict(s)
+
+
+def solve_pyramid(levels, q, t, **opts):
+    """coarse-to-fine over complete per-level problems, levels[0] = finest; returns q, t, [summary per level]"""
+    q, t = _f64(q).copy(), _f64(t).copy()
+    o = default_options(**opts)
+    hs = (C.c_void_p * len(levels))(*[p._h for p in levels])
+    s = (Summary * len(levels))()
+    _check(load().ea_solve_pyramid(hs, len(levels), C.byref(o), _dp(q), _dp(t), s))
+    return q, t, [summary_to_dict(x) for x in s]
 
 
 class Batch:

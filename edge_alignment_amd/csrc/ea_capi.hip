@@ -39,6 +39,7 @@ hipError_t launch_canny(const uint8_t *bgr, int H, int W, int low, int high, con
                         hipStream_t s);
 hipError_t launch_dt_store(int dtype, const int *dist_fix, int H, int W, const unsigned int *minmax, int normalize,
                            double lo, double hi, void *dst, int pitch, float *plain, hipStream_t s);
+hipError_t launch_gate_by_mask(uint8_t *grad, const uint8_t *mask, int H, int W, hipStream_t s);
 hipError_t launch_edge_count_scan(const uint8_t *lap, const uint16_t *depth, int H, int W, int thr, int *block_counts,
                                   int *total, hipStream_t s);
 hipError_t launch_edge_scatter(int dtype, const uint8_t *lap, const uint16_t *depth, int H, int W, int thr,
@@ -890,6 +891,28 @@ extern "C" int ea_solve(ea_problem *p, const ea_options *opt, double q[4], doubl
   return ea_batch_solve(b, opt, q, t, summary);
 }
 
+// Coarse-to-fine driver (BASELINE config C3; the reference has no pyramid -- SURVEY 8f row 4): levels[0] is the finest
+// level; the solve starts on levels[nlevels-1] and carries the pose down level by level.  Every level is a complete
+// problem (its own points, DT image and intrinsics scaled by the caller).  A level that fails (termination FAILURE)
+// stops the descent and its status is returned through the summaries; q, t hold the last pose reached.
+extern "C" int ea_solve_pyramid(ea_problem *const *levels, int nlevels, const ea_options *opt, double q[4], double t[3],
+                                ea_summary *summaries) {
+  if (!levels || nlevels < 1 || !q || !t) return fail(EA_ERR_INVALID_ARG, "bad argument");
+  for (int l = 0; l < nlevels; ++l)
+    if (!levels[l]) return fail(EA_ERR_INVALID_ARG, "NULL level");
+  for (int l = nlevels - 1; l >= 0; --l) {
+    ea_summary local;
+    ea_summary *s = summaries ? &summaries[l] : &local;
+    const int rc = ea_solve(levels[l], opt, q, t, s);
+    if (rc != EA_OK) return rc;
+    if (s->termination == EA_FAILURE) {
+      for (int k = l - 1; k >= 0 && summaries; --k) std::memset(&summaries[k], 0, sizeof(ea_summary));
+      break;
+    }
+  }
+  return EA_OK;
+}
+
 // ---- self-test of the wavefront reduction primitives (DPP row_mirror / row_half_mirror with bank
 // masks, v_permlane16/32_swap, quad_perm): in = 32 slots x 64 lanes (fp32); out32/out64 = the 32 wave
 // totals from the fp32 and fp64 reductions; stages (nullable) = 16+8+4+2 rows of 64 lanes.
@@ -946,8 +969,8 @@ static size_t frame_ws_bytes(int H, int W) {
          ((np + 1023) / 1024 + 8) * 4 + 64 * 256;
 }
 
-extern "C" int ea_problem_set_ref_frame(ea_problem *p, const uint8_t *bgr, const uint16_t *depth, int height, int width,
-                                        double z_scaling, int threshold) {
+static int ref_frame_impl(ea_problem *p, const uint8_t *bgr, const uint8_t *mask, const uint16_t *depth, int height,
+                          int width, double z_scaling, int threshold) {
   if (!p || !bgr || !depth) return fail(EA_ERR_INVALID_ARG, "NULL argument");
   if (height < 3 || width < 3 || (int64_t)height * width > 0x3fffffff) return fail(EA_ERR_INVALID_ARG, "image extent out of range");
   if (!(z_scaling > 0.0)) return fail(EA_ERR_INVALID_ARG, "z_scaling must be > 0");
@@ -959,12 +982,17 @@ extern "C" int ea_problem_set_ref_frame(ea_problem *p, const uint8_t *bgr, const
   uint8_t *d_bgr = ws.take<uint8_t>(np * 3);
   uint16_t *d_depth = ws.take<uint16_t>(np);
   uint8_t *d_gray = ws.take<uint8_t>(np), *d_lap = ws.take<uint8_t>(np);
+  uint8_t *d_keep = mask ? ws.take<uint8_t>(np) : nullptr;
   const int nblocks = (int)((np + 1023) / 1024);
   int *d_counts = ws.take<int>(nblocks + 1);
   int *d_total = d_counts + nblocks;
   HIPCHK(hipMemcpyAsync(d_bgr, bgr, np * 3, hipMemcpyHostToDevice, nullptr));
   HIPCHK(hipMemcpyAsync(d_depth, depth, np * 2, hipMemcpyHostToDevice, nullptr));
   HIPCHK(launch_edge_strength(d_bgr, height, width, d_gray, d_lap, nullptr));
+  if (mask) {
+    HIPCHK(hipMemcpyAsync(d_keep, mask, np, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(launch_gate_by_mask(d_lap, d_keep, height, width, nullptr));
+  }
   HIPCHK(launch_edge_count_scan(d_lap, d_depth, height, width, threshold, d_counts, d_total, nullptr));
   int total = 0;
   HIPCHK(hipMemcpy(&total, d_total, sizeof(int), hipMemcpyDeviceToHost));
@@ -982,6 +1010,18 @@ extern "C" int ea_problem_set_ref_frame(ea_problem *p, const uint8_t *bgr, const
   }
   p->n = total;
   return EA_OK;
+}
+
+extern "C" int ea_problem_set_ref_frame(ea_problem *p, const uint8_t *bgr, const uint16_t *depth, int height, int width,
+                                        double z_scaling, int threshold) {
+  return ref_frame_impl(p, bgr, nullptr, depth, height, width, z_scaling, threshold);
+}
+
+// get_aX_mask (ref: utils.cpp:283-369, call sites standalone_edge_align.cpp:1039, :1081): also requires mask > 0
+extern "C" int ea_problem_set_ref_frame_masked(ea_problem *p, const uint8_t *bgr, const uint8_t *mask, const uint16_t *depth,
+                                               int height, int width, double z_scaling, int threshold) {
+  if (!mask) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  return ref_frame_impl(p, bgr, mask, depth, height, width, z_scaling, threshold);
 }
 
 // mask (0 = edge / DT source) -> chamfer DT -> [normalise to [lo, hi]] -> the problem's padded DT image

@@ -347,6 +347,12 @@ __global__ void ea_dt_store_kernel(const int *__restrict__ dist_fix, int H, int 
     plain[(size_t)(pv - kImagePad) * W + (pu - kImagePad)] = f;
 }
 
+// get_aX_mask (ref: utils.cpp:283-369): a point also needs mask > 0 -- the gradient map is zeroed elsewhere
+__global__ void ea_gate_by_mask_kernel(uint8_t *__restrict__ grad, const uint8_t *__restrict__ mask, int npix) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npix && mask[i] == 0) grad[i] = 0;
+}
+
 // ---- edge points: flag, count per block, scan, scatter (raster order preserved) ----------------
 
 constexpr int kScanBlock = 1024;
@@ -494,6 +500,12 @@ hipError_t launch_canny(const uint8_t *bgr, int H, int W, int low, int high, con
   if (rounds_out) *rounds_out = rounds;
   const int npix = H * W;
   hipLaunchKernelGGL(ea_canny_finish_kernel, dim3((npix + 255) / 256), block, 0, s, label, keep, npix, edges, inv);
+  return hipGetLastError();
+}
+
+hipError_t launch_gate_by_mask(uint8_t *grad, const uint8_t *mask, int H, int W, hipStream_t s) {
+  const int npix = H * W;
+  hipLaunchKernelGGL(ea_gate_by_mask_kernel, dim3((npix + 255) / 256), dim3(256), 0, s, grad, mask, npix);
   return hipGetLastError();
 }
 

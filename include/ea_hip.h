@@ -186,6 +186,12 @@ int ea_cost(ea_problem *p, const double q[4], const double t[3], double *cost,
  * q,t in/out.  The whole trust-region loop runs on the device. */
 int ea_solve(ea_problem *p, const ea_options *opt, double q[4], double t[3], ea_summary *summary);
 
+/* Coarse-to-fine driver (BASELINE config C3; the reference has no pyramid): levels[0] = finest.
+ * Solves levels[nlevels-1] first and carries q, t down level by level; every level is a complete problem with its own
+ * points, DT image and (caller-scaled) intrinsics.  summaries: nlevels entries or NULL. */
+int ea_solve_pyramid(ea_problem *const *levels, int nlevels, const ea_options *opt, double q[4], double t[3],
+                     ea_summary *summaries);
+
 /* ---- batches of independent frame pairs (one launch sequence for all of them) --------- */
 int ea_batch_create(ea_batch **out, ea_problem *const *problems, int count);
 void ea_batch_destroy(ea_batch *b);
@@ -220,6 +226,10 @@ int ea_batch_get_info(const ea_batch *b, const char *key, int64_t *value);
  * depth: H x W uint16 (TUM: z_scaling 5000).  Host pointers. */
 int ea_problem_set_ref_frame(ea_problem *p, const uint8_t *bgr, const uint16_t *depth, int height, int width,
                              double z_scaling, int threshold);
+/* get_aX_mask (utils.cpp:283-369; call sites standalone_edge_align.cpp:1039, :1081): the same, and mask > 0
+ * (mask: H x W bytes) */
+int ea_problem_set_ref_frame_masked(ea_problem *p, const uint8_t *bgr, const uint8_t *mask, const uint16_t *depth,
+                                    int height, int width, double z_scaling, int threshold);
 /* Current frame: replaces get_distance_transform (utils.cpp:38-83) + cv2eigen + Grid2D (:201-206, :258):
  * edge map (same gradient, > threshold) -> [3x3 median] -> 3x3 chamfer DT (DIST_L2, mask 3) -> [min-max
  * normalise to [0,1]] written straight into the problem's DT image in HBM. */

@@ -6,7 +6,7 @@ reference's only recorded log (standalone/README.md:34).  tests/test_preprocess_
 that check.
 
 Follows (ref = /root/reference):
-  get_aX                  ref: standalone/utils.cpp:201-281
+  get_aX / get_aX_mask    ref: standalone/utils.cpp:201-281, :283-369
   get_distance_transform  ref: standalone/utils.cpp:38-83
   get_distance_transform2 / _masked / _NoNormalize / _masked_NoNormalize   ref: standalone/utils.cpp:85-199
   get_aX_canny            ref: standalone/utils.cpp:371-462
@@ -72,8 +72,9 @@ def edge_strength(img_bgr):
     return laplacian3_abs_u8(rgb2gray_u8(gaussian_blur3_u8(img_bgr)))
 
 
-def get_aX(img_bgr, depth_u16, fx, fy, cx, cy, z_scaling=5000.0, threshold=35):
-    """ref: utils.cpp:201-281.  Returns (a_X 4xN float64 in raster order, (v,u) index arrays)."""
+def get_aX(img_bgr, depth_u16, fx, fy, cx, cy, z_scaling=5000.0, threshold=35, mask_u8=None):
+    """ref: utils.cpp:201-281; with `mask_u8`: get_aX_mask, utils.cpp:283-369 (also requires mask > 0).
+    Returns (a_X 4xN float64 in raster order, (v,u) index arrays)."""
     grad = edge_strength(img_bgr)
     H, W = grad.shape
     Z = depth_u16.astype(np.float64) / float(z_scaling)
@@ -82,6 +83,8 @@ def get_aX(img_bgr, depth_u16, fx, fy, cx, cy, z_scaling=5000.0, threshold=35):
     X = (u - cx) * Z / fx
     Y = (v - cy) * Z / fy
     keep = (grad.astype(np.float64) > threshold) & (Z > 0)
+    if mask_u8 is not None:
+        keep &= mask_u8 > 0
     vv, uu = np.nonzero(keep)  # raster order: v outer, u inner
     a_X = np.stack([X[vv, uu], Y[vv, uu], Z[vv, uu], np.ones(vv.size)], axis=0)
     return a_X, (vv, uu)

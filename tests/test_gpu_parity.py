@@ -393,6 +393,25 @@ def test_c3_pyramid_coarse_to_fine(hip):
     assert np.linalg.norm(t - levels[0]["t_true"]) < 1e-3
 
 
+def test_c3_pyramid_driver(hip):
+    """ea_solve_pyramid == the level-by-level loop above, through one C-ABI call."""
+    levels = synth.config_c3_levels()
+    Ps = []
+    for lv in levels:
+        P = hip.Problem(*lv["K"], dtype=hip.EA_F32)
+        P.set_points(lv["xyz"]); P.set_dt_grid(lv["grid"])
+        Ps.append(P)
+    q, t = Q0.copy(), T0.copy()
+    for P in reversed(Ps):
+        q, t, _ = P.solve(q, t)
+    q2, t2, ss = hip.solve_pyramid(Ps, Q0, T0)
+    assert np.array_equal(q, q2) and np.array_equal(t, t2)
+    assert len(ss) == 3 and all(s["num_iterations"] >= 1 for s in ss)
+    assert synth.rotation_angle_between(q2, levels[0]["q_true"]) < 1e-4 and np.linalg.norm(t2 - levels[0]["t_true"]) < 1e-3
+    for P in Ps:
+        P.close()
+
+
 def test_wave_reduce_primitives(hip):
     """The cross-lane building blocks of the fused kernel on real hardware: write-masked DPP adds
     (row_mirror / row_half_mirror), v_permlane16/32_swap, quad_perm — against exact integer sums."""

@@ -243,3 +243,20 @@ def test_canny_frames_to_pose_end_to_end(hip, oracle, frames):
     assert np.abs(q - qo).max() < 1e-9 and np.abs(t - to).max() < 1e-9
     assert s["final_cost"] == pytest.approx(so["final_cost"], rel=1e-10)
     P.close()
+
+
+def test_masked_edge_points_bit_exact(hip, frames):
+    """get_aX_mask (ref: utils.cpp:283-369): gradient > 35 && depth > 0 && mask > 0."""
+    pp = frames["pp"]
+    H, W = frames["depth1"].shape
+    rng = np.random.default_rng(11)
+    mask = (rng.random((H, W)) < 0.6).astype(np.uint8) * rng.integers(1, 256, (H, W)).astype(np.uint8)
+    mask[100:300, 150:500] = 0
+    aX, _ = pp.get_aX(frames["rgb1"], frames["depth1"], *K, mask_u8=mask)
+    P = hip.Problem(*K, dtype=hip.EA_F64)
+    P.set_ref_frame(frames["rgb1"], frames["depth1"], mask=mask)
+    assert 0 < P.num_points == aX.shape[1] < 44457
+    assert np.array_equal(P.get_points(), aX[:3].T)
+    P.set_ref_frame(frames["rgb1"], frames["depth1"], mask=np.zeros((H, W), np.uint8))
+    assert P.num_points == 0
+    P.close()
