@@ -31,6 +31,7 @@ EXPORTED = [
     "ea_solve_pyramid", "ea_batch_bench_eval", "ea_batch_bench_kernel", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
     "ea_problem_set_ref_frame", "ea_problem_set_ref_frame_masked", "ea_problem_set_now_frame", "ea_problem_debug_now_frame",
     "ea_problem_set_ref_frame_canny", "ea_problem_set_now_frame_canny", "ea_problem_debug_now_frame_canny",
+    "ea_problem_set_ref_frame_ros", "ea_problem_set_now_frame_ros", "ea_problem_debug_now_frame_ros",
     "ea_problem_get_points", "ea_problem_get_dt",
     "ea_problem_set_distortion", "ea_problem_set_second_camera", "ea_problem_add_term", "ea_problem_clear_terms",
 ]
@@ -121,6 +122,9 @@ def load():
     L.ea_problem_set_ref_frame.argtypes = [vp, u8p, u16p, C.c_int, C.c_int, C.c_double, C.c_int]
     L.ea_problem_set_now_frame.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.ea_problem_set_ref_frame_masked.argtypes = [vp, u8p, u8p, u16p, C.c_int, C.c_int, C.c_double, C.c_int]
+    L.ea_problem_set_ref_frame_ros.argtypes = [vp, u8p, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_double, C.c_double]
+    L.ea_problem_set_now_frame_ros.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_double, C.c_double]
+    L.ea_problem_debug_now_frame_ros.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_double, C.c_double, u8p, C.POINTER(C.c_float)]
     L.ea_problem_set_ref_frame_canny.argtypes = [vp, u8p, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
     L.ea_problem_set_now_frame_canny.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double]
     L.ea_problem_debug_now_frame_canny.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double,
@@ -284,6 +288,28 @@ class Problem:
                                                        edges.ctypes.data_as(u8), cham.ctypes.data_as(C.POINTER(C.c_int32)),
                                                        dt.ctypes.data_as(C.POINTER(C.c_float)), C.byref(rounds)))
         return dict(edges=edges, chamfer=cham, dt=dt, hysteresis_launches=rounds.value)
+
+    def set_ref_frame_ros(self, bgr, depth_f32, t1=150.0, t2=100.0):
+        """SolveEA::setRefFrame on the GPU (ref: src/SolveEA.cpp:29-82)"""
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        depth_f32 = np.ascontiguousarray(depth_f32, dtype=np.float32)
+        H, W = depth_f32.shape
+        assert bgr.shape == (H, W, 3)
+        _check(load().ea_problem_set_ref_frame_ros(self._h, bgr.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                   depth_f32.ctypes.data_as(C.POINTER(C.c_float)), H, W, t1, t2))
+
+    def set_now_frame_ros(self, bgr, t1=150.0, t2=100.0, debug=False):
+        """SolveEA::setNowFrame on the GPU (ref: src/SolveEA.cpp:86-119)"""
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        H, W = bgr.shape[:2]
+        u8 = C.POINTER(C.c_uint8)
+        if not debug:
+            _check(load().ea_problem_set_now_frame_ros(self._h, bgr.ctypes.data_as(u8), H, W, t1, t2))
+            return None
+        edges = np.zeros((H, W), np.uint8); dt = np.zeros((H, W), np.float32)
+        _check(load().ea_problem_debug_now_frame_ros(self._h, bgr.ctypes.data_as(u8), H, W, t1, t2, edges.ctypes.data_as(u8),
+                                                     dt.ctypes.data_as(C.POINTER(C.c_float))))
+        return dict(edges=edges, dt=dt)
 
     def get_points(self):
         n = self.num_points

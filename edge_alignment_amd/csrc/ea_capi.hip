@@ -32,13 +32,16 @@ hipError_t launch_selftest_reduce(const float *in, float *a, float *b, float *c,
 // ea_preprocess.hip
 hipError_t launch_edge_strength(const uint8_t *bgr, int H, int W, uint8_t *gray, uint8_t *lap, hipStream_t s);
 hipError_t launch_threshold_median(const uint8_t *lap, int H, int W, int thr, int median, uint8_t *mask, hipStream_t s);
-hipError_t launch_chamfer(const uint8_t *mask, int H, int W, int *G, int *scratch, int *dist_fix, unsigned int *minmax,
-                          hipStream_t s);
-hipError_t launch_canny(const uint8_t *bgr, int H, int W, int low, int high, const uint8_t *keep, uint8_t *gray, int *mag,
-                        uint8_t *dir, uint8_t *label, uint8_t *edges, uint8_t *inv, int *changed, int *rounds_out,
+hipError_t launch_chamfer(const uint8_t *mask, int H, int W, int *G, int *scratch, int *dist_fix, float *dist_f32,
+                          unsigned int *minmax, hipStream_t s);
+hipError_t launch_canny(const uint8_t *bgr, int H, int W, int low, int high, int l2_bgr, const uint8_t *keep, uint8_t *gray,
+                        int *mag, uint8_t *dir, uint8_t *label, uint8_t *edges, uint8_t *inv, int *changed, int *rounds_out,
                         hipStream_t s);
-hipError_t launch_dt_store(int dtype, const int *dist_fix, int H, int W, const unsigned int *minmax, int normalize,
-                           double lo, double hi, void *dst, int pitch, float *plain, hipStream_t s);
+hipError_t launch_edge_scatter_ros(int dtype, const uint8_t *edges, const float *depth, int H, int W, const int *block_offsets,
+                                   double fx, double fy, double cx, double cy, void *X, void *Y, void *Z, int capacity,
+                                   hipStream_t s);
+hipError_t launch_dt_store(int dtype, const int *dist_fix, const float *dist_f32, int H, int W, const unsigned int *minmax,
+                           int normalize, double lo, double hi, void *dst, int pitch, float *plain, hipStream_t s);
 hipError_t launch_gate_by_mask(uint8_t *grad, const uint8_t *mask, int H, int W, hipStream_t s);
 hipError_t launch_edge_count_scan(const uint8_t *lap, const uint16_t *depth, int H, int W, int thr, int *block_counts,
                                   int *total, hipStream_t s);
@@ -1026,13 +1029,14 @@ extern "C" int ea_problem_set_ref_frame_masked(ea_problem *p, const uint8_t *bgr
 
 // mask (0 = edge / DT source) -> chamfer DT -> [normalise to [lo, hi]] -> the problem's padded DT image
 static int dt_from_mask(ea_problem *p, WsCarver &ws, const uint8_t *d_mask, int height, int width, int normalize,
-                        double lo, double hi, int **dist_out, float **plain_out) {
+                        double lo, double hi, int **dist_out, float **plain_out, bool precise = false) {
   const size_t np = (size_t)height * width;
-  int *d_G = ws.take<int>(np), *d_dist = ws.take<int>(np);
+  int *d_G = ws.take<int>(np), *d_dist = ws.take<int>(np);  // d_dist doubles as the float32 distance when `precise`
   int *d_scan = ws.take<int>(4 * (size_t)((height + 31) / 32) * width);
   float *d_plain = ws.take<float>(np);
   unsigned int *d_minmax = ws.take<unsigned int>(2);
-  HIPCHK(launch_chamfer(d_mask, height, width, d_G, d_scan, d_dist, d_minmax, nullptr));
+  float *d_dist_f32 = precise ? reinterpret_cast<float *>(d_dist) : nullptr;
+  HIPCHK(launch_chamfer(d_mask, height, width, d_G, d_scan, d_dist, d_dist_f32, d_minmax, nullptr));
   {
     if (p->d_dt) { (void)hipFree(p->d_dt); p->d_dt = nullptr; }
     p->W = width; p->H = height;
@@ -1040,7 +1044,8 @@ static int dt_from_mask(ea_problem *p, WsCarver &ws, const uint8_t *d_mask, int 
     const size_t esz = p->dtype == EA_F32 ? 4 : 8;
     HIPCHK(hipMalloc(&p->d_dt, (size_t)p->pitch * (size_t)(height + 2 * kImagePad) * esz));
   }
-  HIPCHK(launch_dt_store(p->dtype, d_dist, height, width, d_minmax, normalize, lo, hi, p->d_dt, p->pitch, d_plain, nullptr));
+  HIPCHK(launch_dt_store(p->dtype, d_dist, d_dist_f32, height, width, d_minmax, normalize, lo, hi, p->d_dt, p->pitch, d_plain,
+                         nullptr));
   HIPCHK(hipDeviceSynchronize());
   p->version++;
   if (dist_out) *dist_out = d_dist;
@@ -1061,15 +1066,15 @@ static int run_dt(ea_problem *p, WsCarver &ws, const uint8_t *d_bgr, int height,
 
 // blur 3x3 -> gray -> Canny(low, high) [-> AND (keep > 1)]: edge map and its inverse in the workspace
 static int run_canny(WsCarver &ws, const uint8_t *d_bgr, const uint8_t *d_keep, int height, int width, int low, int high,
-                     uint8_t **edges_out, uint8_t **inv_out, int *rounds_out) {
+                     uint8_t **edges_out, uint8_t **inv_out, int *rounds_out, int l2_bgr = 0) {
   const size_t np = (size_t)height * width;
   uint8_t *d_gray = ws.take<uint8_t>(np);
   int *d_mag = ws.take<int>(np);
   uint8_t *d_dir = ws.take<uint8_t>(np), *d_label = ws.take<uint8_t>(np);
   uint8_t *d_edges = ws.take<uint8_t>(np), *d_inv = ws.take<uint8_t>(np);
   int *d_changed = ws.take<int>(1);
-  HIPCHK(launch_canny(d_bgr, height, width, low, high, d_keep, d_gray, d_mag, d_dir, d_label, d_edges, d_inv, d_changed,
-                      rounds_out, nullptr));
+  HIPCHK(launch_canny(d_bgr, height, width, low, high, l2_bgr, d_keep, d_gray, d_mag, d_dir, d_label, d_edges, d_inv,
+                      d_changed, rounds_out, nullptr));
   *edges_out = d_edges;
   *inv_out = d_inv;
   return EA_OK;
@@ -1154,6 +1159,97 @@ static int now_frame_canny(ea_problem *p, const uint8_t *bgr, const uint8_t *mas
   if (chamfer_fix_out) HIPCHK(hipMemcpy(chamfer_fix_out, d_dist, np * 4, hipMemcpyDeviceToHost));
   if (dt_out) HIPCHK(hipMemcpy(dt_out, d_plain, np * 4, hipMemcpyDeviceToHost));
   return EA_OK;
+}
+
+// ---- ROS flavour of the producers (ref: src/SolveEA.cpp:29-119): Canny(rgb, 150, 100, 3, true) on the 3-channel image
+static void ros_thresholds(double t1, double t2, int *low, int *high) {
+  // cv::Canny with L2gradient: min(t, 32767)^2, ordered
+  double lo = std::min(t1, t2), hi = std::max(t1, t2);
+  lo = std::min(32767.0, lo); hi = std::min(32767.0, hi);
+  if (lo > 0) lo *= lo;
+  if (hi > 0) hi *= hi;
+  *low = (int)std::floor(lo);
+  *high = (int)std::floor(hi);
+}
+
+// SolveEA::setRefFrame (src/SolveEA.cpp:29-82): every edge pixel, depth CV_32F in metres, Z == 0 -> 1.0
+extern "C" int ea_problem_set_ref_frame_ros(ea_problem *p, const uint8_t *bgr, const float *depth, int height, int width,
+                                            double threshold1, double threshold2) {
+  int rc = check_frame_args(p, bgr, height, width);
+  if (rc != EA_OK) return rc;
+  if (!depth) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(p->device));
+  rc = ensure_ws(p, frame_ws_bytes(height, width));
+  if (rc != EA_OK) return rc;
+  const size_t np = (size_t)height * width;
+  WsCarver ws{p->ws};
+  uint8_t *d_bgr = ws.take<uint8_t>(np * 3);
+  float *d_depth = ws.take<float>(np);
+  const int nblocks = (int)((np + 1023) / 1024);
+  int *d_counts = ws.take<int>(nblocks + 1);
+  int *d_total = d_counts + nblocks;
+  HIPCHK(hipMemcpyAsync(d_bgr, bgr, np * 3, hipMemcpyHostToDevice, nullptr));
+  HIPCHK(hipMemcpyAsync(d_depth, depth, np * 4, hipMemcpyHostToDevice, nullptr));
+  int lo, hi;
+  ros_thresholds(threshold1, threshold2, &lo, &hi);
+  uint8_t *d_edges, *d_inv;
+  rc = run_canny(ws, d_bgr, nullptr, height, width, lo, hi, &d_edges, &d_inv, nullptr, /*l2_bgr=*/1);
+  if (rc != EA_OK) return rc;
+  HIPCHK(launch_edge_count_scan(d_edges, nullptr, height, width, 0, d_counts, d_total, nullptr));
+  int total = 0;
+  HIPCHK(hipMemcpy(&total, d_total, sizeof(int), hipMemcpyDeviceToHost));
+  free_points(p);
+  p->version++;
+  if (total > 0) {
+    const size_t esz = p->dtype == EA_F32 ? 4 : 8;
+    HIPCHK(hipMalloc(&p->d_x, (size_t)total * esz));
+    HIPCHK(hipMalloc(&p->d_y, (size_t)total * esz));
+    HIPCHK(hipMalloc(&p->d_z, (size_t)total * esz));
+    p->own_points = true;
+    HIPCHK(launch_edge_scatter_ros(p->dtype, d_edges, d_depth, height, width, d_counts, p->cam.fx, p->cam.fy, p->cam.cx,
+                                   p->cam.cy, p->d_x, p->d_y, p->d_z, total, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+  }
+  p->n = total;
+  return EA_OK;
+}
+
+// SolveEA::setNowFrame (src/SolveEA.cpp:86-119): Canny -> 255 - edges -> distanceTransform(L2, DIST_MASK_PRECISE) ->
+// normalize to [0, 255].  An image without a single edge has no defined result upstream either: EA_ERR_STATE.
+extern "C" int ea_problem_debug_now_frame_ros(ea_problem *p, const uint8_t *bgr, int height, int width, double threshold1,
+                                              double threshold2, uint8_t *edges_out, float *dt_out) {
+  int rc = check_frame_args(p, bgr, height, width);
+  if (rc != EA_OK) return rc;
+  HIPCHK(hipSetDevice(p->device));
+  rc = ensure_ws(p, frame_ws_bytes(height, width));
+  if (rc != EA_OK) return rc;
+  const size_t np = (size_t)height * width;
+  WsCarver ws{p->ws};
+  uint8_t *d_bgr = ws.take<uint8_t>(np * 3);
+  const int nblocks = (int)((np + 1023) / 1024);
+  int *d_counts = ws.take<int>(nblocks + 1);
+  HIPCHK(hipMemcpyAsync(d_bgr, bgr, np * 3, hipMemcpyHostToDevice, nullptr));
+  int lo, hi;
+  ros_thresholds(threshold1, threshold2, &lo, &hi);
+  uint8_t *d_edges, *d_inv;
+  rc = run_canny(ws, d_bgr, nullptr, height, width, lo, hi, &d_edges, &d_inv, nullptr, /*l2_bgr=*/1);
+  if (rc != EA_OK) return rc;
+  HIPCHK(launch_edge_count_scan(d_edges, nullptr, height, width, 0, d_counts, d_counts + nblocks, nullptr));
+  int total = 0;
+  HIPCHK(hipMemcpy(&total, d_counts + nblocks, sizeof(int), hipMemcpyDeviceToHost));
+  if (total == 0) return fail(EA_ERR_STATE, "no edge in the frame: the exact distance transform is undefined");
+  int *d_dist;
+  float *d_plain;
+  rc = dt_from_mask(p, ws, d_inv, height, width, 1, 0.0, 255.0, &d_dist, &d_plain, /*precise=*/true);
+  if (rc != EA_OK) return rc;
+  if (edges_out) HIPCHK(hipMemcpy(edges_out, d_edges, np, hipMemcpyDeviceToHost));
+  if (dt_out) HIPCHK(hipMemcpy(dt_out, d_plain, np * 4, hipMemcpyDeviceToHost));
+  return EA_OK;
+}
+
+extern "C" int ea_problem_set_now_frame_ros(ea_problem *p, const uint8_t *bgr, int height, int width, double threshold1,
+                                            double threshold2) {
+  return ea_problem_debug_now_frame_ros(p, bgr, height, width, threshold1, threshold2, nullptr, nullptr);
 }
 
 extern "C" int ea_problem_set_now_frame_canny(ea_problem *p, const uint8_t *bgr, const uint8_t *mask, int height, int width,

@@ -2,6 +2,7 @@
 //   edge-point extractor  = get_aX                  ref: standalone/utils.cpp:201-281
 //   DT image producer     = get_distance_transform  ref: standalone/utils.cpp:38-83
 //   Canny flavour         = get_distance_transform2* / get_aX_canny   ref: utils.cpp:85-199, :371-462
+//   ROS flavour           = SolveEA::setRefFrame / setNowFrame        ref: src/SolveEA.cpp:29-119
 // so that a frame pair goes from raw images to a solved pose without the CPU touching a pixel.
 //
 // All of it is 8/16/32-bit integer work plus one float scaling — bit-exact against
@@ -17,6 +18,9 @@
 //                                    non-maximum suppression by the fixed-point tan(22.5 deg) test
 //                                    (TG22 = 13573, shift 15; magnitudes outside the image are 0),
 //                                    hysteresis over the 8-neighbourhood
+//   Canny(bgr, 150, 100, 3, true):   per pixel the channel with the largest dx^2 + dy^2 (first on ties), squared
+//                                    thresholds, the same suppression and hysteresis
+//   distanceTransform(DIST_L2, DIST_MASK_PRECISE): float32 sqrt((float)dx^2 + (float)dy^2) of the nearest zero pixel
 //
 // The two-pass raster chamfer of OpenCV is inherently sequential; what it computes is the exact
 // shortest 8-connected path length, which has the closed form  a*max(dx,dy) + (b-a)*min(dx,dy).
@@ -136,6 +140,32 @@ __global__ void ea_sobel_mag_kernel(const uint8_t *__restrict__ gray, int H, int
   if (y < tg22x) cls = 0;
   else if (y > tg22x + (x << 16)) cls = 1;
   else cls = 2 | (((dx ^ dy) < 0) ? 4 : 0);
+  dir[(size_t)v * W + u] = (uint8_t)cls;
+}
+
+// ROS flavour (ref: src/SolveEA.cpp:46, :102): cv::Canny on the 3-channel image with L2gradient = true -- the channel
+// with the largest dx^2 + dy^2 (the first one on ties) supplies dx, dy; the magnitude is that sum of squares
+__global__ void ea_sobel_mag_l2_bgr_kernel(const uint8_t *__restrict__ bgr, int H, int W, int *__restrict__ mag,
+                                           uint8_t *__restrict__ dir) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
+  if (u >= W) return;
+  const int ym = max(v - 1, 0), yp = min(v + 1, H - 1), xm = max(u - 1, 0), xp = min(u + 1, W - 1);
+  int bdx = 0, bdy = 0, bm = -1;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    auto P = [&](int yy, int xx) { return (int)bgr[((size_t)yy * W + xx) * 3 + c]; };
+    const int dx = (P(ym, xp) + 2 * P(v, xp) + P(yp, xp)) - (P(ym, xm) + 2 * P(v, xm) + P(yp, xm));
+    const int dy = (P(yp, xm) + 2 * P(yp, u) + P(yp, xp)) - (P(ym, xm) + 2 * P(ym, u) + P(ym, xp));
+    const int m = dx * dx + dy * dy;
+    if (m > bm) { bm = m; bdx = dx; bdy = dy; }
+  }
+  mag[(size_t)v * W + u] = bm;
+  const long long x = abs(bdx), y = (long long)abs(bdy) << 15;
+  const long long tg22x = x * 13573;
+  int cls;
+  if (y < tg22x) cls = 0;
+  else if (y > tg22x + (x << 16)) cls = 1;
+  else cls = 2 | (((bdx ^ bdy) < 0) ? 4 : 0);
   dir[(size_t)v * W + u] = (uint8_t)cls;
 }
 
@@ -326,15 +356,62 @@ __global__ void ea_chamfer_row_kernel(const int *__restrict__ G, const int *__re
   atomicMax(&minmax[1], __float_as_uint(lmax));
 }
 
+// Exact Euclidean variant of the row pass (DIST_MASK_PRECISE): the same per-column distances G, squared cost
+// dx^2 + G(x')^2, search outwards until dx^2 alone reaches the best.  The result is formed like OpenCV's row pass:
+// sqrt((float)dx^2 + (float)dy^2) in float32.  dist_f32 takes the place of the fixed-point chamfer distance.
+__global__ void ea_edt_row_kernel(const int *__restrict__ G, const int *__restrict__ carry_dn,
+                                  const int *__restrict__ carry_up, int H, int W, float *__restrict__ dist_f32,
+                                  unsigned int *__restrict__ minmax) {
+  extern __shared__ int s_g[];
+  const int y = blockIdx.x;
+  const int seg = y / kSegRows, y0 = seg * kSegRows, y1 = min(H, y0 + kSegRows);
+  for (int x = threadIdx.x; x < W; x += blockDim.x) {
+    int g = G[(size_t)y * W + x];
+    const int cd = carry_dn[(size_t)seg * W + x], cu = carry_up[(size_t)seg * W + x];
+    if (cd < kNoFeature) g = min(g, cd + (y - y0 + 1));
+    if (cu < kNoFeature) g = min(g, cu + (y1 - y));
+    s_g[x] = g;
+  }
+  __syncthreads();
+  float lmin = 3.0e38f, lmax = 0.0f;
+  for (int x = threadIdx.x; x < W; x += blockDim.x) {
+    long long best = 1ll << 40;
+    int bdx = 0, bg = 0;
+    {
+      const int g = s_g[x];
+      if (g < kNoFeature) { best = (long long)g * g; bg = g; }
+    }
+    for (int dx = 1; dx < W; ++dx) {
+      const long long d2 = (long long)dx * dx;
+      if (d2 >= best) break;
+      const int xl = x - dx, xr = x + dx;
+      if (xl < 0 && xr >= W) break;
+      if (xl >= 0) {
+        const int g = s_g[xl];
+        if (g < kNoFeature && d2 + (long long)g * g < best) { best = d2 + (long long)g * g; bdx = dx; bg = g; }
+      }
+      if (xr < W) {
+        const int g = s_g[xr];
+        if (g < kNoFeature && d2 + (long long)g * g < best) { best = d2 + (long long)g * g; bdx = dx; bg = g; }
+      }
+    }
+    const float f = sqrtf(__fadd_rn((float)((long long)bdx * bdx), (float)((long long)bg * bg)));  // correctly rounded (HIP default); __fsqrt_rn is the native approximation
+    dist_f32[(size_t)y * W + x] = f;
+    lmin = fminf(lmin, f); lmax = fmaxf(lmax, f);
+  }
+  atomicMin(&minmax[0], __float_as_uint(lmin));
+  atomicMax(&minmax[1], __float_as_uint(lmax));
+}
+
 // dist (16.16 fixed) -> float32 [-> min-max normalised] -> padded image of the problem dtype
 template <typename T>
-__global__ void ea_dt_store_kernel(const int *__restrict__ dist_fix, int H, int W, const unsigned int *__restrict__ minmax,
-                                   int normalize, double lo, double hi, T *__restrict__ dst, int pitch,
-                                   float *__restrict__ plain /*nullable HxW*/) {
+__global__ void ea_dt_store_kernel(const int *__restrict__ dist_fix, const float *__restrict__ dist_f32 /* one of the two */,
+                                   int H, int W, const unsigned int *__restrict__ minmax, int normalize, double lo, double hi,
+                                   T *__restrict__ dst, int pitch, float *__restrict__ plain /*nullable HxW*/) {
   const int pu = blockIdx.x * blockDim.x + threadIdx.x, pv = blockIdx.y;  // padded coordinates
   if (pu >= W + 2 * kImagePad) return;
   const int u = min(max(pu - kImagePad, 0), W - 1), v = min(max(pv - kImagePad, 0), H - 1);
-  float f = (float)((double)dist_fix[(size_t)v * W + u] * (1.0 / 65536.0));
+  float f = dist_f32 ? dist_f32[(size_t)v * W + u] : (float)((double)dist_fix[(size_t)v * W + u] * (1.0 / 65536.0));
   if (normalize) {
     // cv::normalize(NORM_MINMAX, lo, hi) on CV_32F: scale/shift in double, applied in float
     const double smin = (double)__uint_as_float(minmax[0]), smax = (double)__uint_as_float(minmax[1]);
@@ -358,7 +435,8 @@ __global__ void ea_gate_by_mask_kernel(uint8_t *__restrict__ grad, const uint8_t
 constexpr int kScanBlock = 1024;
 
 __device__ __forceinline__ bool edge_flag(const uint8_t *lap, const uint16_t *depth, size_t i, int thr) {
-  return lap[i] > thr && depth[i] > 0;  // ref: utils.cpp:258-262  grad > threshold && Z > 0
+  // ref: utils.cpp:258-262  grad > threshold && Z > 0; depth == nullptr: the ROS flavour keeps every edge pixel
+  return lap[i] > thr && (!depth || depth[i] > 0);
 }
 
 __global__ void ea_edge_count_kernel(const uint8_t *__restrict__ lap, const uint16_t *__restrict__ depth, int npix,
@@ -428,6 +506,33 @@ __global__ void ea_edge_scatter_kernel(const uint8_t *__restrict__ lap, const ui
   X[off] = (T)x; Y[off] = (T)y; Z[off] = (T)z;
 }
 
+// ROS flavour of the scatter (ref: src/SolveEA.cpp:61-78): every edge pixel, float depth in metres, Z == 0 -> 1.0,
+// X = Z * (xx - cx) / fx
+template <typename T>
+__global__ void ea_edge_scatter_ros_kernel(const uint8_t *__restrict__ edges, const float *__restrict__ depth, int H, int W,
+                                           const int *__restrict__ block_offsets, double fx, double fy, double cx, double cy,
+                                           T *__restrict__ X, T *__restrict__ Y, T *__restrict__ Z, int capacity) {
+  __shared__ int s_cnt[kScanBlock / 64];
+  const int npix = H * W;
+  const int i = blockIdx.x * kScanBlock + threadIdx.x;
+  const bool f = i < npix && edges[i] > 0;
+  const unsigned long long m = __ballot(f);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) s_cnt[wave] = __popcll(m);
+  __syncthreads();
+  if (!f) return;
+  int off = block_offsets[blockIdx.x];
+  for (int w = 0; w < wave; ++w) off += s_cnt[w];
+  off += __popcll(m & ((1ull << lane) - 1ull));
+  if (off >= capacity) return;
+  const int v = i / W, u = i - v * W;
+  double z = (double)depth[i];
+  z = (z == 0.0) ? 1.0 : z;
+  const double x = __dmul_rn(z, (double)u - cx) / fx;
+  const double y = __dmul_rn(z, (double)v - cy) / fy;
+  X[off] = (T)x; Y[off] = (T)y; Z[off] = (T)z;
+}
+
 // ---- launchers ----------------------------------------------------------------------------------
 
 hipError_t launch_edge_strength(const uint8_t *bgr, int H, int W, uint8_t *gray, uint8_t *lap, hipStream_t s) {
@@ -444,8 +549,9 @@ hipError_t launch_threshold_median(const uint8_t *lap, int H, int W, int thr, in
 }
 
 // scratch: 4 * ceil(H/32) * W ints
-hipError_t launch_chamfer(const uint8_t *mask, int H, int W, int *G, int *scratch, int *dist_fix, unsigned int *minmax,
-                          hipStream_t s) {
+// dist_fix (3x3 chamfer, 16.16 fixed point) or, when dist_f32 is given, the exact Euclidean distance in float32
+hipError_t launch_chamfer(const uint8_t *mask, int H, int W, int *G, int *scratch, int *dist_fix, float *dist_f32,
+                          unsigned int *minmax, hipStream_t s) {
   hipError_t e = hipMemsetAsync(minmax, 0xff, sizeof(unsigned int), s);  // min slot = max uint
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(minmax + 1, 0, sizeof(unsigned int), s);
@@ -455,30 +561,39 @@ hipError_t launch_chamfer(const uint8_t *mask, int H, int W, int *G, int *scratc
       *carry_up = scratch + 3 * (size_t)S * W;
   hipLaunchKernelGGL(ea_column_local_kernel, dim3((W + 63) / 64, S), dim3(64), 0, s, mask, H, W, G, end_dn, end_up);
   hipLaunchKernelGGL(ea_column_carry_kernel, dim3((W + 63) / 64), dim3(64), 0, s, end_dn, end_up, H, W, S, carry_dn, carry_up);
-  hipLaunchKernelGGL(ea_chamfer_row_kernel, dim3(H), dim3(256), (size_t)W * sizeof(int), s, G, carry_dn, carry_up, H, W,
-                     dist_fix, minmax);
+  if (dist_f32)
+    hipLaunchKernelGGL(ea_edt_row_kernel, dim3(H), dim3(256), (size_t)W * sizeof(int), s, G, carry_dn, carry_up, H, W,
+                       dist_f32, minmax);
+  else
+    hipLaunchKernelGGL(ea_chamfer_row_kernel, dim3(H), dim3(256), (size_t)W * sizeof(int), s, G, carry_dn, carry_up, H, W,
+                       dist_fix, minmax);
   return hipGetLastError();
 }
 
-hipError_t launch_dt_store(int dtype, const int *dist_fix, int H, int W, const unsigned int *minmax, int normalize,
-                           double lo, double hi, void *dst, int pitch, float *plain, hipStream_t s) {
+hipError_t launch_dt_store(int dtype, const int *dist_fix, const float *dist_f32, int H, int W, const unsigned int *minmax,
+                           int normalize, double lo, double hi, void *dst, int pitch, float *plain, hipStream_t s) {
   dim3 block(256), grid((W + 2 * kImagePad + 255) / 256, H + 2 * kImagePad);
   if (dtype == 1)
-    hipLaunchKernelGGL((ea_dt_store_kernel<float>), grid, block, 0, s, dist_fix, H, W, minmax, normalize, lo, hi, (float *)dst, pitch, plain);
+    hipLaunchKernelGGL((ea_dt_store_kernel<float>), grid, block, 0, s, dist_fix, dist_f32, H, W, minmax, normalize, lo, hi, (float *)dst, pitch, plain);
   else
-    hipLaunchKernelGGL((ea_dt_store_kernel<double>), grid, block, 0, s, dist_fix, H, W, minmax, normalize, lo, hi, (double *)dst, pitch, plain);
+    hipLaunchKernelGGL((ea_dt_store_kernel<double>), grid, block, 0, s, dist_fix, dist_f32, H, W, minmax, normalize, lo, hi, (double *)dst, pitch, plain);
   return hipGetLastError();
 }
 
 // blur 3x3 -> gray -> Canny(low, high): labels are left in `label` (2 = edge after the hysteresis), `edges` is the
 // CV_8U edge map [AND keep > 1], `inv` = 255 - edges.  mag: H*W ints, dir/label/edges/inv: H*W bytes,
 // changed: one int in device memory, h_changed: its pinned host mirror (polled between hysteresis rounds).
-hipError_t launch_canny(const uint8_t *bgr, int H, int W, int low, int high, const uint8_t *keep, uint8_t *gray, int *mag,
-                        uint8_t *dir, uint8_t *label, uint8_t *edges, uint8_t *inv, int *changed, int *rounds_out,
+// l2_bgr != 0: the ROS flavour -- no blur / gray, Sobel on the three channels, L2 magnitude, (low, high) already squared
+hipError_t launch_canny(const uint8_t *bgr, int H, int W, int low, int high, int l2_bgr, const uint8_t *keep, uint8_t *gray,
+                        int *mag, uint8_t *dir, uint8_t *label, uint8_t *edges, uint8_t *inv, int *changed, int *rounds_out,
                         hipStream_t s) {
   dim3 block(256), grid((W + 255) / 256, H);
-  hipLaunchKernelGGL(ea_boxblur_gray_kernel, grid, block, 0, s, bgr, H, W, gray);
-  hipLaunchKernelGGL(ea_sobel_mag_kernel, grid, block, 0, s, gray, H, W, mag, dir);
+  if (l2_bgr) {
+    hipLaunchKernelGGL(ea_sobel_mag_l2_bgr_kernel, grid, block, 0, s, bgr, H, W, mag, dir);
+  } else {
+    hipLaunchKernelGGL(ea_boxblur_gray_kernel, grid, block, 0, s, bgr, H, W, gray);
+    hipLaunchKernelGGL(ea_sobel_mag_kernel, grid, block, 0, s, gray, H, W, mag, dir);
+  }
   hipLaunchKernelGGL(ea_canny_nms_kernel, grid, block, 0, s, mag, dir, H, W, low, high, label);
   // hysteresis rounds: four launches per check of the change flag (a launch that changes nothing is ~3 us, a
   // flag read-back is a stream synchronisation)
@@ -500,6 +615,19 @@ hipError_t launch_canny(const uint8_t *bgr, int H, int W, int low, int high, con
   if (rounds_out) *rounds_out = rounds;
   const int npix = H * W;
   hipLaunchKernelGGL(ea_canny_finish_kernel, dim3((npix + 255) / 256), block, 0, s, label, keep, npix, edges, inv);
+  return hipGetLastError();
+}
+
+hipError_t launch_edge_scatter_ros(int dtype, const uint8_t *edges, const float *depth, int H, int W, const int *block_offsets,
+                                   double fx, double fy, double cx, double cy, void *X, void *Y, void *Z, int capacity,
+                                   hipStream_t s) {
+  const int npix = H * W, nblocks = (npix + kScanBlock - 1) / kScanBlock;
+  if (dtype == 1)
+    hipLaunchKernelGGL((ea_edge_scatter_ros_kernel<float>), dim3(nblocks), dim3(kScanBlock), 0, s, edges, depth, H, W,
+                       block_offsets, fx, fy, cx, cy, (float *)X, (float *)Y, (float *)Z, capacity);
+  else
+    hipLaunchKernelGGL((ea_edge_scatter_ros_kernel<double>), dim3(nblocks), dim3(kScanBlock), 0, s, edges, depth, H, W,
+                       block_offsets, fx, fy, cx, cy, (double *)X, (double *)Y, (double *)Z, capacity);
   return hipGetLastError();
 }
 

@@ -3,10 +3,12 @@
 // Public surface kept: SolveEA(), setRefFrame(rgb, depth), setNowFrame(rgb, depth),
 // setAsCERESProblem(), _verify3dPts(), _sampleCERESProblem()  (src/ea.cpp:184-191 calls them in
 // that order).  The cv::Mat overloads exist only when OpenCV headers are present (they are not in
-// this image); their pre-processing (Canny, distanceTransform) is the producer side of the hot
-// path and stays on OpenCV there.  What this build owns is setAsCERESProblem(): the residual
-// blocks, the loss, the parameterisation and the DOGLEG solve (src/SolveEA.cpp:124-216) — run on
-// the GPU through the ceres:: facade.  OpenCV-free entry points feed the same members.
+// this image) and keep upstream's OpenCV calls.  The raw-buffer overloads of setRefFrame / setNowFrame
+// (bgr8 + float32 depth, what the cv::Mat arguments hold) run the same pre-processing on the GPU
+// (ea_problem_set_ref_frame_ros / ea_problem_set_now_frame_ros: Canny(150, 100, 3, true) on the 3-channel
+// image, DIST_MASK_PRECISE, normalisation to [0, 255], Z == 0 -> 1) and feed the same members.
+// setAsCERESProblem() — the residual blocks, the loss, the parameterisation and the DOGLEG solve
+// (src/SolveEA.cpp:124-216) — runs on the GPU through the ceres:: facade.
 // Upstream never returns the pose (App. D 4): getPose()/summary() are additions.
 #pragma once
 #include <cstdio>
@@ -66,6 +68,42 @@ class SolveEA {
   }
 #endif
 
+  // OpenCV-free forms of the same two calls (src/SolveEA.cpp:29-82, :86-119), pre-processing on the GPU.
+  // bgr: rows x cols x 3 bytes (bgr8, src/ea.cpp:34), depth: rows x cols float32 metres (NaN already set to 0, :56-58).
+  // Return false (and leave the members untouched) when the library reports an error, e.g. a frame without edges.
+  bool setRefFrame(const unsigned char *bgr, const float *depth, int rows, int cols) {
+    ea_problem *p = nullptr;
+    const ea_camera cam = {fx, fy, cx, cy};
+    if (ea_problem_create(&p, &cam, EA_F64, 0) != EA_OK) return false;
+    bool ok = ea_problem_set_ref_frame_ros(p, bgr, depth, rows, cols, 150, 100) == EA_OK;
+    if (ok) {
+      const long long n = ea_problem_num_points(p);
+      std::vector<double> pts((size_t)3 * (size_t)n);
+      ok = ea_problem_get_points(p, pts.data(), n) == EA_OK;
+      if (ok) setRefPoints(pts.data(), (int)n);
+    }
+    ea_problem_destroy(p);
+    return ok;
+  }
+  bool setNowFrame(const unsigned char *bgr, const float * /*depth*/, int rows, int cols) {
+    ea_problem *p = nullptr;
+    const ea_camera cam = {fx, fy, cx, cy};
+    if (ea_problem_create(&p, &cam, EA_F64, 0) != EA_OK) return false;
+    bool ok = ea_problem_set_now_frame_ros(p, bgr, rows, cols, 150, 100) == EA_OK;
+    if (ok) {
+      std::vector<double> img((size_t)rows * cols), colmajor((size_t)rows * cols);
+      int h = 0, w = 0;
+      ok = ea_problem_get_dt(p, img.data(), &h, &w) == EA_OK && h == rows && w == cols;
+      if (ok) {
+        for (int c = 0; c < cols; ++c)
+          for (int r = 0; r < rows; ++r) colmajor[(size_t)c * rows + r] = img[(size_t)r * cols + c];
+        setNowDistanceTransform(colmajor.data(), rows, cols);
+      }
+    }
+    ea_problem_destroy(p);
+    return ok;
+  }
+
   // list_edge_ref: 3 x N, column-major (src/SolveEA.cpp:55,73-75)
   void setRefPoints(const double *xyz_3xN, int N) { list_edge_ref.assign(xyz_3xN, xyz_3xN + 3 * (size_t)N); }
   // now_dist_transform_eig: rows x cols, column-major like Eigen::MatrixXd (src/SolveEA.cpp:110)
@@ -117,6 +155,7 @@ class SolveEA {
     for (int i = 0; i < 3; i++) t[i] = t_[i];
   }
   const ceres::Solver::Summary &summary() const { return summary_; }
+  int numRefPoints() const { return (int)(list_edge_ref.size() / 3); }
   bool verbose = false;
 
  private:

@@ -257,6 +257,17 @@ int ea_problem_debug_now_frame_canny(ea_problem *p, const uint8_t *bgr, const ui
                                      double low_threshold, double high_threshold, int normalize, double norm_lo,
                                      double norm_hi, uint8_t *edges_out, int32_t *chamfer_fix_out, float *dt_out,
                                      int *hysteresis_launches);
+/* ROS flavour of the two producers (src/SolveEA.cpp:29-119): cv::Canny(rgb, 150, 100, 3, true) on the 3-channel image
+ * (per pixel the channel with the largest dx^2 + dy^2; squared thresholds).
+ * setRefFrame (:29-82): every edge pixel gives a point; depth: H x W float32 in metres, Z == 0 -> 1.0. */
+int ea_problem_set_ref_frame_ros(ea_problem *p, const uint8_t *bgr, const float *depth, int height, int width,
+                                 double threshold1, double threshold2);
+/* setNowFrame (:86-119): 255 - edges -> distanceTransform(DIST_L2, DIST_MASK_PRECISE) (exact Euclidean) -> normalize to
+ * [0, 255].  A frame without any edge returns EA_ERR_STATE.  The debug form copies the edge map / float32 DT back. */
+int ea_problem_set_now_frame_ros(ea_problem *p, const uint8_t *bgr, int height, int width, double threshold1,
+                                 double threshold2);
+int ea_problem_debug_now_frame_ros(ea_problem *p, const uint8_t *bgr, int height, int width, double threshold1,
+                                   double threshold2, uint8_t *edges_out, float *dt_out);
 /* read back what the problem holds in HBM: points (n x 3 doubles), DT image (H x W doubles, [v][u]) */
 int ea_problem_get_points(ea_problem *p, double *xyz, int64_t capacity);
 int ea_problem_get_dt(ea_problem *p, double *image, int *height, int *width);

@@ -10,11 +10,15 @@ Follows (ref = /root/reference):
   get_distance_transform  ref: standalone/utils.cpp:38-83
   get_distance_transform2 / _masked / _NoNormalize / _masked_NoNormalize   ref: standalone/utils.cpp:85-199
   get_aX_canny            ref: standalone/utils.cpp:371-462
+  SolveEA::setRefFrame / setNowFrame (ROS flavour)   ref: src/SolveEA.cpp:29-82, :86-119
 and the published OpenCV 3 algorithms those call (OpenCV is absent from this image):
   blur 3x3 on 8-bit                  -> box sum / 9 rounded to nearest, reflect-101
   Canny(gray, 30, 90) (aperture 3, L1 gradient) -> Sobel 3x3 CV_16S with replicated border, |dx|+|dy|,
                                         non-maximum suppression with the tan(22.5 deg) fixed-point test
                                         (TG22 = 13573, shift 15), hysteresis over 8-neighbours
+  Canny(bgr, 150, 100, 3, true)      -> per pixel the channel with the largest dx^2 + dy^2 (first on ties) supplies
+                                        dx, dy; thresholds min(t, 32767)^2; the same suppression and hysteresis
+  distanceTransform(DIST_L2, DIST_MASK_PRECISE) -> exact Euclidean: float32 sqrt(dx^2 + dy^2) of the nearest zero pixel
   GaussianBlur 3x3 sigma=0 on 8-bit  -> [1 2 1]x[1 2 1]/16, fixed point, round-half-up, reflect-101
   cvtColor CV_RGB2GRAY on 8-bit      -> (4899*c0 + 9617*c1 + 1868*c2 + 8192) >> 14  (c0 is really
                                         blue: imread returns BGR, the code says RGB — utils.cpp:51,216)
@@ -180,13 +184,27 @@ CANNY_SHIFT = 15
 TG22 = int(0.4142135623730950488016887242097 * (1 << CANNY_SHIFT) + 0.5)  # 13573
 
 
-def canny_nms_labels(gray, low_thresh, high_thresh):
-    """Stages 1-2 of cv::Canny(gray, edges, t1, t2, 3, false): per-pixel label 2 = strong edge (local maximum
-    above `high`), 0 = candidate (local maximum above `low`), 1 = not an edge.  Magnitudes outside the image are 0."""
-    low, high = sorted((int(np.floor(low_thresh)), int(np.floor(high_thresh))))
-    dx, dy = sobel3_s16_replicate(gray)
-    mag = np.abs(dx) + np.abs(dy)
-    H, W = gray.shape
+def canny_nms_labels(img, low_thresh, high_thresh, l2_gradient=False):
+    """Stages 1-2 of cv::Canny(img, edges, t1, t2, 3, l2_gradient) on CV_8UC1 or CV_8UC3: per-pixel label 2 = strong
+    edge (local maximum above `high`), 0 = candidate (local maximum above `low`), 1 = not an edge.  Magnitudes outside
+    the image are 0.  Multi-channel input: the channel with the largest magnitude (first on ties) supplies dx, dy."""
+    lo_t, hi_t = sorted((float(low_thresh), float(high_thresh)))
+    if l2_gradient:
+        lo_t, hi_t = min(32767.0, lo_t), min(32767.0, hi_t)
+        lo_t = lo_t * lo_t if lo_t > 0 else lo_t
+        hi_t = hi_t * hi_t if hi_t > 0 else hi_t
+    low, high = int(np.floor(lo_t)), int(np.floor(hi_t))
+    chans = [img] if img.ndim == 2 else [img[:, :, c] for c in range(img.shape[2])]
+    dx = dy = mag = None
+    for ch in chans:
+        cdx, cdy = sobel3_s16_replicate(ch)
+        cm = (cdx * cdx + cdy * cdy) if l2_gradient else (np.abs(cdx) + np.abs(cdy))
+        if mag is None:
+            dx, dy, mag = cdx, cdy, cm
+        else:
+            better = cm > mag
+            dx, dy, mag = np.where(better, cdx, dx), np.where(better, cdy, dy), np.where(better, cm, mag)
+    H, W = mag.shape
     m = np.pad(mag, 1)  # zero border
     c = m[1:-1, 1:-1]
     left, right = m[1:-1, :-2], m[1:-1, 2:]
@@ -223,9 +241,42 @@ def canny_hysteresis(labels):
     return np.where(keep[comp], 255, 0).astype(np.uint8)
 
 
-def canny_u8(gray, low_thresh, high_thresh):
-    """cv::Canny(gray, edges, low_thresh, high_thresh) (apertureSize 3, L2gradient false) on CV_8UC1."""
-    return canny_hysteresis(canny_nms_labels(gray, low_thresh, high_thresh))
+def canny_u8(img, low_thresh, high_thresh, l2_gradient=False):
+    """cv::Canny(img, edges, low_thresh, high_thresh, 3, l2_gradient) on CV_8UC1 / CV_8UC3."""
+    return canny_hysteresis(canny_nms_labels(img, low_thresh, high_thresh, l2_gradient))
+
+
+def distance_transform_precise(src_u8):
+    """cv::distanceTransform(src, DIST_L2, DIST_MASK_PRECISE): float32 sqrt of the exact squared Euclidean distance
+    to the nearest zero pixel (the sum dx^2 + dy^2 formed in float32 like OpenCV's row pass; exact below 2^24).
+    Needs at least one zero pixel."""
+    from scipy import ndimage
+    assert (src_u8 == 0).any(), "DIST_MASK_PRECISE on an image without zero pixels is not restated"
+    _, (iy, ix) = ndimage.distance_transform_edt(src_u8 != 0, return_indices=True)
+    H, W = src_u8.shape
+    yy, xx = np.mgrid[0:H, 0:W]
+    dx2 = ((xx - ix).astype(np.int64) ** 2).astype(np.float32)
+    dy2 = ((yy - iy).astype(np.int64) ** 2).astype(np.float32)
+    return np.sqrt(dx2 + dy2, dtype=np.float32)
+
+
+def ros_ref_points(img_bgr, depth_f32, fx, fy, cx, cy, low=150.0, high=100.0):
+    """SolveEA::setRefFrame (ref: src/SolveEA.cpp:29-82): Canny(rgb, 150, 100, 3, true) on the 3-channel image; every
+    edge pixel gives a point, Z = depth (float, metres), Z == 0 -> 1.0.  Returns (3xN float64 raster order, (v, u))."""
+    edges = canny_u8(img_bgr, low, high, l2_gradient=True)
+    vv, uu = np.nonzero(edges)
+    Z = depth_f32[vv, uu].astype(np.float64)
+    Z = np.where(Z == 0, 1.0, Z)
+    X = Z * (uu.astype(np.float64) - cx) / fx
+    Y = Z * (vv.astype(np.float64) - cy) / fy
+    return np.stack([X, Y, Z], axis=0), (vv, uu)
+
+
+def ros_now_distance_transform(img_bgr, low=150.0, high=100.0):
+    """SolveEA::setNowFrame (ref: src/SolveEA.cpp:86-119): Canny -> 255 - edges -> distanceTransform(L2, PRECISE) ->
+    normalize to [0, 255]."""
+    edges = canny_u8(img_bgr, low, high, l2_gradient=True)
+    return normalize_minmax_f32(distance_transform_precise(255 - edges), 0.0, 255.0)
 
 
 def canny_edges_of_frame(img_bgr, low=30, high=90):

@@ -22,6 +22,11 @@ print('640x480  set_now_frame_canny (... + chamfer DT + normalise)          %.3f
 t0 = time.perf_counter(); pp.get_aX_canny(rgb1, d1, *K); t1 = time.perf_counter(); pp.get_distance_transform2(rgb3); t2 = time.perf_counter()
 print('numpy/scipy restatement on the host: get_aX_canny %.1f ms, get_distance_transform2 %.1f ms' % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
 q, t, s = P.solve([1, 0, 0, 0], [0, 0, 0]); print('solve (Canny inputs)', s['why'], s['num_iterations'], '%.3f ms' % s['total_time_ms'])
+half = rgb3[::2, ::2].copy(); dhalf = (d1[::2, ::2].astype(np.float32) / np.float32(5000.0)).copy()
+Pr = capi.Problem(262.5, 262.5, 159.75, 119.75, dtype=capi.EA_F64)
+print('320x240  set_ref_frame_ros (3-channel L2 Canny 150/100, compaction)      %.3f ms  (n=%d)' % (timeit(lambda: Pr.set_ref_frame_ros(half, dhalf)), Pr.num_points))
+print('320x240  set_now_frame_ros (... + exact Euclidean DT + [0,255])          %.3f ms' % timeit(lambda: Pr.set_now_frame_ros(half)))
+Pr.close()
 rng = np.random.default_rng(0)
 big = np.kron(rgb3, np.ones((4, 4, 1), np.uint8))[:1536, :2048].copy()
 bigd = np.kron(d1, np.ones((4, 4), np.uint16))[:1536, :2048].copy()

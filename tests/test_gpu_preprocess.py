@@ -260,3 +260,34 @@ def test_masked_edge_points_bit_exact(hip, frames):
     P.set_ref_frame(frames["rgb1"], frames["depth1"], mask=np.zeros((H, W), np.uint8))
     assert P.num_points == 0
     P.close()
+
+
+# ---- ROS flavour (SolveEA::setRefFrame / setNowFrame, ref: src/SolveEA.cpp:29-119) ---------------------------
+
+def test_ros_producers_bit_exact(hip, frames):
+    """Canny(bgr, 150, 100, 3, true) on the 3-channel image, exact Euclidean DT normalised to [0, 255], and the
+    float-depth back-projection with Z == 0 -> 1 -- every stage against the restatement."""
+    pp = frames["pp"]
+    Kh = (0.5 * 525.0, 0.5 * 525.0, 0.5 * 319.5, 0.5 * 239.5)  # src/SolveEA.cpp:15-18: half-resolution intrinsics
+    for k, bgr in enumerate([frames["rgb3"], frames["rgb1"][::2, ::2].copy(), _random_frame(5, 120, 160)]):
+        P = hip.Problem(*Kh, dtype=hip.EA_F64)
+        got = P.set_now_frame_ros(bgr, debug=True)
+        edges = pp.canny_u8(bgr, 150.0, 100.0, l2_gradient=True)
+        assert np.array_equal(got["edges"], edges), k
+        want = pp.ros_now_distance_transform(bgr)
+        assert np.array_equal(got["dt"], want), k
+        assert got["dt"].min() == 0.0 and got["dt"].max() == 255.0
+        assert np.array_equal(P.get_dt().astype(np.float32), want), k
+        H, W = bgr.shape[:2]
+        rng = np.random.default_rng(20 + k)
+        depth = (rng.random((H, W)) * 4.0 + 0.4).astype(np.float32)
+        depth[rng.random((H, W)) < 0.2] = 0.0        # invalid depth: the reference substitutes Z = 1
+        pts, _ = pp.ros_ref_points(bgr, depth, *Kh)
+        P.set_ref_frame_ros(bgr, depth)
+        assert P.num_points == pts.shape[1] == int((edges > 0).sum())
+        assert np.array_equal(P.get_points(), pts.T)
+        P.close()
+    P = hip.Problem(*Kh, dtype=hip.EA_F32)
+    with pytest.raises(Exception):
+        P.set_now_frame_ros(np.full((48, 64, 3), 90, np.uint8))   # no edge: undefined upstream, refused here
+    P.close()
