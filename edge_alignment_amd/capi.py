@@ -28,7 +28,8 @@ EXPORTED = [
     "ea_problem_set_loss", "ea_problem_set_flavour", "ea_problem_num_points",
     "ea_eval", "ea_eval_points", "ea_cost", "ea_solve",
     "ea_batch_create", "ea_batch_destroy", "ea_batch_count", "ea_batch_eval", "ea_batch_solve",
-    "ea_solve_pyramid", "ea_batch_bench_eval", "ea_batch_bench_kernel", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
+    "ea_solve_pyramid", "ea_tracker_create", "ea_tracker_destroy", "ea_tracker_problem", "ea_tracker_push_frame",
+    "ea_batch_bench_eval", "ea_batch_bench_kernel", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
     "ea_problem_set_ref_frame", "ea_problem_set_ref_frame_masked", "ea_problem_set_now_frame", "ea_problem_debug_now_frame",
     "ea_problem_set_ref_frame_canny", "ea_problem_set_now_frame_canny", "ea_problem_debug_now_frame_canny",
     "ea_problem_set_ref_frame_ros", "ea_problem_set_now_frame_ros", "ea_problem_debug_now_frame_ros",
@@ -119,6 +120,13 @@ def load():
     L.ea_batch_get_info.argtypes = [vp, C.c_char_p, i64p]
     L.ea_selftest_wave_reduce.argtypes = [C.c_int, C.POINTER(C.c_float), dp, dp, C.POINTER(C.c_float)]
     u8p, u16p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint16)
+    L.ea_tracker_create.argtypes = [C.POINTER(vp), C.POINTER(Camera), C.c_int, C.c_int, C.c_int]
+    L.ea_tracker_destroy.argtypes = [vp]
+    L.ea_tracker_destroy.restype = None
+    L.ea_tracker_problem.argtypes = [vp]
+    L.ea_tracker_problem.restype = vp
+    L.ea_tracker_push_frame.argtypes = [vp, u8p, u16p, C.c_int, C.c_int, C.c_double, C.POINTER(Options), dp, dp,
+                                        C.POINTER(Summary), C.POINTER(C.c_int)]
     L.ea_problem_set_ref_frame.argtypes = [vp, u8p, u16p, C.c_int, C.c_int, C.c_double, C.c_int]
     L.ea_problem_set_now_frame.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.ea_problem_set_ref_frame_masked.argtypes = [vp, u8p, u8p, u16p, C.c_int, C.c_int, C.c_double, C.c_int]
@@ -374,6 +382,35 @@ class Problem:
         s = Summary()
         _check(load().ea_solve(self._h, C.byref(o), _dp(q), _dp(t), C.byref(s)))
         return q, t, summary_to_dict(s)
+
+
+class Tracker:
+    """frame-to-frame driver: push_frame aligns the previous frame's edge points against the new frame"""
+
+    def __init__(self, fx, fy, cx, cy, dtype=EA_F64, device=0, flavour=0, loss=None):
+        self._h = C.c_void_p()
+        cam = Camera(fx, fy, cx, cy)
+        _check(load().ea_tracker_create(C.byref(self._h), C.byref(cam), dtype, device, flavour))
+        if loss is not None:
+            _check(load().ea_problem_set_loss(load().ea_tracker_problem(self._h), loss[0], loss[1]))
+
+    def push_frame(self, bgr, depth_u16, z_scaling=5000.0, **opts):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        depth_u16 = np.ascontiguousarray(depth_u16, dtype=np.uint16)
+        H, W = depth_u16.shape
+        q, t = np.zeros(4), np.zeros(3)
+        o = default_options(**opts)
+        s = Summary()
+        aligned = C.c_int()
+        _check(load().ea_tracker_push_frame(self._h, bgr.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                            depth_u16.ctypes.data_as(C.POINTER(C.c_uint16)), H, W, z_scaling, C.byref(o),
+                                            _dp(q), _dp(t), C.byref(s), C.byref(aligned)))
+        return q, t, (summary_to_dict(s) if aligned.value else None)
+
+    def close(self):
+        if self._h:
+            load().ea_tracker_destroy(self._h)
+            self._h = C.c_void_p()
 
 
 def solve_pyramid(levels, q, t, **opts):

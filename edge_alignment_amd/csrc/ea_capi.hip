@@ -8,7 +8,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ea_hip.h"
@@ -800,6 +802,9 @@ extern "C" int ea_batch_bench_kernel(ea_batch *b, const double *q, const double 
   HIPCHK(hipEventCreate(&e1));
   for (int i = 0; i < warmup; ++i) if ((rc = batch_launch_eval(b)) != EA_OK) return rc;
   HIPCHK(hipStreamSynchronize(b->stream));
+  // hold the stream on a host function while the whole run is enqueued: the launches then execute from the queue,
+  // back to back, however fast this thread happens to enqueue them
+  HIPCHK(hipLaunchHostFunc(b->stream, [](void *) { std::this_thread::sleep_for(std::chrono::milliseconds(3)); }, nullptr));
   HIPCHK(hipEventRecord(e0, b->stream));
   for (int i = 0; i < launches; ++i) if ((rc = batch_launch_eval(b)) != EA_OK) return rc;
   HIPCHK(hipEventRecord(e1, b->stream));
@@ -913,6 +918,72 @@ extern "C" int ea_solve_pyramid(ea_problem *const *levels, int nlevels, const ea
       break;
     }
   }
+  return EA_OK;
+}
+
+// ---- frame-to-frame driver (the reference aligns one stored pair, src/ea.cpp:155-200) -------------
+// Every pushed frame is aligned against the previous one: its DT image is produced, the previous frame's edge points
+// are solved against it starting from the last relative pose (constant-velocity prior), then the new frame's edge
+// points become the reference.  All of it stays on the device; one ea_problem is reused.
+struct ea_tracker {
+  ea_problem *p = nullptr;
+  int flavour = 0;      // 0: get_aX / get_distance_transform, 1: Canny (get_aX_canny / get_distance_transform2)
+  int frames = 0;
+  double q[4] = {1, 0, 0, 0}, t[3] = {0, 0, 0};
+};
+
+extern "C" int ea_tracker_create(ea_tracker **out, const ea_camera *cam, int dtype, int device, int flavour) {
+  if (!out) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  if (flavour != 0 && flavour != 1) return fail(EA_ERR_INVALID_ARG, "unknown pre-processing flavour");
+  ea_tracker *tr = new (std::nothrow) ea_tracker;
+  if (!tr) return fail(EA_ERR_ALLOC, "out of host memory");
+  const int rc = ea_problem_create(&tr->p, cam, dtype, device);
+  if (rc != EA_OK) { delete tr; return rc; }
+  tr->flavour = flavour;
+  *out = tr;
+  return EA_OK;
+}
+
+extern "C" void ea_tracker_destroy(ea_tracker *tr) {
+  if (!tr) return;
+  ea_problem_destroy(tr->p);
+  delete tr;
+}
+
+extern "C" ea_problem *ea_tracker_problem(ea_tracker *tr) { return tr ? tr->p : nullptr; }
+
+// q_rel, t_rel: pose of the previous frame in the new frame's coordinates (b_T_a with a = previous, b = new); identity
+// for the first frame.  aligned (nullable): 1 when a solve took place.  A failed solve keeps the prior for the next frame.
+extern "C" int ea_tracker_push_frame(ea_tracker *tr, const uint8_t *bgr, const uint16_t *depth, int height, int width,
+                                     double z_scaling, const ea_options *opt, double q_rel[4], double t_rel[3],
+                                     ea_summary *summary, int *aligned) {
+  if (!tr || !bgr || !depth || !q_rel || !t_rel) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  int rc = EA_OK;
+  if (aligned) *aligned = 0;
+  if (summary) std::memset(summary, 0, sizeof(*summary));
+  if (tr->frames > 0 && ea_problem_num_points(tr->p) > 0) {
+    rc = tr->flavour == 0 ? ea_problem_set_now_frame(tr->p, bgr, height, width, 35, 1, 1)
+                          : ea_problem_set_now_frame_canny(tr->p, bgr, nullptr, height, width, 30, 90, 1, 0.0, 1.0);
+    if (rc != EA_OK) return rc;
+    double q[4], t[3];
+    std::memcpy(q, tr->q, sizeof(q));
+    std::memcpy(t, tr->t, sizeof(t));
+    ea_summary s;
+    rc = ea_solve(tr->p, opt, q, t, &s);
+    if (rc != EA_OK) return rc;
+    if (s.termination != EA_FAILURE) {
+      std::memcpy(tr->q, q, sizeof(q));
+      std::memcpy(tr->t, t, sizeof(t));
+    }
+    if (summary) *summary = s;
+    if (aligned) *aligned = 1;
+  }
+  std::memcpy(q_rel, tr->q, sizeof(tr->q));
+  std::memcpy(t_rel, tr->t, sizeof(tr->t));
+  rc = tr->flavour == 0 ? ea_problem_set_ref_frame(tr->p, bgr, depth, height, width, z_scaling, 35)
+                        : ea_problem_set_ref_frame_canny(tr->p, bgr, depth, height, width, z_scaling, 30, 90);
+  if (rc != EA_OK) return rc;
+  tr->frames += 1;
   return EA_OK;
 }
 

@@ -192,6 +192,18 @@ int ea_solve(ea_problem *p, const ea_options *opt, double q[4], double t[3], ea_
 int ea_solve_pyramid(ea_problem *const *levels, int nlevels, const ea_options *opt, double q[4], double t[3],
                      ea_summary *summaries);
 
+/* Frame-to-frame driver (upstream aligns one stored pair, src/ea.cpp:155-200): every pushed frame
+ * is aligned against the previous one, starting from the last relative pose; pre-processing (flavour 0: get_aX /
+ * get_distance_transform, 1: the Canny forms) and solve stay on the device.  q_rel, t_rel: pose of the previous frame
+ * in the new frame's coordinates (identity for the first frame); *aligned (nullable) = 1 when a solve took place. */
+typedef struct ea_tracker ea_tracker;
+int ea_tracker_create(ea_tracker **out, const ea_camera *cam, int dtype, int device, int flavour);
+void ea_tracker_destroy(ea_tracker *tr);
+ea_problem *ea_tracker_problem(ea_tracker *tr); /* the problem it drives (set loss / flavour knobs on it) */
+int ea_tracker_push_frame(ea_tracker *tr, const uint8_t *bgr, const uint16_t *depth, int height, int width,
+                          double z_scaling, const ea_options *opt, double q_rel[4], double t_rel[3],
+                          ea_summary *summary, int *aligned);
+
 /* ---- batches of independent frame pairs (one launch sequence for all of them) --------- */
 int ea_batch_create(ea_batch **out, ea_problem *const *problems, int count);
 void ea_batch_destroy(ea_batch *b);

@@ -291,3 +291,29 @@ def test_ros_producers_bit_exact(hip, frames):
     with pytest.raises(Exception):
         P.set_now_frame_ros(np.full((48, 64, 3), 90, np.uint8))   # no edge: undefined upstream, refused here
     P.close()
+
+
+@pytest.mark.parametrize("flavour", [0, 1])
+def test_frame_to_frame_tracker(hip, flavour):
+    """ea_tracker: the bundled five frames as a sequence.  Each push must equal the manual set_now / solve-from-prior /
+    set_ref sequence on a plain problem (same calls underneath), and the relative motions between consecutive grabs
+    of the hand-held sequence stay small."""
+    from oracle import preprocess_np as pp
+    seq = [(pp.load_rgb_as_bgr(os.path.join(G, "rgb_%d.png" % i)), pp.load_depth_u16(os.path.join(G, "depth_%d.png" % i))) for i in range(1, 6)]
+    T = hip.Tracker(*K, dtype=hip.EA_F64, flavour=flavour, loss=(hip.LOSS_CAUCHY, 1.0))
+    P = hip.Problem(*K, dtype=hip.EA_F64)
+    P.set_loss(hip.LOSS_CAUCHY, 1.0)
+    q_prior, t_prior = np.array([1.0, 0, 0, 0]), np.zeros(3)
+    for k, (bgr, depth) in enumerate(seq):
+        q, t, s = T.push_frame(bgr, depth)
+        if k == 0:
+            assert s is None and np.array_equal(q, [1, 0, 0, 0]) and np.array_equal(t, [0, 0, 0])
+        else:
+            (P.set_now_frame if flavour == 0 else P.set_now_frame_canny)(bgr)
+            qm, tm, sm = P.solve(q_prior, t_prior)
+            assert np.array_equal(q, qm) and np.array_equal(t, tm) and s["num_iterations"] == sm["num_iterations"]
+            assert s["termination"] != 2 and s["final_cost"] < s["initial_cost"]
+            assert 2 * np.arccos(min(1.0, abs(q[0]))) < 0.2 and np.linalg.norm(t) < 0.3
+            q_prior, t_prior = qm, tm
+        (P.set_ref_frame if flavour == 0 else P.set_ref_frame_canny)(bgr, depth)
+    T.close(); P.close()
