@@ -199,6 +199,29 @@ def main():
         extras = {"lm_iters_per_s_at_1e5_pts": lm_total, "lm_iterations_per_solve": its / reps,
                   "lm_solve_ms": el / reps * 1e3, "pose_gather_ms": gather_ms,
                   "lm_pose_err_vs_planted": {"rad": err_rot, "m": err_t}}
+        # the other way to use N GPUs on this path: ONE 1e5-point problem sharded by points, an
+        # all-reduce of the 32 accumulator slots per iteration (RCCL when world > 1), the step replicated on every rank
+        try:
+            sl = ead.shard_slice(cfg2["xyz"].shape[0], rank, world)
+            P3 = capi.Problem(*cfg2["K"], dtype=dt2, device=local_rank)
+            P3.set_points(cfg2["xyz"][sl]); P3.set_dt_grid(cfg2["grid"]); P3.set_loss(*loss2)
+            ar = ead.make_allreduce(world, device=coll_dev if world > 1 else "cpu")
+            P3.solve_sharded(q0, t0, ar)
+            barrier_sync()
+            ts = time.perf_counter()
+            reps3, its3 = 10, 0
+            for _ in range(reps3):
+                q3, t3, s3 = P3.solve_sharded(q0, t0, ar)
+                its3 += s3["num_iterations"]
+            barrier_sync()
+            el3 = time.perf_counter() - ts
+            extras["lm_point_sharded_1e5_pts"] = {"iters_per_s": its3 / el3, "solve_ms": el3 / reps3 * 1e3,
+                                                  "points_per_gpu": int(sl.stop - sl.start),
+                                                  "pose_err_vs_planted": {"rad": synth.rotation_angle_between(q3, cfg2["q_true"]),
+                                                                          "m": float(np.linalg.norm(t3 - cfg2["t_true"]))}}
+            P3.close()
+        except Exception as e:  # never let the secondary measurement take the headline line down
+            extras["lm_point_sharded_1e5_pts"] = {"error": repr(e)}
         P2.close()
 
     # Throughput-regime context for the same kernel (not the headline value): the C5 roofline-stress

@@ -28,7 +28,7 @@ EXPORTED = [
     "ea_problem_set_loss", "ea_problem_set_flavour", "ea_problem_num_points",
     "ea_eval", "ea_eval_points", "ea_cost", "ea_solve",
     "ea_batch_create", "ea_batch_destroy", "ea_batch_count", "ea_batch_eval", "ea_batch_solve",
-    "ea_solve_pyramid", "ea_tracker_create", "ea_tracker_destroy", "ea_tracker_problem", "ea_tracker_push_frame",
+    "ea_solve_pyramid", "ea_solve_sharded", "ea_tracker_create", "ea_tracker_destroy", "ea_tracker_problem", "ea_tracker_push_frame",
     "ea_batch_bench_eval", "ea_batch_bench_kernel", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
     "ea_problem_set_ref_frame", "ea_problem_set_ref_frame_masked", "ea_problem_set_now_frame", "ea_problem_debug_now_frame",
     "ea_problem_set_ref_frame_canny", "ea_problem_set_now_frame_canny", "ea_problem_debug_now_frame_canny",
@@ -42,6 +42,9 @@ class EAError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("libea_hip error %d: %s" % (code, msg))
         self.code = code
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_void_p)
 
 
 class Camera(C.Structure):
@@ -115,6 +118,7 @@ def load():
     L.ea_batch_solve.argtypes = [vp, C.POINTER(Options), dp, dp, C.POINTER(Summary)]
     L.ea_batch_bench_eval.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp, dp]
     L.ea_batch_bench_kernel.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp]
+    L.ea_solve_sharded.argtypes = [vp, C.POINTER(Options), ALLREDUCE_FN, vp, dp, dp, C.POINTER(Summary)]
     L.ea_solve_pyramid.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Options), dp, dp, C.POINTER(Summary)]
     L.ea_batch_set_tuning.argtypes = [vp, C.c_char_p, C.c_int]
     L.ea_batch_get_info.argtypes = [vp, C.c_char_p, i64p]
@@ -318,6 +322,25 @@ class Problem:
         _check(load().ea_problem_debug_now_frame_ros(self._h, bgr.ctypes.data_as(u8), H, W, t1, t2, edges.ctypes.data_as(u8),
                                                      dt.ctypes.data_as(C.POINTER(C.c_float))))
         return dict(edges=edges, dt=dt)
+
+    def solve_sharded(self, q, t, allreduce, **opts):
+        """ea_solve_sharded: `allreduce(array_of_32_doubles)` sums its argument in place over all ranks"""
+        q, t = _f64(q).copy(), _f64(t).copy()
+        o = default_options(**opts)
+        s = Summary()
+
+        def _cb(buf, count, _user):
+            try:
+                a = np.ctypeslib.as_array(buf, shape=(count,))
+                allreduce(a)
+                return 0
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = ALLREDUCE_FN(_cb)
+        _check(load().ea_solve_sharded(self._h, C.byref(o), cb, None, _dp(q), _dp(t), C.byref(s)))
+        return q, t, summary_to_dict(s)
 
     def get_points(self):
         n = self.num_points

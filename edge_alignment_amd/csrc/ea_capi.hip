@@ -899,6 +899,80 @@ extern "C" int ea_solve(ea_problem *p, const ea_options *opt, double q[4], doubl
   return ea_batch_solve(b, opt, q, t, summary);
 }
 
+// ---- one problem sharded by points over several processes / GPUs ----------------------------------
+// Every rank holds a shard of the edge points and the whole DT image.  Per trust-region iteration: the local fused
+// evaluation (device) -> the 32 accumulator slots -> `allreduce` (in-place sum over ranks: RCCL through
+// torch.distributed in edge_alignment_amd/dist.py) -> the same state machine on every rank.  The step is a
+// deterministic function of the reduced sums, so the ranks stay in lockstep without a broadcast.  The state machine
+// runs on the host here (ea_lm.h, the code the device kernels run): the collective returns its result to the host
+// anyway.  A rank with an empty shard takes part with zero sums.
+extern "C" int ea_solve_sharded(ea_problem *p, const ea_options *opt_in, ea_allreduce_fn allreduce, void *user, double q[4],
+                                double t[3], ea_summary *summary) {
+  if (!p || !allreduce || !q || !t) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  const auto t0 = std::chrono::steady_clock::now();
+  ea_options o;
+  if (opt_in) o = *opt_in; else ea_default_options(&o);
+  if (o.max_num_iterations < 0) return fail(EA_ERR_INVALID_ARG, "max_num_iterations < 0");
+  if (o.strategy != EA_STRATEGY_LM && o.strategy != EA_STRATEGY_DOGLEG)
+    return fail(EA_ERR_INVALID_ARG, "unknown trust-region strategy");
+  ea_batch *b = nullptr;
+  int rc = self_batch(p, &b);
+  if (rc != EA_OK) return rc;
+  rc = batch_build(b);
+  if (rc != EA_OK) return rc;
+  LMOptions lo;
+  lo.max_num_iterations = o.max_num_iterations;
+  lo.function_tolerance = o.function_tolerance;
+  lo.gradient_tolerance = o.gradient_tolerance;
+  lo.parameter_tolerance = o.parameter_tolerance;
+  lo.initial_trust_region_radius = o.initial_trust_region_radius;
+  lo.max_trust_region_radius = o.max_trust_region_radius;
+  lo.min_trust_region_radius = o.min_trust_region_radius;
+  lo.min_relative_decrease = o.min_relative_decrease;
+  lo.min_lm_diagonal = o.min_lm_diagonal;
+  lo.max_lm_diagonal = o.max_lm_diagonal;
+  lo.max_num_consecutive_invalid_steps = o.max_num_consecutive_invalid_steps;
+  lo.jacobi_scaling = o.jacobi_scaling;
+  lo.strategy = o.strategy;
+  LMState st;
+  LMCold cold;
+  std::memset(&cold, 0, sizeof(cold));
+  std::vector<LMTrace> trv(1);
+  LMTrace &tr = trv[0];
+  std::memset(&tr, 0, sizeof(tr));
+  lm_init(&st, &lo, q, t, p->rot_transposed);
+  int guard = o.max_num_iterations + 4;
+  while (st.running && guard-- > 0) {
+    const double *pose = st.num_evals == 0 ? st.x : st.cand;
+    double acc[kAccSlots];
+    if (p->n > 0 || !p->terms.empty()) {
+      rc = batch_upload_poses(b, pose, pose + 4);
+      if (rc != EA_OK) return rc;
+      rc = batch_launch_eval(b);
+      if (rc != EA_OK) return rc;
+      HIPCHK(launch_reduce(b->d_groups, 1, b->d_partials, b->d_out, b->stream));
+      HIPCHK(hipMemcpyAsync(b->h_out, b->d_out, sizeof(EvalOut), hipMemcpyDeviceToHost, b->stream));
+      HIPCHK(hipStreamSynchronize(b->stream));
+      std::memcpy(acc, b->h_out[0].acc, sizeof(acc));
+    } else {
+      std::memset(acc, 0, sizeof(acc));
+    }
+    if (allreduce(acc, kAccSlots, user) != 0) return fail(EA_ERR_STATE, "the all-reduce callback reported a failure");
+    LMPending pend;
+    if (st.num_evals == 0) lm_begin_rt(&st, &cold, &tr, &lo, acc, &pend);
+    else lm_advance_rt(&st, &cold, &tr, &lo, acc, &pend);
+    lm_flush(&pend, &cold, &tr, acc);
+  }
+  if (st.running) return fail(EA_ERR_STATE, "sharded solve did not terminate");
+  for (int k = 0; k < 4; ++k) q[k] = st.x[k];
+  for (int k = 0; k < 3; ++k) t[k] = st.x[4 + k];
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  int64_t npts = p->n;
+  for (ea_problem *tm : p->terms) npts += tm->n;
+  if (summary) fill_summary(st, tr, npts, ms, summary);
+  return EA_OK;
+}
+
 // Coarse-to-fine driver (BASELINE config C3; the reference has no pyramid -- SURVEY 8f row 4): levels[0] is the finest
 // level; the solve starts on levels[nlevels-1] and carries the pose down level by level.  Every level is a complete
 // problem (its own points, DT image and intrinsics scaled by the caller).  A level that fails (termination FAILURE)

@@ -186,6 +186,15 @@ int ea_cost(ea_problem *p, const double q[4], const double t[3], double *cost,
  * q,t in/out.  The whole trust-region loop runs on the device. */
 int ea_solve(ea_problem *p, const ea_options *opt, double q[4], double t[3], ea_summary *summary);
 
+/* One problem whose points are sharded over several processes / GPUs: every rank holds a shard of
+ * the points (ea_problem_set_points with its slice) and the whole DT image.  Per iteration: local fused evaluation ->
+ * 32 accumulator slots -> `allreduce` (in-place sum over all ranks; 0 = success) -> the same trust-region step on every
+ * rank (deterministic: no broadcast).  Every rank must call it with the same options and initial pose.  summary->
+ * num_point_evals counts the local shard. */
+typedef int (*ea_allreduce_fn)(double *buf, int count, void *user);
+int ea_solve_sharded(ea_problem *p, const ea_options *opt, ea_allreduce_fn allreduce, void *user, double q[4], double t[3],
+                     ea_summary *summary);
+
 /* Coarse-to-fine driver (BASELINE config C3; the reference has no pyramid): levels[0] = finest.
  * Solves levels[nlevels-1] first and carries q, t down level by level; every level is a complete problem with its own
  * points, DT image and (caller-scaled) intrinsics.  summaries: nlevels entries or NULL. */

@@ -56,3 +56,63 @@ def test_single_rank_gather_needs_no_process_group():
     from edge_alignment_amd import dist as ead
     q, t, st = ead.gather_poses([[1, 0, 0, 0], [0, 1, 0, 0]], [[1, 2, 3], [4, 5, 6]], [0, 1], 2, 0, 1)
     assert q.tolist() == [[1, 0, 0, 0], [0, 1, 0, 0]] and t.tolist() == [[1, 2, 3], [4, 5, 6]] and st.tolist() == [0, 1]
+
+
+# ---- one problem sharded by points: an all-reduce of the 32 accumulator slots per trust-region iteration ---------
+# (on the GPU the local evaluation is ea_solve_sharded's fused kernel, here the oracle plays the
+# evaluator so the sharding + collective + replicated state machine run on CPU)
+
+def _sharded_worker(rank, world, port, shim_path, out_dir):
+    import ctypes as C
+    import torch.distributed as dist
+    from edge_alignment_amd import dist as ead, synth
+    from oracle import ea_oracle as eo
+    import test_lm_host_logic as tl
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    pr = synth.make_problem(60, 80, 901, 14, 42, 65.0, 65.0, 39.5, 29.5,
+                            planted_q=synth.quat_from_axis_angle([1, -2, 0.5], np.deg2rad(0.6)),
+                            planted_t=(0.004, -0.002, 0.003), normalize=True)
+    X = pr["xyz"][ead.shard_slice(pr["xyz"].shape[0], rank, world)]
+    P = eo.OracleProblem(pr["grid"], *pr["K"])
+    allreduce = ead.make_allreduce(world)
+    shim = C.CDLL(shim_path)
+
+    def cb(pose, acc, _):
+        x = np.array([pose[i] for i in range(7)])
+        a = np.zeros(32)
+        if X.shape[0]:
+            e = P.eval(X, x[:4], x[4:])
+            a[:21] = e["JtJ"][np.triu_indices(6)]
+            a[21:27] = e["Jtr"]; a[27] = e["cost"]; a[28] = float(e["n_invalid"])
+        allreduce(a)                      # the one exchange step of an iteration
+        for i in range(32):
+            acc[i] = a[i]
+    out = tl.ShimOut()
+    o = tl._opts()
+    q0 = np.array([1.0, 0, 0, 0]); t0 = np.zeros(3)
+    shim.ea_lm_host_solve.argtypes = [C.POINTER(tl.LMOptions), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, tl.CB,
+                                      C.c_void_p, C.POINTER(tl.ShimOut)]
+    rc = shim.ea_lm_host_solve(C.byref(o), q0.ctypes.data_as(C.POINTER(C.c_double)), t0.ctypes.data_as(C.POINTER(C.c_double)),
+                               0, tl.CB(cb), None, C.byref(out))
+    assert rc == 0
+    np.savez(os.path.join(out_dir, "sh%d.npz" % rank), x=np.array(out.x[:]), it=out.iteration, why=out.why)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_point_sharded_solve_world2(tmp_path, lm_host_shim, oracle):
+    import torch.multiprocessing as mp
+    from edge_alignment_amd import dist as ead, synth
+    assert [ead.shard_slice(10, r, 3) for r in range(3)] == [slice(0, 3), slice(3, 6), slice(6, 10)]
+    world = 2
+    mp.spawn(_sharded_worker, args=(world, _free_port(), lm_host_shim._name, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "sh0.npz"), np.load(tmp_path / "sh1.npz")
+    # lockstep: both ranks took the same decisions and hold the same pose, bit for bit
+    assert np.array_equal(r0["x"], r1["x"]) and r0["it"] == r1["it"] and r0["why"] == r1["why"]
+    # and the sharded solve is the unsharded one up to the order of the sums
+    pr = synth.make_problem(60, 80, 901, 14, 42, 65.0, 65.0, 39.5, 29.5,
+                            planted_q=synth.quat_from_axis_angle([1, -2, 0.5], np.deg2rad(0.6)),
+                            planted_t=(0.004, -0.002, 0.003), normalize=True)
+    q, t, s = oracle.OracleProblem(pr["grid"], *pr["K"]).solve(pr["xyz"], [1, 0, 0, 0], [0, 0, 0])
+    assert r0["it"] == s["num_iterations"]
+    assert np.abs(r0["x"][:4] - q).max() < 1e-10 and np.abs(r0["x"][4:] - t).max() < 1e-10

@@ -1,0 +1,77 @@
+"""One problem sharded by points: ea_solve_sharded = local fused evaluation on the device, an
+all-reduce of the 32 accumulator slots per iteration, the trust-region step replicated on every rank."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from edge_alignment_amd import synth
+
+pytestmark = pytest.mark.gpu
+Q0, T0 = np.array([1.0, 0, 0, 0]), np.zeros(3)
+
+
+def _problem():
+    return synth.config_c2_twin(seed=17, n_points=30011)
+
+
+def test_sharded_solve_single_rank_equals_device_solve(hip):
+    """world size 1: the all-reduce is the identity; the host-side replica of the state machine must take the same
+    decisions as the device LM-step kernel."""
+    from edge_alignment_amd import dist as ead
+    cfg = _problem()
+    for dtype, tol in ((hip.EA_F64, 1e-10), (hip.EA_F32, 1e-6)):
+        P = hip.Problem(*cfg["K"], dtype=dtype)
+        P.set_points(cfg["xyz"]); P.set_dt_grid(cfg["grid"]); P.set_loss(hip.LOSS_CAUCHY, 1.0)
+        q, t, s = P.solve(Q0, T0)
+        calls = []
+        ident = ead.make_allreduce(1)
+        def ar(a):
+            calls.append(a.shape[0]); ident(a)
+        q2, t2, s2 = P.solve_sharded(Q0, T0, ar)
+        assert s2["num_iterations"] == s["num_iterations"] and s2["why"] == s["why"]
+        assert np.abs(q - q2).max() < tol and np.abs(t - t2).max() < tol
+        assert calls == [32] * (s["num_iterations"] + 1)   # one exchange per evaluation
+        q3, t3, s3 = P.solve_sharded(Q0, T0, ar, strategy=hip.STRATEGY_DOGLEG, max_num_iterations=25)
+        q4, t4, s4 = P.solve(Q0, T0, strategy=hip.STRATEGY_DOGLEG, max_num_iterations=25)
+        assert s3["num_iterations"] == s4["num_iterations"] and np.abs(q3 - q4).max() < tol
+        P.close()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from edge_alignment_amd import capi, dist as ead
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    cfg = _problem()
+    X = cfg["xyz"][ead.shard_slice(cfg["xyz"].shape[0], rank, world)]
+    P = capi.Problem(*cfg["K"], dtype=capi.EA_F64, device=0)   # both ranks share the one GPU of the test box
+    P.set_points(X); P.set_dt_grid(cfg["grid"]); P.set_loss(capi.LOSS_CAUCHY, 1.0)
+    q, t, s = P.solve_sharded(Q0, T0, ead.make_allreduce(world))
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), q=q, t=t, it=s["num_iterations"], cost=s["final_cost"])
+    P.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_solve_two_ranks(hip, tmp_path):
+    import torch.multiprocessing as mp
+    cfg = _problem()
+    P = hip.Problem(*cfg["K"], dtype=hip.EA_F64)
+    P.set_points(cfg["xyz"]); P.set_dt_grid(cfg["grid"]); P.set_loss(hip.LOSS_CAUCHY, 1.0)
+    q, t, s = P.solve(Q0, T0)
+    P.close()
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    assert np.array_equal(r0["q"], r1["q"]) and np.array_equal(r0["t"], r1["t"]) and r0["it"] == r1["it"]   # lockstep
+    assert r0["it"] == s["num_iterations"]
+    assert np.abs(r0["q"] - q).max() < 1e-10 and np.abs(r0["t"] - t).max() < 1e-10
+    assert r0["cost"] == pytest.approx(s["final_cost"], rel=1e-10)
