@@ -82,7 +82,8 @@ template <> __device__ __forceinline__ float t_rcp<float>(float x) { return __bu
 template <> __device__ __forceinline__ double t_rcp<double>(double x) { return 1.0 / x; }
 
 template <typename T> __device__ __forceinline__ T t_log(T x);
-template <> __device__ __forceinline__ float t_log<float>(float x) { return __logf(x); }
+// v_log_f32 is log2 and needs no denormal pre-scaling here: its only caller passes 1 + s / a^2 >= 1
+template <> __device__ __forceinline__ float t_log<float>(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 template <> __device__ __forceinline__ double t_log<double>(double x) { return log(x); }
 
 template <typename T> __device__ __forceinline__ T t_sqrt(T x);
@@ -611,7 +612,7 @@ __device__ __forceinline__ double fused_chunk(const ProblemDesc &pd, const PoseS
     else project_point<T>(pd, ps, X[k], Y[k], Z[k], pr[k]);
     valid[k] = inb && pr[k].state == 1;
     n_bad += (inb && pr[k].state == 2) ? 1 : 0;
-    if (!valid[k]) {
+    if (__any(!valid[k]) && !valid[k]) {  // (uniform test first: the common wavefront has nothing to fix up)
       pr[k].iu = 0; pr[k].iv = 0; pr[k].fu = T(0); pr[k].fv = T(0);
       pr[k].iz = T(1);
       if constexpr (VAR) {
