@@ -112,7 +112,8 @@ struct ea_batch {
   PoseState *d_poses = nullptr;
   double *d_partials = nullptr;
   EvalOut *d_out = nullptr;
-  unsigned char *d_lm_block = nullptr;  // [LMState x count | PoseState x count], one upload per solve
+  unsigned char *d_lm_block = nullptr;  // [PoseState x count | LMState x count | LMTrace x count]: poses + states go up
+                                        // in ONE copy per solve, states + traces come back in ONE copy
   LMState *d_states = nullptr;
   LMCold *d_cold = nullptr;             // written by the first LM step before anything reads it
   LMTrace *d_traces = nullptr;
@@ -373,10 +374,10 @@ extern "C" int ea_problem_set_flavour(ea_problem *p, double z_guard, double z_ep
 // ---- batch --------------------------------------------------------------------------------------
 
 static void batch_free_device(ea_batch *b) {
-  (void)hipFree(b->d_probs); (void)hipFree(b->d_groups); (void)hipFree(b->d_lm_block); (void)hipFree(b->d_traces); (void)hipFree(b->d_cold);
+  (void)hipFree(b->d_probs); (void)hipFree(b->d_groups); (void)hipFree(b->d_lm_block); (void)hipFree(b->d_cold);
   (void)hipFree(b->d_partials); (void)hipFree(b->d_out);
   (void)hipHostFree(b->h_lm_block); (void)hipHostFree(b->h_out);
-  (void)hipHostFree(b->h_traces); (void)hipHostFree(b->h_progress);
+  (void)hipHostFree(b->h_progress);
   b->d_probs = nullptr; b->d_groups = nullptr; b->d_poses = nullptr; b->d_partials = nullptr; b->d_traces = nullptr; b->d_cold = nullptr; b->d_lm_block = nullptr;
   b->d_out = nullptr; b->d_states = nullptr; b->d_progress = nullptr;
   b->h_poses = nullptr; b->h_out = nullptr; b->h_states = nullptr; b->h_traces = nullptr; b->h_progress = nullptr;
@@ -401,22 +402,23 @@ extern "C" int ea_batch_create(ea_batch **out, ea_problem *const *problems, int 
   if (e != hipSuccess) { delete b; return fail(EA_ERR_HIP, hipGetErrorString(e)); }
   b->own_stream = true;
   const size_t c = (size_t)count;
-  const size_t lm_bytes = c * (sizeof(LMState) + sizeof(PoseState));
+  const size_t lm_bytes = c * (sizeof(LMState) + sizeof(LMTrace) + sizeof(PoseState));
   e = hipMalloc(&b->d_groups, c * sizeof(GroupDesc));
   if (e == hipSuccess) e = hipMalloc(&b->d_lm_block, lm_bytes);
   if (e == hipSuccess) e = hipMalloc(&b->d_out, c * sizeof(EvalOut));
-  if (e == hipSuccess) e = hipMalloc(&b->d_traces, c * sizeof(LMTrace));
   if (e == hipSuccess) e = hipMalloc(&b->d_cold, c * sizeof(LMCold));
   if (e == hipSuccess) e = hipHostMalloc(&b->h_lm_block, lm_bytes);
   if (e == hipSuccess) e = hipHostMalloc(&b->h_out, c * sizeof(EvalOut));
-  if (e == hipSuccess) e = hipHostMalloc(&b->h_traces, c * sizeof(LMTrace));
   if (e == hipSuccess) e = hipHostMalloc(&b->h_progress, 2 * c * sizeof(int), hipHostMallocMapped);
   if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&b->d_progress), b->h_progress, 0);
   if (e == hipSuccess) {
-    b->d_states = reinterpret_cast<LMState *>(b->d_lm_block);
-    b->d_poses = reinterpret_cast<PoseState *>(b->d_lm_block + c * sizeof(LMState));
-    b->h_states = reinterpret_cast<LMState *>(b->h_lm_block);
-    b->h_poses = reinterpret_cast<PoseState *>(b->h_lm_block + c * sizeof(LMState));
+    static_assert(sizeof(PoseState) % 8 == 0 && sizeof(LMState) % 8 == 0, "8-byte aligned sub-blocks");
+    b->d_poses = reinterpret_cast<PoseState *>(b->d_lm_block);
+    b->d_states = reinterpret_cast<LMState *>(b->d_lm_block + c * sizeof(PoseState));
+    b->d_traces = reinterpret_cast<LMTrace *>(b->d_lm_block + c * (sizeof(PoseState) + sizeof(LMState)));
+    b->h_poses = reinterpret_cast<PoseState *>(b->h_lm_block);
+    b->h_states = reinterpret_cast<LMState *>(b->h_lm_block + c * sizeof(PoseState));
+    b->h_traces = reinterpret_cast<LMTrace *>(b->h_lm_block + c * (sizeof(PoseState) + sizeof(LMState)));
   }
   if (e != hipSuccess) {
     batch_free_device(b);
@@ -677,7 +679,7 @@ extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, 
     b->h_progress[i] = 1;          // running
     b->h_progress[count + i] = 0;  // evaluations completed
   }
-  HIPCHK(hipMemcpyAsync(b->d_lm_block, b->h_lm_block, (size_t)count * (sizeof(LMState) + sizeof(PoseState)),
+  HIPCHK(hipMemcpyAsync(b->d_lm_block, b->h_lm_block, (size_t)count * (sizeof(PoseState) + sizeof(LMState)),
                         hipMemcpyHostToDevice, b->stream));
   // The loop runs on the device: each (evaluate, LM step) pair reads the pose the previous step
   // published.  The step kernel reports progress into pinned host memory; the host only keeps a few
@@ -711,9 +713,10 @@ extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, 
       if (qe != hipSuccess && qe != hipErrorNotReady) return fail(EA_ERR_HIP, hipGetErrorString(qe));
     }
   }
-  HIPCHK(hipMemcpyAsync(b->h_states, b->d_states, count * sizeof(LMState), hipMemcpyDeviceToHost, b->stream));
-  if (summaries || o.minimizer_progress_to_stdout)
-    HIPCHK(hipMemcpyAsync(b->h_traces, b->d_traces, count * sizeof(LMTrace), hipMemcpyDeviceToHost, b->stream));
+  // final states [+ traces, contiguous behind them] in one copy
+  HIPCHK(hipMemcpyAsync(b->h_states, b->d_states,
+                        (size_t)count * (sizeof(LMState) + ((summaries || o.minimizer_progress_to_stdout) ? sizeof(LMTrace) : 0)),
+                        hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   for (int i = 0; i < count; ++i) {
