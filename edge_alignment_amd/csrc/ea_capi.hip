@@ -27,7 +27,7 @@ hipError_t launch_reduce(const GroupDesc *groups, int count, const double *parti
                          hipStream_t stream);
 hipError_t launch_lm_step(const GroupDesc *groups, int count, const double *partials, PoseState *poses,
                           LMState *states, LMCold *cold, LMTrace *traces, const LMOptions &opt, int *running_flags,
-                          hipStream_t stream);
+                          LMState *host_states, LMTrace *host_traces, hipStream_t stream);
 hipError_t launch_pad_image(int dtype, const void *src, int H, int W, void *dst, int pitch, hipStream_t stream);
 hipError_t launch_selftest_reduce(const float *in, float *a, float *b, float *c, float *d, double *o32, double *o64,
                                   hipStream_t stream);
@@ -121,6 +121,11 @@ struct ea_batch {
   // pinned host mirrors
   PoseState *h_poses = nullptr;
   EvalOut *h_out = nullptr;
+  // final delivery of a solve: [LMState x count | LMTrace x count] in pinned, device-mapped host memory, written by the
+  // step kernel that ends a problem's solve (dv_* = the device's view of the same memory)
+  unsigned char *h_deliver = nullptr;
+  LMState *hd_states = nullptr, *dv_states = nullptr;
+  LMTrace *hd_traces = nullptr, *dv_traces = nullptr;
   unsigned char *h_lm_block = nullptr;
   LMState *h_states = nullptr;
   LMTrace *h_traces = nullptr;
@@ -377,11 +382,11 @@ static void batch_free_device(ea_batch *b) {
   (void)hipFree(b->d_probs); (void)hipFree(b->d_groups); (void)hipFree(b->d_lm_block); (void)hipFree(b->d_cold);
   (void)hipFree(b->d_partials); (void)hipFree(b->d_out);
   (void)hipHostFree(b->h_lm_block); (void)hipHostFree(b->h_out);
-  (void)hipHostFree(b->h_progress);
+  (void)hipHostFree(b->h_progress); (void)hipHostFree(b->h_deliver);
   b->d_probs = nullptr; b->d_groups = nullptr; b->d_poses = nullptr; b->d_partials = nullptr; b->d_traces = nullptr; b->d_cold = nullptr; b->d_lm_block = nullptr;
   b->d_out = nullptr; b->d_states = nullptr; b->d_progress = nullptr;
   b->h_poses = nullptr; b->h_out = nullptr; b->h_states = nullptr; b->h_traces = nullptr; b->h_progress = nullptr;
-  b->h_lm_block = nullptr;
+  b->h_lm_block = nullptr; b->h_deliver = nullptr;
 }
 
 extern "C" int ea_batch_create(ea_batch **out, ea_problem *const *problems, int count) {
@@ -411,6 +416,15 @@ extern "C" int ea_batch_create(ea_batch **out, ea_problem *const *problems, int 
   if (e == hipSuccess) e = hipHostMalloc(&b->h_out, c * sizeof(EvalOut));
   if (e == hipSuccess) e = hipHostMalloc(&b->h_progress, 2 * c * sizeof(int), hipHostMallocMapped);
   if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&b->d_progress), b->h_progress, 0);
+  if (e == hipSuccess) e = hipHostMalloc(&b->h_deliver, c * (sizeof(LMState) + sizeof(LMTrace)), hipHostMallocMapped);
+  if (e == hipSuccess) {
+    unsigned char *dv = nullptr;
+    e = hipHostGetDevicePointer(reinterpret_cast<void **>(&dv), b->h_deliver, 0);
+    b->hd_states = reinterpret_cast<LMState *>(b->h_deliver);
+    b->hd_traces = reinterpret_cast<LMTrace *>(b->h_deliver + c * sizeof(LMState));
+    b->dv_states = reinterpret_cast<LMState *>(dv);
+    b->dv_traces = reinterpret_cast<LMTrace *>(dv + c * sizeof(LMState));
+  }
   if (e == hipSuccess) {
     static_assert(sizeof(PoseState) % 8 == 0 && sizeof(LMState) % 8 == 0, "8-byte aligned sub-blocks");
     b->d_poses = reinterpret_cast<PoseState *>(b->d_lm_block);
@@ -689,6 +703,7 @@ extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, 
   const int budget = o.max_num_iterations + 2;  // every pair consumes at least one iteration
   int enq = 0;
   unsigned spins = 0;
+  bool any_running_after_loop = false;
   for (;;) {
     bool any = false;
     int done = 0;
@@ -701,11 +716,13 @@ extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, 
       rc = batch_launch_eval(b);
       if (rc != EA_OK) return rc;
       HIPCHK(launch_lm_step(b->d_groups, count, b->d_partials, b->d_poses, b->d_states, b->d_cold, b->d_traces, lo,
-                            b->d_progress, b->stream));
+                            b->d_progress, b->dv_states, b->dv_traces, b->stream));
       ++enq;
       spins = 0;
     } else if (enq >= budget) {
       HIPCHK(hipStreamSynchronize(b->stream));
+      for (int i = 0; i < count; ++i)
+        any_running_after_loop = any_running_after_loop || (__atomic_load_n(&b->h_progress[i], __ATOMIC_ACQUIRE) != 0);
       break;
     } else if ((++spins & 0x3fff) == 0) {
       // nothing to enqueue and no progress for a while: make sure the stream is still healthy
@@ -713,11 +730,32 @@ extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, 
       if (qe != hipSuccess && qe != hipErrorNotReady) return fail(EA_ERR_HIP, hipGetErrorString(qe));
     }
   }
-  // final states [+ traces, contiguous behind them] in one copy
-  HIPCHK(hipMemcpyAsync(b->h_states, b->d_states,
-                        (size_t)count * (sizeof(LMState) + ((summaries || o.minimizer_progress_to_stdout) ? sizeof(LMTrace) : 0)),
-                        hipMemcpyDeviceToHost, b->stream));
-  HIPCHK(hipStreamSynchronize(b->stream));
+  // The step kernel that ended a problem's solve has already delivered its final state and trace rows into pinned
+  // host memory, in front of the flag polled above: no copy, and no wait for the launches queued ahead (they find
+  // every problem finished and drain behind our back; the next use of the stream is ordered after them anyway).
+  // Only a solve cut short by the launch budget has to be fetched the classic way.
+  if (any_running_after_loop) {
+    HIPCHK(hipMemcpyAsync(b->h_states, b->d_states, (size_t)count * (sizeof(LMState) + sizeof(LMTrace)),
+                          hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+  } else {
+    std::memcpy(b->h_states, b->hd_states, (size_t)count * sizeof(LMState));
+    if (summaries || o.minimizer_progress_to_stdout) {
+      for (int i = 0; i < count; ++i) {
+        // rows 0 .. iteration were delivered; the rest of the pinned block is stale
+        const int ni = std::min(b->hd_states[i].iteration + 1, (int)kTrace);
+        LMTrace &d = b->h_traces[i];
+        const LMTrace &sr = b->hd_traces[i];
+        std::memcpy(d.it_cost, sr.it_cost, ni * sizeof(double));
+        std::memcpy(d.it_cost_change, sr.it_cost_change, ni * sizeof(double));
+        std::memcpy(d.it_gradient_max_norm, sr.it_gradient_max_norm, ni * sizeof(double));
+        std::memcpy(d.it_step_norm, sr.it_step_norm, ni * sizeof(double));
+        std::memcpy(d.it_relative_decrease, sr.it_relative_decrease, ni * sizeof(double));
+        std::memcpy(d.it_radius, sr.it_radius, ni * sizeof(double));
+        std::memcpy(d.it_successful, sr.it_successful, ni * sizeof(int));
+      }
+    }
+  }
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   for (int i = 0; i < count; ++i) {
     const LMState &s = b->h_states[i];

@@ -933,11 +933,13 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_step_kernel(
     const GroupDesc *__restrict__ groups, const double *__restrict__ partials,
     PoseState *__restrict__ poses, LMState *__restrict__ states, LMCold *__restrict__ cold,
     LMTrace *__restrict__ traces, LMOptions opt,
-    int *__restrict__ progress /* pinned host: [running x n | evals x n] */) {
+    int *__restrict__ progress /* pinned host: [running x n | evals x n] */,
+    LMState *__restrict__ host_states, LMTrace *__restrict__ host_traces /* pinned host, nullable: final delivery */) {
   __shared__ double s_part[(kLmThreads / 32) * kAccSlots];
   __shared__ double s_acc[kAccSlots];
   __shared__ LMState s_st;
   __shared__ PoseState s_ps;
+  __shared__ int s_trace_it;
   constexpr int kStateWords = (int)(sizeof(LMState) / 8);
   constexpr int kPoseDoubles = 4 + 3 + 9 + 27, kPoseFloats = 9 + 3 + 27;
   static_assert(sizeof(LMState) % 8 == 0 && kStateWords <= kLmThreads, "one 8-byte state word per lane");
@@ -975,6 +977,7 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_step_kernel(
     EA_LM_STAMP(3, ev_);
     make_pose_core(st.cand, st.rot_transposed, st.running, &s_ps, /*zero_unused_G=*/false);
     s_st = st;
+    s_trace_it = pend.trace_it;
     EA_LM_STAMP(4, ev_);
   }
   __syncthreads();
@@ -993,9 +996,42 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_step_kernel(
     }
     if (tid == 192) { poses[p].unit_q = s_ps.unit_q; poses[p].active = s_ps.active; }
   }
-  if (tid == 0) {
-    lm_flush(&pend, cold + p, traces + p, acc);
-    if (!s_st.running) __hip_atomic_store(progress + p, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (tid == 0) lm_flush(&pend, cold + p, traces + p, acc);
+  if (!s_st.running) {  // uniform: the solve of this problem ends with this launch
+    // Deliver the result straight into pinned host memory -- final state and the trace rows written so far -- and
+    // only then lower the flag the host polls: the host returns without a device-to-host copy or a stream
+    // synchronisation behind launches that were queued ahead and now have nothing to do.
+    if (host_states) {
+      if (tid < kStateWords) reinterpret_cast<double *>(host_states + p)[tid] = reinterpret_cast<const double *>(&s_st)[tid];
+      const int last = min(s_st.iteration, kTrace - 1);  // rows 0 .. last exist
+      auto copy_row = [&](int r) {
+        const LMTrace &src = traces[p];
+        LMTrace &dst = host_traces[p];
+        dst.it_cost[r] = src.it_cost[r];
+        dst.it_cost_change[r] = src.it_cost_change[r];
+        dst.it_gradient_max_norm[r] = src.it_gradient_max_norm[r];
+        dst.it_step_norm[r] = src.it_step_norm[r];
+        dst.it_relative_decrease[r] = src.it_relative_decrease[r];
+        dst.it_radius[r] = src.it_radius[r];
+        dst.it_successful[r] = src.it_successful[r];
+      };
+      if (s_trace_it == last) {
+        // the usual end: rows < last come from earlier launches (one lane each), lane 0 holds the last one
+        if (tid < last) copy_row(tid);
+        if (tid == 0) {
+          LMPending h = pend;
+          h.store_system = 0;
+          lm_flush(&h, cold + p, host_traces + p, acc);
+        }
+      } else if (tid == 0) {
+        // rows written by this very launch through lm_trace (invalid steps): lane 0 wrote them, lane 0 copies them
+        __threadfence();
+        for (int r = 0; r <= last; ++r) copy_row(r);
+      }
+      __threadfence_system();
+    }
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(progress + p, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 #ifdef EA_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1073,14 +1109,14 @@ hipError_t launch_reduce(const GroupDesc *groups, int count, const double *parti
 
 hipError_t launch_lm_step(const GroupDesc *groups, int count, const double *partials, PoseState *poses,
                           LMState *states, LMCold *cold, LMTrace *traces, const LMOptions &opt, int *progress,
-                          hipStream_t stream) {
+                          LMState *host_states, LMTrace *host_traces, hipStream_t stream) {
   if (count <= 0) return hipSuccess;
   if (opt.strategy == 0)
     hipLaunchKernelGGL(ea_lm_step_kernel<0>, dim3(count), dim3(kLmThreads), 0, stream, groups, partials, poses,
-                       states, cold, traces, opt, progress);
+                       states, cold, traces, opt, progress, host_states, host_traces);
   else
     hipLaunchKernelGGL(ea_lm_step_kernel<1>, dim3(count), dim3(kLmThreads), 0, stream, groups, partials, poses,
-                       states, cold, traces, opt, progress);
+                       states, cold, traces, opt, progress, host_states, host_traces);
   return hipGetLastError();
 }
 
