@@ -362,20 +362,14 @@ __device__ __forceinline__ void jacobian_row(const ProblemDesc &pd, const PoseSt
 }
 
 // ------------------------------------------------------------------------------------------------
-// wavefront reduction of 32 values per lane: transposing butterfly on DPP.
+// wavefront reduction of 32 values per lane: a transposing butterfly.
 //
 // Each step pairs lanes, lets the pair split its values in two halves, and adds the partner's
-// copy of the kept half — so the number of live values halves while the number of lanes summed
-// doubles: 16+8+4+2+1 exchanges instead of 32*6.  The lane pairings are the ones DPP offers for
-// free inside a 16-lane row (row_mirror = xor 15, row_half_mirror = xor 7, quad_perm = xor 2 and
-// xor 1), ordered so that a partner always agrees on every selection bit used before; the two
-// cross-row steps (xor 16, xor 32) move one value each.
-// After the call lane L holds in v[0] the wave total of slot
-//   id(L) = 16*b3 + 8*b2 + 4*b1 + 2*b0 + b4   (b_k = bit k of L); lanes L and L^32 hold the same.
-
-__device__ __forceinline__ int butterfly_slot(int lane) {
-  return ((lane & 8) << 1) | ((lane & 4) << 1) | ((lane & 2) << 1) | ((lane & 1) << 1) | ((lane & 16) >> 4);
-}
+// copy of the kept half -- so the number of live values halves while the number of lanes summed
+// doubles: 16+8+4+2+1 exchanges instead of 32*6.  The pairings are the ones the hardware offers
+// cheaply: lane-swap instructions across half-waves and 16-lane rows (L ^ 32, L ^ 16), DPP inside a
+// row (row_mirror = xor 15, row_half_mirror = xor 7, quad_perm = xor 2 and xor 1).  The fp32 and the
+// fp64 forms below differ in the order of the levels and hence in the slot a lane ends up with.
 
 constexpr int kDppRowMirror = 0x140, kDppRowHalfMirror = 0x141, kDppQuadXor2 = 0x4E, kDppQuadXor1 = 0xB1;
 
@@ -390,43 +384,6 @@ __device__ __forceinline__ double lane_xchg(double x) {
   const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, false);
   return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
-// xor 16 inside each half-wave: ds_swizzle bit-mask mode (and 0x1f, or 0, xor 0x10); no LDS memory
-__device__ __forceinline__ float lane_xor16(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));
-}
-__device__ __forceinline__ double lane_xor16(double x) {
-  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
-  const int lo = __builtin_amdgcn_ds_swizzle((int)(unsigned)u, 0x401F);
-  const int hi = __builtin_amdgcn_ds_swizzle((int)(unsigned)(u >> 32), 0x401F);
-  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-}
-
-template <int CTRL, int BIT, int C, typename A>
-__device__ __forceinline__ void butterfly_step(A (&v)[32], int lane) {
-  const bool upper = (lane & BIT) != 0;
-#pragma unroll
-  for (int i = 0; i < C; ++i) {
-    const A send = upper ? v[i] : v[i + C];
-    const A keep = upper ? v[i + C] : v[i];
-    v[i] = keep + lane_xchg<CTRL>(send);
-  }
-}
-
-template <typename A>
-__device__ __forceinline__ void wave_reduce32(A (&v)[32], int lane) {
-  butterfly_step<kDppRowMirror, 8, 16>(v, lane);
-  butterfly_step<kDppRowHalfMirror, 4, 8>(v, lane);
-  butterfly_step<kDppQuadXor2, 2, 4>(v, lane);
-  butterfly_step<kDppQuadXor1, 1, 2>(v, lane);
-  {
-    const bool upper = (lane & 16) != 0;
-    const A send = upper ? v[0] : v[1];
-    const A keep = upper ? v[1] : v[0];
-    v[0] = keep + lane_xor16(send);
-  }
-  v[0] += __shfl_xor(v[0], 32, 64);
-}
-
 __device__ __forceinline__ int wave_min_i32(int x) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) x = min(x, __shfl_xor(x, m, 64));
@@ -525,6 +482,75 @@ __device__ __forceinline__ void wave_reduce32_f32(float (&v)[32]) {
   v[1] = d[1];
 }
 
+// fp64 wavefront reduction with lane-swap instructions for the two widest levels.
+//
+// v_permlane32_swap exchanges lanes 32..63 of one register with lanes 0..31 of another: applied to slot i and slot
+// i + 16 (both dwords of the double), the sum of the two registers is exactly the transposing step for the pairing
+// L ^ 32 -- lower half-wave keeps slot i, upper half-wave slot i + 16 -- in three instructions per pair of slots and
+// with no select (the DPP form costs seven).  v_permlane16_swap does the same between odd and even 16-lane rows
+// (pairing L ^ 16).  The three levels inside a row stay on DPP (row_mirror, row_half_mirror, quad_perm), the last
+// pairing (L ^ 1) is a plain add.  ~125 instructions instead of ~220.
+// On return lanes with even L hold in v[0] the wave total of slot  16 b5 + 8 b4 + 4 b3 + 2 b2 + b1  (b_k = bit k of L).
+__device__ __forceinline__ void swap32_f64(double &a, double &b) {
+  unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+  unsigned alo = (unsigned)ua, ahi = (unsigned)(ua >> 32), blo = (unsigned)ub, bhi = (unsigned)(ub >> 32);
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 0"
+               : "+v"(alo), "+v"(ahi), "+v"(blo), "+v"(bhi));
+  a = __builtin_bit_cast(double, ((unsigned long long)ahi << 32) | alo);
+  b = __builtin_bit_cast(double, ((unsigned long long)bhi << 32) | blo);
+}
+__device__ __forceinline__ void swap16_f64(double &a, double &b) {
+  unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+  unsigned alo = (unsigned)ua, ahi = (unsigned)(ua >> 32), blo = (unsigned)ub, bhi = (unsigned)(ub >> 32);
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 0"
+               : "+v"(alo), "+v"(ahi), "+v"(blo), "+v"(bhi));
+  a = __builtin_bit_cast(double, ((unsigned long long)ahi << 32) | alo);
+  b = __builtin_bit_cast(double, ((unsigned long long)bhi << 32) | blo);
+}
+
+__device__ __forceinline__ int swap_slot_f64(int lane) {
+  return ((lane & 32) >> 1) | ((lane & 16) >> 1) | ((lane & 8) >> 1) | ((lane & 4) >> 1) | ((lane & 2) >> 1);
+}
+
+__device__ __forceinline__ void wave_reduce32_f64(double (&v)[32], int lane) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {  // L ^ 32
+    swap32_f64(v[i], v[i + 16]);
+    v[i] += v[i + 16];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {  // L ^ 16
+    swap16_f64(v[i], v[i + 8]);
+    v[i] += v[i + 8];
+  }
+  // inside a 16-lane row: L ^ 15 (bit 3 picks the half kept), L ^ 7 (bit 2), L ^ 2 (bit 1)
+  {
+    const bool upper = (lane & 8) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double send = upper ? v[i] : v[i + 4];
+      const double keep = upper ? v[i + 4] : v[i];
+      v[i] = keep + lane_xchg<kDppRowMirror>(send);
+    }
+  }
+  {
+    const bool upper = (lane & 4) != 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const double send = upper ? v[i] : v[i + 2];
+      const double keep = upper ? v[i + 2] : v[i];
+      v[i] = keep + lane_xchg<kDppRowHalfMirror>(send);
+    }
+  }
+  {
+    const bool upper = (lane & 2) != 0;
+    const double send = upper ? v[0] : v[1];
+    const double keep = upper ? v[1] : v[0];
+    v[0] = keep + lane_xchg<kDppQuadXor2>(send);
+  }
+  v[0] += lane_xchg<kDppQuadXor1>(v[0]);
+}
+
 // self-test of the cross-lane primitives: one wave, lane L loads in[s*64+L] for slot s; dumps the
 // stages of wave_reduce32_f32 (a: 16x64, b: 8x64, c: 4x64, d: 2x64) and the fp64 butterfly result
 __global__ void ea_selftest_reduce_kernel(const float *in, float *stage_a, float *stage_b, float *stage_c,
@@ -555,8 +581,8 @@ __global__ void ea_selftest_reduce_kernel(const float *in, float *stage_a, float
     out_f32[masked_slot(lane, 0)] = (double)v[0];
     out_f32[masked_slot(lane, 1)] = (double)v[1];
   }
-  wave_reduce32<double>(w, lane);
-  if (lane < 32) out_f64[butterfly_slot(lane)] = w[0];
+  wave_reduce32_f64(w, lane);
+  if ((lane & 1) == 0) out_f64[swap_slot_f64(lane)] = w[0];
 }
 
 template <typename T> using GPtr = const T __attribute__((address_space(1))) *;
@@ -720,8 +746,8 @@ __device__ __forceinline__ double fused_chunk(const ProblemDesc &pd, const PoseS
       s_red[wave * kAccSlots + masked_slot(lane, 1)] = (double)v[1];
     }
   } else {
-    wave_reduce32<T>(v, lane);
-    if (lane < 32) s_red[wave * kAccSlots + butterfly_slot(lane)] = (double)v[0];
+    wave_reduce32_f64(v, lane);
+    if ((lane & 1) == 0) s_red[wave * kAccSlots + swap_slot_f64(lane)] = v[0];
   }
   EA_STAMP(5);  // wave reduced
   __syncthreads();

@@ -35,6 +35,15 @@ for i in range(32):
 Bb = capi.Batch(Ps)
 ms = min(Bb.bench_eval(np.tile(q0, (32, 1)), np.tile(t0, (32, 1)), 10, 100, kernel_pass=False)[0] for _ in range(3))
 out['batch32_f32_step_us'] = ms / 100 * 1e3
+Ps64 = []
+for i in range(32):
+    cb = synth.config_c2_twin(seed=100 + i)
+    Pb = capi.Problem(*cb['K'], dtype=capi.EA_F64); Pb.set_points(cb['xyz']); Pb.set_dt_grid(cb['grid']); Pb.set_loss(capi.LOSS_CAUCHY, 1.0)
+    Ps64.append(Pb)
+Bb64 = capi.Batch(Ps64)
+ms = min(Bb64.bench_eval(np.tile(q0, (32, 1)), np.tile(t0, (32, 1)), 10, 100, kernel_pass=False)[0] for _ in range(3))
+out['batch32_f64_step_us'] = ms / 100 * 1e3
+out['c2_kernel_us'] = B.bench_kernel(q0, t0, 10, 300) * 1e3
 print(json.dumps(out))
 '''
 libs = sys.argv[1:3]
