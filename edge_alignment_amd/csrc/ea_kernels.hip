@@ -79,7 +79,14 @@ __device__ int g_lm_probe_row = 0;
 
 template <typename T> __device__ __forceinline__ T t_rcp(T x);
 template <> __device__ __forceinline__ float t_rcp<float>(float x) { return __builtin_amdgcn_rcpf(x); }
-template <> __device__ __forceinline__ double t_rcp<double>(double x) { return 1.0 / x; }
+// v_rcp_f64 + two Newton steps: 5 instructions and <= 1 ulp instead of the ~14 of an IEEE division (three per point)
+template <> __device__ __forceinline__ double t_rcp<double>(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
 
 template <typename T> __device__ __forceinline__ T t_log(T x);
 // v_log_f32 is log2 and needs no denormal pre-scaling here: its only caller passes 1 + s / a^2 >= 1
