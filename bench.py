@@ -245,6 +245,14 @@ def main():
                      for Px, cfgx in zip(Ps, problems))
             res = {"evals_per_s": npts / (ms / 100 * 1e-3), "us_per_step": ms / 100 * 1e3, "kernel_us": msk * 1e3,
                    "roofline_frac": by / (msk * 1e-3) / 1e9 / HBM_PEAK_GBS, "points": int(npts)}
+            if m > 1:  # the production shape of BASELINE config C4: all frame pairs of a GPU solved by one launch sequence
+                Bx.solve(Q, T)
+                tsv = time.perf_counter()
+                for _ in range(5):
+                    qs, tsol, ss = Bx.solve(Q, T)
+                elv = (time.perf_counter() - tsv) / 5
+                res["solve_ms"] = elv * 1e3
+                res["lm_iters_per_s"] = sum(x["num_iterations"] for x in ss) / elv
             Bx.close()
             for Px in Ps:
                 Px.close()

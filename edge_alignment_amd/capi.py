@@ -182,19 +182,23 @@ def default_options(**kw):
     return o
 
 
+_TRACE_FIELDS = ("it_cost", "it_cost_change", "it_gradient_max_norm", "it_step_norm", "it_relative_decrease", "it_radius")
+_TRACE_OFF = Summary.it_cost.offset // 8
+
+
 def summary_to_dict(s):
     ni = min(s.num_iterations + 1, MAX_TRACE)
-    return dict(termination=s.termination, why=WHY[s.why], num_iterations=s.num_iterations,
-                num_successful_steps=s.num_successful_steps,
-                num_unsuccessful_steps=s.num_unsuccessful_steps,
-                initial_cost=s.initial_cost, final_cost=s.final_cost,
-                num_point_evals=s.num_point_evals, total_time_ms=s.total_time_ms,
-                it_cost=np.array(s.it_cost[:ni]), it_cost_change=np.array(s.it_cost_change[:ni]),
-                it_gradient_max_norm=np.array(s.it_gradient_max_norm[:ni]),
-                it_step_norm=np.array(s.it_step_norm[:ni]),
-                it_relative_decrease=np.array(s.it_relative_decrease[:ni]),
-                it_radius=np.array(s.it_radius[:ni]),
-                it_successful=np.array(s.it_successful[:ni]))
+    # one zero-copy view of the struct's six double[MAX_TRACE] arrays instead of six ctypes slices
+    tr = np.frombuffer(s, dtype=np.float64, count=6 * MAX_TRACE, offset=8 * _TRACE_OFF).reshape(6, MAX_TRACE)[:, :ni].copy()
+    d = dict(termination=s.termination, why=WHY[s.why], num_iterations=s.num_iterations,
+             num_successful_steps=s.num_successful_steps,
+             num_unsuccessful_steps=s.num_unsuccessful_steps,
+             initial_cost=s.initial_cost, final_cost=s.final_cost,
+             num_point_evals=s.num_point_evals, total_time_ms=s.total_time_ms,
+             it_successful=np.frombuffer(s, dtype=np.int32, count=ni, offset=Summary.it_successful.offset).copy())
+    for k, name in enumerate(_TRACE_FIELDS):
+        d[name] = tr[k]
+    return d
 
 
 class Problem:
