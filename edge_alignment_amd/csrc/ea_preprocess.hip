@@ -610,7 +610,9 @@ hipError_t launch_canny(const uint8_t *bgr, int H, int W, int low, int high, int
     rounds += 4;
     // the flag is the OR over the four launches: it can only be clear when the last one changed nothing either
     if (!h) break;
-    if (rounds > 4 * (H + W)) return hipErrorUnknown;  // cannot happen: every launch that reports a change grows the edge set
+    // safety net only: a launch that reports a change has grown the edge set, and a chain crosses at least one tile
+    // per launch, so the number of tiles bounds the launches
+    if (rounds > (int)(((long long)H * W) / 256) + 64) return hipErrorUnknown;
   }
   if (rounds_out) *rounds_out = rounds;
   const int npix = H * W;
