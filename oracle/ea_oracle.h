@@ -20,7 +20,7 @@
  * independent Jacobian derivations (forward-mode Jet<7> of the literal functor  vs  analytic
  * 1x6 row) plus finite differences and a numpy restatement (oracle/ea_numpy.py), and planted-
  * pose recoveries.  The only reference-held number reproduced is the residual-block count
- * 1482 = ceil(44457/30) of `standalone/README.md:34` (tests/test_preprocess_oracle.py).
+ * 1482 = ceil(44457/30) of `standalone/README.md:34` (tests/test_golden_and_preprocess.py).
  */
 #ifndef EA_ORACLE_H
 #define EA_ORACLE_H

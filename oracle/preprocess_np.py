@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE ONLY — PARITY UNPINNED except for one number: `get_aX` on the bundled frame 1
 yields 44 457 edge points, i.e. ceil(44457/30) = 1482 residual blocks, the count in the
-reference's only recorded log (standalone/README.md:34).  tests/test_preprocess_oracle.py holds
+reference's only recorded log (standalone/README.md:34).  tests/test_golden_and_preprocess.py holds
 that check.
 
 Follows (ref = /root/reference):
