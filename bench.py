@@ -78,8 +78,8 @@ def cpu_baseline(cfg, loss, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="c2", choices=["c2", "c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
@@ -150,7 +150,7 @@ def main():
     # (profiles/); kernel_ms_isolated: an event pair around every single launch of the timed pattern, which also
     # contains the command processor's dispatch (~2.6 us) because nothing is in flight to hide it.
     _, ms_kernel_isolated = B.bench_eval(q0, t0, 2, min(args.steps, 64))
-    ms_kernel = B.bench_kernel(q0, t0, 10, max(args.steps, 100))
+    ms_kernel = B.bench_kernel(q0, t0, 10, min(max(args.steps, 100), 1000))
     bytes_launch = algorithmic_bytes(n_pts, H, W, esize)
     achieved = bytes_launch / (ms_kernel * 1e-3) / 1e9
     traffic = None
