@@ -59,6 +59,25 @@ def test_argument_validation_needs_no_device(lib):
     assert lib.ea_batch_create(C.byref(h), None, 0) == -1
     assert lib.ea_problem_set_loss(None, 1, 1.0) == -1
     assert lib.ea_problem_num_points(None) == 0
+    # the drivers on top of the solve and the frame producers reject missing arguments before they touch a device
+    q = (C.c_double * 4)(1, 0, 0, 0)
+    t = (C.c_double * 3)()
+    assert lib.ea_solve_pyramid(None, 3, None, q, t, None) == -1
+    from edge_alignment_amd import capi
+    assert lib.ea_solve_sharded(None, None, C.cast(None, capi.ALLREDUCE_FN), None, q, t, None) == -1
+    assert lib.ea_tracker_create(None, None, 0, 0, 0) == -1
+    assert lib.ea_tracker_create(C.byref(h), None, 0, 0, 7) == -1          # unknown pre-processing flavour
+    assert lib.ea_tracker_push_frame(None, None, None, 480, 640, 5000.0, None, q, t, None, None) == -1
+    assert lib.ea_tracker_problem(None) is None
+    lib.ea_tracker_destroy(None)                                            # like free(NULL)
+    assert lib.ea_problem_set_ref_frame(None, None, None, 480, 640, 5000.0, 35) == -1
+    assert lib.ea_problem_set_ref_frame_canny(None, None, None, 480, 640, 5000.0, 30.0, 90.0) == -1
+    assert lib.ea_problem_set_ref_frame_masked(None, None, None, None, 480, 640, 5000.0, 35) == -1
+    assert lib.ea_problem_set_ref_frame_ros(None, None, None, 240, 320, 150.0, 100.0) == -1
+    assert lib.ea_problem_set_now_frame(None, None, 480, 640, 35, 1, 1) == -1
+    assert lib.ea_problem_set_now_frame_canny(None, None, None, 480, 640, 30.0, 90.0, 1, 0.0, 1.0) == -1
+    assert lib.ea_problem_set_now_frame_ros(None, None, 240, 320, 150.0, 100.0) == -1
+    assert b"NULL" in lib.ea_last_error() or b"argument" in lib.ea_last_error()
 
 
 def test_product_never_imports_the_oracle():
