@@ -174,3 +174,24 @@ def test_box_blur_and_canny_pipeline_on_the_bundled_frames():
     assert dt.dtype == np.float32 and dt.min() == 0.0 and dt.max() == 1.0 and np.all(dt[edges > 0] == 0.0)
     raw = pp.get_distance_transform2(bgr, normalize=None)
     assert raw.max() > 1.0 and np.all(raw[edges > 0] == 0.0)
+
+
+def test_canny_and_ros_restatements_frozen():
+    """Build-owned regression pins (not reference data: the reference records nothing for these stages): edge counts
+    and CRCs of the Canny-flavour and ROS-flavour restatements on the bundled frames, so that a change to
+    oracle/preprocess_np.py cannot go unnoticed while the GPU tests keep agreeing with it."""
+    import zlib
+    from oracle import preprocess_np as pp
+    G = os.path.join(ROOT, "tests", "golden", "rgbd")
+    b1 = pp.load_rgb_as_bgr(os.path.join(G, "rgb_1.png"))
+    d1 = pp.load_depth_u16(os.path.join(G, "depth_1.png"))
+    b3 = pp.load_rgb_as_bgr(os.path.join(G, "rgb_3.png"))
+    e1, e3 = pp.canny_edges_of_frame(b1), pp.canny_edges_of_frame(b3)
+    assert int((e1 > 0).sum()) == 27364 and int((e3 > 0).sum()) == 25429
+    assert zlib.crc32(e3.tobytes()) == 2720892122
+    aX, _ = pp.get_aX_canny(b1, d1, 525.0, 525.0, 319.5, 239.5)
+    assert aX.shape[1] == 21766
+    assert zlib.crc32(pp.get_distance_transform2(b3).tobytes()) == 2656819730
+    half = b3[::2, ::2].copy()
+    assert int((pp.canny_u8(half, 150, 100, l2_gradient=True) > 0).sum()) == 10048
+    assert zlib.crc32(pp.ros_now_distance_transform(half).tobytes()) == 2893064688
