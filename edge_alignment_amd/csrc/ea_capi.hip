@@ -1216,6 +1216,8 @@ extern "C" int ea_problem_set_ref_frame_masked(ea_problem *p, const uint8_t *bgr
 // mask (0 = edge / DT source) -> chamfer DT -> [normalise to [lo, hi]] -> the problem's padded DT image
 static int dt_from_mask(ea_problem *p, WsCarver &ws, const uint8_t *d_mask, int height, int width, int normalize,
                         double lo, double hi, int **dist_out, float **plain_out, bool precise = false) {
+  // the row pass stages one image row of column distances in LDS (4 bytes per pixel, 64 KB)
+  if (width > 16384) return fail(EA_ERR_INVALID_ARG, "frames wider than 16384 pixels are not supported by the DT producers");
   const size_t np = (size_t)height * width;
   int *d_G = ws.take<int>(np), *d_dist = ws.take<int>(np);  // d_dist doubles as the float32 distance when `precise`
   int *d_scan = ws.take<int>(4 * (size_t)((height + 31) / 32) * width);
