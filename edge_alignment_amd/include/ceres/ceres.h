@@ -114,6 +114,19 @@ class Problem {
   }
   int NumResidualBlocks() const { return (int)blocks_.size(); }
   int NumResiduals() const { return (int)blocks_.size(); }
+  int NumParameterBlocks() const { return blocks_.empty() ? 0 : 2; }  // the quaternion and the translation
+  int NumParameters() const { return blocks_.empty() ? 0 : 7; }
+
+  // src/SolveEA.cpp:241  problem.Evaluate(Problem::EvaluateOptions(), &cost, &residuals, NULL, NULL)
+  // cost = 1/2 sum rho(r^2); residuals: one per block in the order they were added, loss-corrected like Ceres'
+  // apply_loss_function = true; gradient: the 6 tangent-space entries (J^T r).  The sparse Jacobian is not offered.
+  struct EvaluateOptions {
+    bool apply_loss_function = true;
+    int ea_dtype = EA_F64;
+    int ea_device = 0;
+  };
+  inline bool Evaluate(const EvaluateOptions &opt, double *cost, std::vector<double> *residuals,
+                       std::vector<double> *gradient, void *jacobian);
 
  private:
   struct Block {
@@ -223,38 +236,38 @@ inline void Solve(const Solver::Options &options, Problem *problem, Solver::Summ
 
 class ProblemAccess {  // keeps Problem's internals private to user code
  public:
-  static void Run(const Solver::Options &options, Problem *problem, Solver::Summary *summary) {
-    Solver::Summary &s = *summary;
-    s = Solver::Summary();
+  // Blocks -> residual families (same interpolator, intrinsics, functor variant and loss) -> one GPU problem per
+  // family, the first one carrying the others as terms: all of them share (q, t), the way the reference adds
+  // camera-1 and camera-2 blocks to one ceres::Problem (standalone_edge_align.cpp:791-803).  order[k] = indices of
+  // family k's blocks in the order they were added.  Returns EA_OK, a libea_hip error code, or -1000 with *err set
+  // for a problem this facade cannot host.
+  static int Build(Problem *problem, int dtype, int device, std::vector<ea_problem *> *ps_out,
+                   std::vector<std::vector<int>> *order, std::string *err) {
     const auto &blocks = problem->blocks_;
-    s.num_residual_blocks = s.num_residuals = (int)blocks.size();
-    auto fail = [&](const std::string &m) { s.termination_type = FAILURE; s.message = m; };
-    if (options.minimizer_type != TRUST_REGION) return fail("only TRUST_REGION is supported");
-    if (blocks.empty()) { s.termination_type = CONVERGENCE; s.message = "No residual blocks."; s.initial_cost = s.final_cost = 0; s.num_successful_steps = s.num_unsuccessful_steps = 0; return; }
     const auto &b0 = blocks[0];
-    // Split the blocks into residual families: same interpolator, intrinsics, functor variant and loss.
-    // The first family becomes the problem, the others its terms; all of them share (q, t), the way the
-    // reference adds camera-1 and camera-2 blocks to one ceres::Problem (standalone_edge_align.cpp:791-803).
-    struct Family { const Problem::Block *first; std::vector<double> xyz; };
+    struct Family { const Problem::Block *first; std::vector<double> xyz; std::vector<int> idx; };
     std::vector<Family> fams;
     for (size_t i = 0; i < blocks.size(); ++i) {
       const auto &b = blocks[i];
-      if (!b.ok) return fail("residual block is not an EAResidue-family block (this facade only hosts the edge-alignment hot path)");
-      if (b.q != b0.q || b.t != b0.t) return fail("all residual blocks must share one (quaternion, translation) pair");
+      if (!b.ok) { *err = "residual block is not an EAResidue-family block (this facade only hosts the edge-alignment hot path)"; return -1000; }
+      if (b.q != b0.q || b.t != b0.t) { *err = "all residual blocks must share one (quaternion, translation) pair"; return -1000; }
       Family *f = nullptr;
       for (auto &cand : fams)
         if (SameFamily(*cand.first, b)) { f = &cand; break; }
-      if (!f) { fams.push_back(Family{&b, {}}); f = &fams.back(); }
+      if (!f) { fams.push_back(Family{&b, {}, {}}); f = &fams.back(); }
       f->xyz.push_back(b.info.X); f->xyz.push_back(b.info.Y); f->xyz.push_back(b.info.Z);
+      f->idx.push_back((int)i);
     }
-    if (problem->quat_param_on_ != b0.q)
-      return fail("the quaternion block needs QuaternionParameterization (problem.SetParameterization)");
-    std::vector<ea_problem *> ps(fams.size(), nullptr);
+    if (problem->quat_param_on_ != b0.q) { *err = "the quaternion block needs QuaternionParameterization (problem.SetParameterization)"; return -1000; }
+    std::vector<ea_problem *> &ps = *ps_out;
+    ps.assign(fams.size(), nullptr);
+    order->clear();
     int rc = EA_OK;
     for (size_t k = 0; k < fams.size() && rc == EA_OK; ++k) {
       const auto &bi = fams[k].first->info;
+      order->push_back(fams[k].idx);
       ea_camera cam = {bi.fx, bi.fy, bi.cx, bi.cy};
-      rc = ea_problem_create(&ps[k], &cam, options.ea_dtype, options.ea_device);
+      rc = ea_problem_create(&ps[k], &cam, dtype, device);
       if (rc == EA_OK) rc = ea_problem_set_points(ps[k], fams[k].xyz.data(), (int64_t)(fams[k].xyz.size() / 3), 3);
       if (rc == EA_OK) rc = ea_problem_set_dt(ps[k], bi.grid_data, bi.grid_rows, bi.grid_cols);
       if (rc == EA_OK) rc = ea_problem_set_flavour(ps[k], bi.z_guard, bi.z_eps, bi.rot_transposed);
@@ -267,6 +280,58 @@ class ProblemAccess {  // keeps Problem's internals private to user code
       }
       if (rc == EA_OK && k > 0) rc = ea_problem_add_term(ps[0], ps[k]);
     }
+    return rc;
+  }
+
+  static bool Evaluate(Problem *problem, const Problem::EvaluateOptions &opt, double *cost, std::vector<double> *residuals,
+                       std::vector<double> *gradient, void *jacobian) {
+    if (jacobian) return false;  // the N x 6 Jacobian is never materialised on this path
+    const auto &blocks = problem->blocks_;
+    if (blocks.empty()) {
+      if (cost) *cost = 0.0;
+      if (residuals) residuals->clear();
+      if (gradient) gradient->clear();
+      return true;
+    }
+    std::vector<ea_problem *> ps;
+    std::vector<std::vector<int>> order;
+    std::string err;
+    int rc = Build(problem, opt.ea_dtype, opt.ea_device, &ps, &order, &err);
+    const double *q = blocks[0].q, *t = blocks[0].t;
+    double c = 0.0, JtJ[36], Jtr[6];
+    int64_t bad = 0;
+    if (rc == EA_OK) rc = ea_eval(ps[0], q, t, &c, JtJ, Jtr, &bad);  // the problem with all its terms
+    if (rc == EA_OK && residuals) {
+      residuals->assign(blocks.size(), 0.0);
+      for (size_t k = 0; k < ps.size() && rc == EA_OK; ++k) {
+        std::vector<double> r(order[k].size());
+        // a term evaluated on its own: its residuals in the order its blocks were added
+        rc = ea_eval_points(ps[k], q, t, r.data(), nullptr, opt.apply_loss_function ? 1 : 0);
+        for (size_t i = 0; i < r.size(); ++i) (*residuals)[order[k][i]] = r[i];
+      }
+    }
+    for (auto *p : ps)
+      if (p) ea_problem_destroy(p);
+    if (rc != EA_OK || bad > 0) return false;  // Ceres: a failed residual block fails the evaluation
+    if (cost) *cost = c;
+    if (gradient) gradient->assign(Jtr, Jtr + 6);
+    return true;
+  }
+
+  static void Run(const Solver::Options &options, Problem *problem, Solver::Summary *summary) {
+    Solver::Summary &s = *summary;
+    s = Solver::Summary();
+    const auto &blocks = problem->blocks_;
+    s.num_residual_blocks = s.num_residuals = (int)blocks.size();
+    auto fail = [&](const std::string &m) { s.termination_type = FAILURE; s.message = m; };
+    if (options.minimizer_type != TRUST_REGION) return fail("only TRUST_REGION is supported");
+    if (blocks.empty()) { s.termination_type = CONVERGENCE; s.message = "No residual blocks."; s.initial_cost = s.final_cost = 0; s.num_successful_steps = s.num_unsuccessful_steps = 0; return; }
+    const auto &b0 = blocks[0];
+    std::vector<ea_problem *> ps;
+    std::vector<std::vector<int>> order;
+    std::string berr;
+    int rc = Build(problem, options.ea_dtype, options.ea_device, &ps, &order, &berr);
+    if (rc == -1000) return fail(berr);
     ea_options o;
     ea_default_options(&o);
     o.max_num_iterations = options.max_num_iterations;
@@ -315,6 +380,11 @@ class ProblemAccess {  // keeps Problem's internals private to user code
     return a->ea_scale() == b->ea_scale();
   }
 };
+
+inline bool Problem::Evaluate(const EvaluateOptions &opt, double *cost, std::vector<double> *residuals,
+                              std::vector<double> *gradient, void *jacobian) {
+  return ProblemAccess::Evaluate(this, opt, cost, residuals, gradient, jacobian);
+}
 
 inline void Solve(const Solver::Options &options, Problem *problem, Solver::Summary *summary) {
   ProblemAccess::Run(options, problem, summary);

@@ -50,6 +50,16 @@ int main(int argc, char **argv) {
   ceres::LocalParameterization *quaternion_parameterization = new ceres::QuaternionParameterization;
   problem.SetParameterization(b_quat_a, quaternion_parameterization);
 
+  // src/SolveEA.cpp:241-253: problem.Evaluate + the Num* queries, at the initial pose
+  double cost0 = -1.0;
+  std::vector<double> all_residues, grad0;
+  const bool eval_ok = problem.Evaluate(ceres::Problem::EvaluateOptions(), &cost0, &all_residues, &grad0, NULL);
+  double r2 = 0.0;
+  for (double r : all_residues) r2 += r * r;
+  std::cerr << "Evaluate: ok " << eval_ok << " cost " << cost0 << " residuals " << all_residues.size() << " NumParameterBlocks "
+            << problem.NumParameterBlocks() << " NumParameters " << problem.NumParameters() << " NumResidualBlocks "
+            << problem.NumResidualBlocks() << "\n";
+
   auto start1 = std::chrono::high_resolution_clock::now();
   ceres::Solver::Options options;
   options.minimizer_progress_to_stdout = false;
@@ -63,8 +73,9 @@ int main(int argc, char **argv) {
   std::cerr << summary.FullReport() << "\n";
   // ---- end of reference text --------------------------------------------------------------------
 
-  std::printf("%.17g %.17g %.17g %.17g %.17g %.17g %.17g %d %d %.17g %.17g\n", b_quat_a[0], b_quat_a[1], b_quat_a[2],
-              b_quat_a[3], b_t_a[0], b_t_a[1], b_t_a[2], summary.num_successful_steps + summary.num_unsuccessful_steps,
-              (int)summary.termination_type, summary.initial_cost, summary.final_cost);
+  std::printf("%.17g %.17g %.17g %.17g %.17g %.17g %.17g %d %d %.17g %.17g %d %.17g %d %.17g %d\n", b_quat_a[0], b_quat_a[1],
+              b_quat_a[2], b_quat_a[3], b_t_a[0], b_t_a[1], b_t_a[2], summary.num_successful_steps + summary.num_unsuccessful_steps,
+              (int)summary.termination_type, summary.initial_cost, summary.final_cost, (int)eval_ok, cost0,
+              (int)all_residues.size(), 0.5 * r2, (int)grad0.size());
   return summary.termination_type == ceres::FAILURE ? 1 : 0;
 }

@@ -47,6 +47,11 @@ def test_edge_align_test1_call_sequence(binaries, bundled_pair, golden, tmp_path
         assert iters == int(golden[tag + "_lm_successful"])
         assert v[9] == pytest.approx(float(golden[tag + "_lm_it_cost"][0]), rel=1e-10)
         assert "Residual blocks" in out.stderr and "CONVERGENCE" in out.stderr
+        # problem.Evaluate (src/SolveEA.cpp:241) at the initial pose: the cost the solve starts from, one
+        # loss-corrected residual per block (1/2 sum r_c^2 is that cost for Cauchy only approximately: rho(s) <= s)
+        assert int(v[11]) == 1 and v[12] == pytest.approx(v[9], rel=1e-12)
+        assert int(v[13]) == -(-bundled_pair["aX"].shape[1] // stride) and int(v[15]) == 6
+        assert 0.0 < v[14] <= v[12] * (1 + 1e-12)
 
 
 def test_solve_ea_class_dogleg(binaries, oracle, bundled_pair, tmp_path):
