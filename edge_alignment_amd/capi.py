@@ -23,7 +23,7 @@ MAX_TRACE = 128
 
 EXPORTED = [
     "ea_last_error", "ea_version", "ea_device_count", "ea_default_options",
-    "ea_problem_create", "ea_problem_destroy", "ea_problem_set_points",
+    "ea_problem_create", "ea_problem_destroy", "ea_problem_set_points", "ea_problem_set_point_order", "ea_problem_get_point_order",
     "ea_problem_set_points_device", "ea_problem_set_dt", "ea_problem_set_dt_image_device",
     "ea_problem_set_loss", "ea_problem_set_flavour", "ea_problem_num_points",
     "ea_eval", "ea_eval_points", "ea_cost", "ea_solve",
@@ -100,6 +100,8 @@ def load():
     L.ea_problem_destroy.restype = None
     L.ea_problem_set_points.argtypes = [vp, dp, C.c_int64, C.c_int64]
     L.ea_problem_set_points_device.argtypes = [vp, vp, vp, vp, C.c_int64]
+    L.ea_problem_set_point_order.argtypes = [vp, C.c_int]
+    L.ea_problem_get_point_order.argtypes = [vp, C.POINTER(C.c_int)]
     L.ea_problem_set_dt.argtypes = [vp, dp, C.c_int, C.c_int]
     L.ea_problem_set_dt_image_device.argtypes = [vp, vp, C.c_int, C.c_int]
     L.ea_problem_set_loss.argtypes = [vp, C.c_int, C.c_double]
@@ -232,6 +234,16 @@ class Problem:
         if xyz.ndim != 2 or xyz.shape[1] < 3:
             raise ValueError("xyz must be (n, >=3)")
         _check(load().ea_problem_set_points(self._h, _dp(xyz), xyz.shape[0], xyz.shape[1]))
+
+    def set_point_order(self, tile_px):
+        """storage order for the next set_points: tiles of tile_px pixels (> 0), the caller's order (0), automatic (< 0)"""
+        _check(load().ea_problem_set_point_order(self._h, int(tile_px)))
+
+    @property
+    def point_order(self):
+        v = C.c_int()
+        _check(load().ea_problem_get_point_order(self._h, C.byref(v)))
+        return v.value
 
     def set_points_device(self, x_ptr, y_ptr, z_ptr, n):
         _check(load().ea_problem_set_points_device(self._h, x_ptr, y_ptr, z_ptr, n))

@@ -129,6 +129,16 @@ void ea_problem_destroy(ea_problem *p);
  * a_X of get_aX (utils.cpp:268-280) or 3 for list_edge_ref (SolveEA.cpp:55).  Converted once
  * to SoA x[],y[],z[] of the problem dtype in HBM. */
 int ea_problem_set_points(ea_problem *p, const double *xyz, int64_t n, int64_t stride_elems);
+/* Storage order of the points ea_problem_set_points uploads after this call.  tile_px > 0: tiles of
+ * tile_px x tile_px pixels of the reference frame (identity-pose projection), tiles in raster order,
+ * the caller's order inside a tile -- a wavefront's points then sample a compact patch of the DT image;
+ * 0: the caller's order (the reference's: residual blocks in the order of the a_X columns);
+ * < 0 (default): automatic, tiles of 16 px from 200 000 points up.  Only the order of summation
+ * changes (results agree to rounding); per-point outputs (ea_eval_points) and ea_problem_get_points
+ * stay in the caller's order. */
+int ea_problem_set_point_order(ea_problem *p, int tile_px);
+/* the tile size the stored points are ordered by (0 = the caller's order) */
+int ea_problem_get_point_order(const ea_problem *p, int *tile_px);
 /* same, from SoA arrays of the problem's dtype already resident in HBM (borrowed, must
  * outlive the problem) */
 int ea_problem_set_points_device(ea_problem *p, const void *x, const void *y, const void *z,

@@ -1,0 +1,65 @@
+"""Storage order of the edge points (ea_problem_set_point_order): tile order changes the order of summation only --
+per-point residuals / Jacobian rows are bit-identical and come back in the caller's order, the sums agree to rounding,
+the solve lands on the same pose; large point sets switch to it on their own."""
+import numpy as np
+import pytest
+
+from edge_alignment_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(cfg, dtype, tile, xyz=None):
+    P = capi.Problem(*cfg["K"], dtype=dtype)
+    P.set_point_order(tile)
+    P.set_points(cfg["xyz"] if xyz is None else xyz)
+    P.set_dt_grid(cfg["grid"])
+    P.set_loss(capi.LOSS_CAUCHY, 1.0)
+    return P
+
+
+@pytest.mark.parametrize("dtype", [capi.EA_F64, capi.EA_F32])
+def test_tile_order_changes_only_the_summation_order(dtype):
+    cfg = synth.config_c2_twin(seed=11, n_points=30000)
+    rng = np.random.default_rng(0)
+    xyz = cfg["xyz"][rng.permutation(len(cfg["xyz"]))]  # an order with no structure at all
+    q = synth.quat_from_axis_angle([0.3, -1.0, 0.2], np.deg2rad(1.5))
+    t = np.array([0.02, -0.01, 0.015])
+    P0, P1 = _problem(cfg, dtype, 0, xyz), _problem(cfg, dtype, 16, xyz)
+    try:
+        assert P0.point_order == 0 and P1.point_order == 16
+        # what the problem holds comes back in the caller's order
+        back = P1.get_points()
+        ref = xyz[:, :3] if dtype == capi.EA_F64 else xyz[:, :3].astype(np.float32).astype(np.float64)
+        assert np.array_equal(back, ref)
+        # per-point outputs: same arithmetic per point, caller's order
+        r0, J0 = P0.eval_points(q, t)
+        r1, J1 = P1.eval_points(q, t)
+        assert np.array_equal(r0, r1, equal_nan=True) and np.array_equal(J0, J1, equal_nan=True)
+        # the sums: same terms, different order
+        e0, e1 = P0.eval(q, t), P1.eval(q, t)
+        tol = 1e-12 if dtype == capi.EA_F64 else 2e-5
+        for k in ("cost", "JtJ", "Jtr"):
+            a, b = np.asarray(e0[k]), np.asarray(e1[k])
+            assert np.abs(a - b).max() <= tol * np.abs(a).max()
+        assert e0["n_invalid"] == e1["n_invalid"]
+        # and the solve
+        qa, ta, sa = P0.solve([1, 0, 0, 0], [0, 0, 0])
+        qb, tb, sb = P1.solve([1, 0, 0, 0], [0, 0, 0])
+        assert sa["why"] == sb["why"]
+        qb = qb if np.dot(qa, qb) >= 0 else -qb
+        ang = 2 * np.linalg.norm(qa - qb)  # small-angle form (arccos of a dot product near 1 has no digits left)
+        assert ang < (1e-9 if dtype == capi.EA_F64 else 1e-4) and np.abs(ta - tb).max() < (1e-9 if dtype == capi.EA_F64 else 1e-3)
+    finally:
+        P0.close(); P1.close()
+
+
+def test_large_point_sets_are_tile_ordered_automatically():
+    cfg = synth.make_problem(480, 640, 210000, 900, 5, 525.0, 525.0, 319.5, 239.5)
+    P = _problem(cfg, capi.EA_F32, -1)
+    S = _problem(synth.config_c2_twin(seed=3, n_points=5000), capi.EA_F32, -1)
+    try:
+        assert P.point_order == 16 and S.point_order == 0
+        assert np.array_equal(P.get_points(), cfg["xyz"][:, :3].astype(np.float32).astype(np.float64))
+    finally:
+        P.close(); S.close()
