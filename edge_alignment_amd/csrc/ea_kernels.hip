@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_step_kernel(
     LMState st = s_st;
 #pragma unroll
     for (int i = 0; i < kAccSlots; ++i) acc[i] = s_acc[i];
-    if (st.num_evals == 0) lm_begin<STRAT>(&st, cold + p, traces + p, &opt, acc, &pend);
+    if (EA_UNLIKELY(st.num_evals == 0)) lm_begin<STRAT>(&st, cold + p, traces + p, &opt, acc, &pend);
     else lm_advance<STRAT>(&st, cold + p, traces + p, &opt, acc, &pend);
     EA_LM_STAMP(3, ev_);
     make_pose_core(st.cand, st.rot_transposed, st.running, &s_ps, /*zero_unused_G=*/false);

@@ -20,6 +20,12 @@
 #define EA_LM_PROBE(k) do {} while (0)  // diagnostic build only (scripts/build_stamps.sh)
 #endif
 
+// Branch-layout hints for the serial state machine: it runs cold on one lane (a different CU every launch), so the
+// usual path -- step accepted, nothing converged, linear solve fine -- should be the fall-through one that the
+// sequential instruction prefetch covers.
+#define EA_LIKELY(x) __builtin_expect(!!(x), 1)
+#define EA_UNLIKELY(x) __builtin_expect(!!(x), 0)
+
 namespace ea {
 
 struct LMOptions {
@@ -85,7 +91,7 @@ EA_HD inline double norm_n(const double *v, int n) {
 // QuaternionParameterization::Plus: x_plus = [cos|d|, sin|d|/|d| d] (x) x
 EA_HD inline void quat_plus(const double x[4], const double d[3], double out[4]) {
   const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-  if (nd > 0.0) {
+  if (EA_LIKELY(nd > 0.0)) {
     double sn, cs;
     sincos(nd, &sn, &cs);
     const double s = sn / nd;
@@ -119,7 +125,7 @@ EA_HD inline void make_pose_core(const double x[7], int rot_transposed, int acti
   R[6] = 2.0 * (qx * qz - w * qy); R[7] = 2.0 * (qy * qz + w * qx); R[8] = 1.0 - 2.0 * (qx * qx + qy * qy);
   const double n2 = w * w + qx * qx + qy * qy + qz * qz;
   const int unit_q = (fabs(n2 - 1.0) <= 1e-12 && !rot_transposed) ? 1 : 0;
-  if (!unit_q) {
+  if (EA_UNLIKELY(!unit_q)) {
     const double dR[4][9] = {
         {0, -2 * qz, 2 * qy, 2 * qz, 0, -2 * qx, -2 * qy, 2 * qx, 0},
         {0, 2 * qy, 2 * qz, 2 * qy, -4 * qx, -2 * w, 2 * qz, 2 * w, -4 * qx},
@@ -185,7 +191,7 @@ EA_HD inline bool solve_spd6(const double A[21] /* packed upper */, const double
     double d = A[sym6(j, j)] + D2[j];
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= L[6 * j + k] * M[6 * j + k];
-    if (!(d > 0.0)) return false;
+    if (EA_UNLIKELY(!(d > 0.0))) return false;
     inv[j] = ea_rcp(d);
 #pragma unroll
     for (int i = j + 1; i < 6; ++i) {
@@ -213,7 +219,7 @@ EA_HD inline bool solve_spd6(const double A[21] /* packed upper */, const double
   }
 #pragma unroll
   for (int i = 0; i < 6; ++i)
-    if (!(fabs(y[i]) <= DBL_MAX)) return false;
+    if (EA_UNLIKELY(!(fabs(y[i]) <= DBL_MAX))) return false;
   return true;
 }
 
@@ -253,13 +259,13 @@ EA_HD inline void lm_pend_trace(const LMState *s, LMPending *p, int it, double c
 }
 
 EA_HD inline void lm_flush(const LMPending *p, LMCold *c, LMTrace *tr, const double acc[kAccSlots]) {
-  if (p->store_system) {
+  if (EA_LIKELY(p->store_system)) {
 #pragma unroll
     for (int k = 0; k < 21; ++k) c->A[k] = acc[kAccJtJ + k];
 #pragma unroll
     for (int a = 0; a < 6; ++a) c->g[a] = acc[kAccJtr + a];
   }
-  if (tr && p->trace_it >= 0 && p->trace_it < kTrace) {
+  if (EA_LIKELY(tr && p->trace_it >= 0 && p->trace_it < kTrace)) {
     const int it = p->trace_it;
     tr->it_cost[it] = p->cost;
     tr->it_cost_change[it] = p->cost_change;
@@ -333,7 +339,7 @@ EA_HD inline bool lm_strategy_step(LMState *s, LMCold *c, const LMOptions *o, co
 #pragma unroll
     for (int i = 0; i < 6; ++i) D2[i] = s->diagonal[i] * inv_radius;
     s->reuse_diagonal = 1;
-    if (!solve_spd6(As, D2, gs, y)) return false;
+    if (EA_UNLIKELY(!solve_spd6(As, D2, gs, y))) return false;
 #pragma unroll
     for (int i = 0; i < 6; ++i) step[i] = -y[i];
     return true;
@@ -407,13 +413,13 @@ EA_HD inline void lm_prepare_next(LMState *s, LMCold *c, LMTrace *tr, const LMOp
   double As[21], gs[6];
   bool have_system = false;
   for (;;) {
-    if (s->iteration >= o->max_num_iterations) { lm_finish(s, 1, 4); return; }
-    if (s->gradient_max_norm <= o->gradient_tolerance) { lm_finish(s, 0, 2); return; }
-    if (s->radius <= o->min_trust_region_radius) { lm_finish(s, 0, 5); return; }
+    if (EA_UNLIKELY(s->iteration >= o->max_num_iterations)) { lm_finish(s, 1, 4); return; }
+    if (EA_UNLIKELY(s->gradient_max_norm <= o->gradient_tolerance)) { lm_finish(s, 0, 2); return; }
+    if (EA_UNLIKELY(s->radius <= o->min_trust_region_radius)) { lm_finish(s, 0, 5); return; }
     s->iteration += 1;
-    if (!have_system) {
+    if (EA_LIKELY(!have_system)) {
       double A[21], g[6];
-      if (fresh) {
+      if (EA_LIKELY(fresh)) {
 #pragma unroll
         for (int k = 0; k < 21; ++k) A[k] = acc[kAccJtJ + k];
 #pragma unroll
@@ -436,7 +442,7 @@ EA_HD inline void lm_prepare_next(LMState *s, LMCold *c, LMTrace *tr, const LMOp
     double step[6];
     bool ok = lm_strategy_step<STRAT>(s, c, o, As, gs, step);
     EA_LM_PROBE(3);
-    if (ok) {
+    if (EA_LIKELY(ok)) {
       // model_cost_change = -(Js s)^T (r + Js s / 2) = -(g^T s + s^T A s / 2)
       double gts = 0.0, diag = 0.0, off = 0.0;
 #pragma unroll
@@ -450,7 +456,7 @@ EA_HD inline void lm_prepare_next(LMState *s, LMCold *c, LMTrace *tr, const LMOp
       if (!(s->model_cost_change > 0.0)) ok = false;
     }
     EA_LM_PROBE(4);
-    if (ok) {
+    if (EA_LIKELY(ok)) {
       double delta[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) delta[i] = step[i] * s->S[i];
@@ -478,7 +484,7 @@ EA_HD inline void lm_begin(LMState *s, LMCold *c, LMTrace *tr, const LMOptions *
   pend->store_system = 0;
   pend->trace_it = -1;
   s->num_evals += 1;
-  if (acc[kAccInvalid] > 0.0) { lm_finish(s, 2, 6); return; }
+  if (EA_UNLIKELY(acc[kAccInvalid] > 0.0)) { lm_finish(s, 2, 6); return; }
   lm_take_system(s, pend, acc);
   if (o->jacobi_scaling)
     for (int i = 0; i < 6; ++i) s->S[i] = 1.0 / (1.0 + sqrt(acc[kAccJtJ + sym6(i, i)]));
@@ -499,13 +505,13 @@ EA_HD inline void lm_advance(LMState *s, LMCold *c, LMTrace *tr, const LMOptions
 #pragma unroll
   for (int i = 0; i < 7; ++i) dx[i] = s->x[i] - s->cand[i];
   const double step_norm = norm_n(dx, 7);
-  if (step_norm <= o->parameter_tolerance * (s->x_norm + o->parameter_tolerance)) {
+  if (EA_UNLIKELY(step_norm <= o->parameter_tolerance * (s->x_norm + o->parameter_tolerance))) {
     lm_pend_trace(s, pend, s->iteration, 0.0, step_norm, 0.0, 0);
     lm_finish(s, 0, 3);
     return;
   }
   const double cost_change = s->cost - cand_cost;
-  if (fabs(cost_change) <= o->function_tolerance * s->cost) {
+  if (EA_UNLIKELY(fabs(cost_change) <= o->function_tolerance * s->cost)) {
     lm_pend_trace(s, pend, s->iteration, cost_change, step_norm, 0.0, 0);
     lm_finish(s, 0, 1);
     return;
@@ -513,7 +519,7 @@ EA_HD inline void lm_advance(LMState *s, LMCold *c, LMTrace *tr, const LMOptions
   const double rel = cost_change / s->model_cost_change;
   EA_LM_PROBE(0);
   bool fresh = false;
-  if (rel > o->min_relative_decrease) {
+  if (EA_LIKELY(rel > o->min_relative_decrease)) {
 #pragma unroll
     for (int i = 0; i < 7; ++i) s->x[i] = s->cand[i];
     s->x_norm = norm_n(s->x, 7);
