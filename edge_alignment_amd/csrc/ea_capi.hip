@@ -135,8 +135,9 @@ struct ea_batch {
   LMTrace *h_traces = nullptr;
   int *h_progress = nullptr;            // pinned, device-visible: [running x count | evaluations done x count]
   // tuning (-1 = heuristic)
-  int t_lds_bytes = -1, t_ppt = -1, t_use_lds = -1, t_xcd = -1, t_nt = -1;
+  int t_lds_bytes = -1, t_ppt = -1, t_use_lds = -1, t_xcd = -1, t_nt = -1, t_streams = -1;
   int ppt = 1, nt = 256, lds_bytes = 0, xcd_remap = 1;
+  std::vector<ea_batch *> parts;  // sub-batches of the concurrent solve (ea_batch_solve)
   bool built = false;
 };
 
@@ -501,6 +502,8 @@ extern "C" int ea_batch_create(ea_batch **out, ea_problem *const *problems, int 
 
 extern "C" void ea_batch_destroy(ea_batch *b) {
   if (!b) return;
+  for (ea_batch *c : b->parts) ea_batch_destroy(c);
+  b->parts.clear();
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   batch_free_device(b);
@@ -716,6 +719,140 @@ static void fill_summary(const LMState &s, const LMTrace &tr, int64_t npts, doub
   }
 }
 
+// ---- solve: the trust-region loop of every problem of a batch, on the device ---------------------------------------
+//
+// One run = one batch on its own stream.  The loop runs on the device: each (evaluate, LM step) pair reads the pose
+// the previous step published.  The step kernel reports progress into pinned host memory; the host only keeps a few
+// pairs queued ahead of it and stops enqueueing when every problem has terminated (pairs that are already queued
+// find `active == 0` and return at once).
+struct SolveRun {
+  ea_batch *b = nullptr;
+  int first = 0;  // index of the run's first problem in the caller's arrays
+  int count = 0, enq = 0, budget = 0, ahead = 2;
+  unsigned spins = 0;
+  bool done = false, fetch = false;
+};
+
+static int solve_start(SolveRun &r, const ea_options &o, const LMOptions &lo, const double *q, const double *t) {
+  ea_batch *b = r.b;
+  int rc = batch_build(b);
+  if (rc != EA_OK) return rc;
+  const int count = r.count = (int)b->probs.size();
+  for (int i = 0; i < count; ++i) {
+    lm_init(&b->h_states[i], &lo, q + 4 * i, t + 3 * i, b->probs[i]->rot_transposed);
+    host_pose_state(b->probs[i], q + 4 * i, t + 3 * i, &b->h_poses[i]);
+    b->h_progress[i] = 1;          // running
+    b->h_progress[count + i] = 0;  // evaluations completed
+  }
+  HIPCHK(hipMemcpyAsync(b->d_lm_block, b->h_lm_block, (size_t)count * (sizeof(PoseState) + sizeof(LMState)),
+                        hipMemcpyHostToDevice, b->stream));
+  r.ahead = o.iterations_per_sync > 0 ? o.iterations_per_sync : 2;  // measured: 2 beats 1, 3, 4, 6 by 1-3 %
+  r.budget = o.max_num_iterations + 2;  // every pair consumes at least one iteration
+  r.enq = 0; r.spins = 0; r.done = false; r.fetch = false;
+  return EA_OK;
+}
+
+// one look at the run's progress words; enqueues the next (evaluate, step) pair when the device is less than
+// `ahead` pairs ahead of the host
+static int solve_pump(SolveRun &r, const LMOptions &lo) {
+  ea_batch *b = r.b;
+  const int count = r.count;
+  bool any = false;
+  int done = 0;
+  for (int i = 0; i < count; ++i) {
+    any = any || (__atomic_load_n(&b->h_progress[i], __ATOMIC_ACQUIRE) != 0);
+    done = std::max(done, __atomic_load_n(&b->h_progress[count + i], __ATOMIC_ACQUIRE));
+  }
+  if (!any) { r.done = true; return EA_OK; }
+  if (r.enq < r.budget && r.enq - done < r.ahead) {
+    int rc = batch_launch_eval(b);
+    if (rc != EA_OK) return rc;
+    HIPCHK(launch_lm_step(b->d_groups, count, b->d_partials, b->d_poses, b->d_states, b->d_cold, b->d_traces, lo,
+                          b->d_progress, b->dv_states, b->dv_traces, b->stream));
+    ++r.enq;
+    r.spins = 0;
+  } else if (r.enq >= r.budget) {
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (int i = 0; i < count; ++i)
+      r.fetch = r.fetch || (__atomic_load_n(&b->h_progress[i], __ATOMIC_ACQUIRE) != 0);
+    r.done = true;
+  } else if ((++r.spins & 0x3fff) == 0) {
+    // nothing to enqueue and no progress for a while: make sure the stream is still healthy
+    hipError_t qe = hipStreamQuery(b->stream);
+    if (qe != hipSuccess && qe != hipErrorNotReady) return fail(EA_ERR_HIP, hipGetErrorString(qe));
+  }
+  return EA_OK;
+}
+
+// The step kernel that ended a problem's solve has already delivered its final state and trace rows into pinned
+// host memory, in front of the flag polled above: no copy, and no wait for the launches queued ahead (they find
+// every problem finished and drain behind our back; the next use of the stream is ordered after them anyway).
+// Only a solve cut short by the launch budget has to be fetched the classic way.
+static int solve_collect(SolveRun &r, const ea_options &o, bool want_traces) {
+  ea_batch *b = r.b;
+  const int count = r.count;
+  if (r.fetch) {
+    HIPCHK(hipMemcpyAsync(b->h_states, b->d_states, (size_t)count * (sizeof(LMState) + sizeof(LMTrace)),
+                          hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return EA_OK;
+  }
+  std::memcpy(b->h_states, b->hd_states, (size_t)count * sizeof(LMState));
+  if (want_traces || o.minimizer_progress_to_stdout) {
+    for (int i = 0; i < count; ++i) {
+      // rows 0 .. iteration were delivered; the rest of the pinned block is stale
+      const int ni = std::min(b->hd_states[i].iteration + 1, (int)kTrace);
+      LMTrace &d = b->h_traces[i];
+      const LMTrace &sr = b->hd_traces[i];
+      std::memcpy(d.it_cost, sr.it_cost, ni * sizeof(double));
+      std::memcpy(d.it_cost_change, sr.it_cost_change, ni * sizeof(double));
+      std::memcpy(d.it_gradient_max_norm, sr.it_gradient_max_norm, ni * sizeof(double));
+      std::memcpy(d.it_step_norm, sr.it_step_norm, ni * sizeof(double));
+      std::memcpy(d.it_relative_decrease, sr.it_relative_decrease, ni * sizeof(double));
+      std::memcpy(d.it_radius, sr.it_radius, ni * sizeof(double));
+      std::memcpy(d.it_successful, sr.it_successful, ni * sizeof(int));
+    }
+  }
+  return EA_OK;
+}
+
+static void solve_report(const SolveRun &r, const ea_options &o, double ms, double *q, double *t, ea_summary *summaries) {
+  const ea_batch *b = r.b;
+  for (int i = 0; i < r.count; ++i) {
+    const LMState &s = b->h_states[i];
+    for (int k = 0; k < 4; ++k) q[4 * i + k] = s.x[k];
+    for (int k = 0; k < 3; ++k) t[3 * i + k] = s.x[4 + k];
+    const LMTrace &tr = b->h_traces[i];
+    int64_t npts = b->probs[i]->n;
+    for (ea_problem *tm : b->probs[i]->terms) npts += tm->n;
+    if (summaries) fill_summary(s, tr, npts, ms, &summaries[i]);
+    if (o.minimizer_progress_to_stdout) {
+      std::printf("problem %d\niter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n", r.first + i);
+      const int ni = std::min(s.iteration + 1, (int)kTrace);
+      for (int it = 0; it < ni; ++it)
+        std::printf("%4d  %.6e  % .2e    %.2e   %.2e  % .2e  %.2e\n", it, tr.it_cost[it], tr.it_cost_change[it],
+                    tr.it_gradient_max_norm[it], tr.it_step_norm[it], tr.it_relative_decrease[it], tr.it_radius[it]);
+    }
+  }
+}
+
+// Sub-batches for the concurrent solve: contiguous slices of the parent's problems, each with its own stream and
+// buffers, created on first use and kept.
+static int batch_parts(ea_batch *b, int parts) {
+  if ((int)b->parts.size() == parts) return EA_OK;
+  for (ea_batch *c : b->parts) ea_batch_destroy(c);
+  b->parts.clear();
+  const int count = (int)b->probs.size();
+  for (int k = 0; k < parts; ++k) {
+    const int lo = (int)((int64_t)count * k / parts), hi = (int)((int64_t)count * (k + 1) / parts);
+    ea_batch *c = nullptr;
+    int rc = ea_batch_create(&c, b->probs.data() + lo, hi - lo);
+    if (rc != EA_OK) return rc;
+    b->parts.push_back(c);
+  }
+  return EA_OK;
+}
+
 extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, double *t, ea_summary *summaries) {
   if (!b || !q || !t) return fail(EA_ERR_INVALID_ARG, "NULL argument");
   static_assert(EA_MAX_TRACE == kTrace, "trace length mismatch");
@@ -725,9 +862,6 @@ extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, 
   if (o.max_num_iterations < 0) return fail(EA_ERR_INVALID_ARG, "max_num_iterations < 0");
   if (o.strategy != EA_STRATEGY_LM && o.strategy != EA_STRATEGY_DOGLEG)
     return fail(EA_ERR_INVALID_ARG, "unknown trust-region strategy");
-  int rc = batch_build(b);
-  if (rc != EA_OK) return rc;
-  const int count = (int)b->probs.size();
   LMOptions lo;
   lo.max_num_iterations = o.max_num_iterations;
   lo.function_tolerance = o.function_tolerance;
@@ -742,92 +876,53 @@ extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, 
   lo.max_num_consecutive_invalid_steps = o.max_num_consecutive_invalid_steps;
   lo.jacobi_scaling = o.jacobi_scaling;
   lo.strategy = o.strategy;
-  for (int i = 0; i < count; ++i) {
-    lm_init(&b->h_states[i], &lo, q + 4 * i, t + 3 * i, b->probs[i]->rot_transposed);
-    host_pose_state(b->probs[i], q + 4 * i, t + 3 * i, &b->h_poses[i]);
-    b->h_progress[i] = 1;          // running
-    b->h_progress[count + i] = 0;  // evaluations completed
-  }
-  HIPCHK(hipMemcpyAsync(b->d_lm_block, b->h_lm_block, (size_t)count * (sizeof(PoseState) + sizeof(LMState)),
-                        hipMemcpyHostToDevice, b->stream));
-  // The loop runs on the device: each (evaluate, LM step) pair reads the pose the previous step
-  // published.  The step kernel reports progress into pinned host memory; the host only keeps a few
-  // pairs queued ahead of it and stops enqueueing when every problem has terminated (pairs that are
-  // already queued find `active == 0` and return at once).
-  const int ahead = o.iterations_per_sync > 0 ? o.iterations_per_sync : 2;  // measured: 2 beats 1, 3, 4, 6 by 1-3 %
-  const int budget = o.max_num_iterations + 2;  // every pair consumes at least one iteration
-  int enq = 0;
-  unsigned spins = 0;
-  bool any_running_after_loop = false;
-  for (;;) {
-    bool any = false;
-    int done = 0;
-    for (int i = 0; i < count; ++i) {
-      any = any || (__atomic_load_n(&b->h_progress[i], __ATOMIC_ACQUIRE) != 0);
-      done = std::max(done, __atomic_load_n(&b->h_progress[count + i], __ATOMIC_ACQUIRE));
-    }
-    if (!any) break;
-    if (enq < budget && enq - done < ahead) {
-      rc = batch_launch_eval(b);
-      if (rc != EA_OK) return rc;
-      HIPCHK(launch_lm_step(b->d_groups, count, b->d_partials, b->d_poses, b->d_states, b->d_cold, b->d_traces, lo,
-                            b->d_progress, b->dv_states, b->dv_traces, b->stream));
-      ++enq;
-      spins = 0;
-    } else if (enq >= budget) {
-      HIPCHK(hipStreamSynchronize(b->stream));
-      for (int i = 0; i < count; ++i)
-        any_running_after_loop = any_running_after_loop || (__atomic_load_n(&b->h_progress[i], __ATOMIC_ACQUIRE) != 0);
-      break;
-    } else if ((++spins & 0x3fff) == 0) {
-      // nothing to enqueue and no progress for a while: make sure the stream is still healthy
-      hipError_t qe = hipStreamQuery(b->stream);
-      if (qe != hipSuccess && qe != hipErrorNotReady) return fail(EA_ERR_HIP, hipGetErrorString(qe));
-    }
-  }
-  // The step kernel that ended a problem's solve has already delivered its final state and trace rows into pinned
-  // host memory, in front of the flag polled above: no copy, and no wait for the launches queued ahead (they find
-  // every problem finished and drain behind our back; the next use of the stream is ordered after them anyway).
-  // Only a solve cut short by the launch budget has to be fetched the classic way.
-  if (any_running_after_loop) {
-    HIPCHK(hipMemcpyAsync(b->h_states, b->d_states, (size_t)count * (sizeof(LMState) + sizeof(LMTrace)),
-                          hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));
+  const int count = (int)b->probs.size();
+  // Concurrent halves: a batch of many problems is solved as two sub-batches on two streams, pumped by this one
+  // thread.  Inside a batch the evaluation (all CUs busy) and the LM step (one workgroup per problem, pure latency)
+  // alternate; with two streams one half's step runs under the other half's evaluation
+  // (32 x C2: 0.38 -> 0.32 ms fp32, 0.57 -> 0.46 ms fp64; scripts/split_batch_probe.py).  Every problem's arithmetic
+  // is what it is in a batch of its own.
+  int parts = b->t_streams > 0 ? b->t_streams : (count >= 16 ? 2 : 1);
+  parts = std::max(1, std::min(parts, std::min(count, 8)));
+  std::vector<SolveRun> runs((size_t)parts);
+  if (parts == 1) {
+    runs[0].b = b;
   } else {
-    std::memcpy(b->h_states, b->hd_states, (size_t)count * sizeof(LMState));
-    if (summaries || o.minimizer_progress_to_stdout) {
-      for (int i = 0; i < count; ++i) {
-        // rows 0 .. iteration were delivered; the rest of the pinned block is stale
-        const int ni = std::min(b->hd_states[i].iteration + 1, (int)kTrace);
-        LMTrace &d = b->h_traces[i];
-        const LMTrace &sr = b->hd_traces[i];
-        std::memcpy(d.it_cost, sr.it_cost, ni * sizeof(double));
-        std::memcpy(d.it_cost_change, sr.it_cost_change, ni * sizeof(double));
-        std::memcpy(d.it_gradient_max_norm, sr.it_gradient_max_norm, ni * sizeof(double));
-        std::memcpy(d.it_step_norm, sr.it_step_norm, ni * sizeof(double));
-        std::memcpy(d.it_relative_decrease, sr.it_relative_decrease, ni * sizeof(double));
-        std::memcpy(d.it_radius, sr.it_radius, ni * sizeof(double));
-        std::memcpy(d.it_successful, sr.it_successful, ni * sizeof(int));
+    int rc = batch_parts(b, parts);
+    if (rc != EA_OK) return rc;
+    int first = 0;
+    for (int k = 0; k < parts; ++k) {
+      ea_batch *c = b->parts[(size_t)k];
+      if (c->t_lds_bytes != b->t_lds_bytes || c->t_ppt != b->t_ppt || c->t_use_lds != b->t_use_lds || c->t_xcd != b->t_xcd ||
+          c->t_nt != b->t_nt) {
+        c->t_lds_bytes = b->t_lds_bytes; c->t_ppt = b->t_ppt; c->t_use_lds = b->t_use_lds; c->t_xcd = b->t_xcd; c->t_nt = b->t_nt;
+        c->built = false;
       }
+      runs[(size_t)k].b = c;
+      runs[(size_t)k].first = first;
+      first += (int)c->probs.size();
     }
+  }
+  for (SolveRun &r : runs) {
+    int rc = solve_start(r, o, lo, q + 4 * r.first, t + 3 * r.first);
+    if (rc != EA_OK) return rc;
+  }
+  for (;;) {
+    bool all_done = true;
+    for (SolveRun &r : runs) {
+      if (r.done) continue;
+      int rc = solve_pump(r, lo);
+      if (rc != EA_OK) return rc;
+      all_done = all_done && r.done;
+    }
+    if (all_done) break;
+  }
+  for (SolveRun &r : runs) {
+    int rc = solve_collect(r, o, summaries != nullptr);
+    if (rc != EA_OK) return rc;
   }
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  for (int i = 0; i < count; ++i) {
-    const LMState &s = b->h_states[i];
-    for (int k = 0; k < 4; ++k) q[4 * i + k] = s.x[k];
-    for (int k = 0; k < 3; ++k) t[3 * i + k] = s.x[4 + k];
-    const LMTrace &tr = b->h_traces[i];
-    int64_t npts = b->probs[i]->n;
-    for (ea_problem *tm : b->probs[i]->terms) npts += tm->n;
-    if (summaries) fill_summary(s, tr, npts, ms, &summaries[i]);
-    if (o.minimizer_progress_to_stdout) {
-      std::printf("problem %d\niter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n", i);
-      const int ni = std::min(s.iteration + 1, (int)kTrace);
-      for (int it = 0; it < ni; ++it)
-        std::printf("%4d  %.6e  % .2e    %.2e   %.2e  % .2e  %.2e\n", it, tr.it_cost[it], tr.it_cost_change[it],
-                    tr.it_gradient_max_norm[it], tr.it_step_norm[it], tr.it_relative_decrease[it], tr.it_radius[it]);
-    }
-  }
+  for (SolveRun &r : runs) solve_report(r, o, ms, q + 4 * r.first, t + 3 * r.first, summaries ? summaries + r.first : nullptr);
   return EA_OK;
 }
 
@@ -921,6 +1016,7 @@ extern "C" int ea_batch_set_tuning(ea_batch *b, const char *key, int value) {
   else if (k == "use_lds") b->t_use_lds = value;
   else if (k == "xcd_remap") b->t_xcd = value;
   else if (k == "threads") b->t_nt = value;
+  else if (k == "solve_streams") { b->t_streams = value; return EA_OK; }
   else return fail(EA_ERR_INVALID_ARG, "unknown tuning key: " + k);
   b->built = false;
   return EA_OK;

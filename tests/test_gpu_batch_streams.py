@@ -1,0 +1,42 @@
+"""ea_batch_solve with concurrent sub-batches (tuning key "solve_streams"): every problem's solve is the one it gets in
+a single-stream batch -- same iterates, same summary -- whatever the number of streams."""
+import numpy as np
+import pytest
+
+from edge_alignment_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", [capi.EA_F64, capi.EA_F32])
+def test_concurrent_halves_solve_every_problem_identically(dtype):
+    n = 18
+    Ps = []
+    for i in range(n):
+        cfg = synth.config_c2_twin(seed=300 + i, n_points=3000 + 500 * (i % 5))
+        P = capi.Problem(*cfg["K"], dtype=dtype)
+        P.set_points(cfg["xyz"]); P.set_dt_grid(cfg["grid"]); P.set_loss(capi.LOSS_CAUCHY, 1.0)
+        Ps.append(P)
+    q0 = np.tile([1.0, 0, 0, 0], (n, 1)); t0 = np.zeros((n, 3))
+    B = capi.Batch(Ps)
+    try:
+        out = {}
+        for streams in (1, 2, 3, -1):
+            B.set_tuning("solve_streams", streams)
+            out[streams] = B.solve(q0, t0)
+        q1, t1, s1 = out[1]
+        assert all(s["num_iterations"] > 3 for s in s1)
+        for streams in (2, 3, -1):
+            q, t, s = out[streams]
+            assert np.array_equal(q, q1) and np.array_equal(t, t1)
+            for a, b in zip(s, s1):
+                for k in ("why", "num_iterations", "num_successful_steps", "initial_cost", "final_cost"):
+                    assert a[k] == b[k], (streams, k)
+                assert np.array_equal(a["it_cost"], b["it_cost"])
+        # and the single-problem solve of one of them
+        qa, ta, sa = Ps[7].solve(q0[7], t0[7])
+        assert np.array_equal(qa, q1[7]) and np.array_equal(ta, t1[7]) and sa["num_iterations"] == s1[7]["num_iterations"]
+    finally:
+        B.close()
+        for P in Ps:
+            P.close()
