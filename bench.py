@@ -145,12 +145,21 @@ def main():
         elapsed = float(tt.item())
     value = world * n_pts * args.steps / elapsed
 
-    # Duration of the dominant kernel, HIP events on the library's stream.  kernel_ms: one event pair around a run of
-    # back-to-back launches / their number -- the execution window, the figure rocprofv3 --kernel-trace reports
-    # (profiles/); kernel_ms_isolated: an event pair around every single launch of the timed pattern, which also
-    # contains the command processor's dispatch (~2.6 us) because nothing is in flight to hide it.
-    _, ms_kernel_isolated = B.bench_eval(q0, t0, 2, min(args.steps, 64))
-    ms_kernel = B.bench_kernel(q0, t0, 10, min(max(args.steps, 100), 1000))
+    # Duration of the dominant kernel, HIP events on the library's stream.  A step of the timed region is the fused
+    # evaluation followed by the fold, two dependent launches:
+    #   kernel_ms               the evaluation kernel's share of a step = (event pair around K steps) / K minus the fold
+    #                           kernel's own time -- what rocprofv3 --kernel-trace reports per launch for this command
+    #                           (profiles/), and what `achieved` / `frac` are computed from;
+    #   kernel_ms_back_to_back  one event pair around a run of evaluation launches executing from the queue, / their
+    #                           number: the kernel's execution window with the next dispatch already decoded;
+    #   kernel_ms_isolated      an event pair around every single launch of the timed pattern, which also contains the
+    #                           command processor's dispatch (~2.6 us) because nothing is in flight to hide it.
+    nk = min(max(args.steps, 100), 1000)
+    ms_steps, ms_kernel_isolated = B.bench_eval(q0, t0, 2, min(args.steps, 64))
+    ms_steps, _ = B.bench_eval(q0, t0, 20, nk, kernel_pass=False)
+    ms_fold = B.bench_fold(10, nk)
+    ms_kernel_b2b = B.bench_kernel(q0, t0, 10, nk)
+    ms_kernel = max(ms_steps / nk - ms_fold, ms_kernel_b2b)
     bytes_launch = algorithmic_bytes(n_pts, H, W, esize)
     achieved = bytes_launch / (ms_kernel * 1e-3) / 1e9
     traffic = None
@@ -163,7 +172,9 @@ def main():
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": "ea_eval_fused_kernel<%s>" % ("double" if esize == 8 else "float"),
-                "kernel_ms": ms_kernel, "kernel_ms_isolated": ms_kernel_isolated,
+                "kernel_ms": ms_kernel, "kernel_ms_back_to_back": ms_kernel_b2b,
+                "frac_back_to_back": bytes_launch / (ms_kernel_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "fold_kernel_ms": ms_fold, "step_ms_events": ms_steps / nk, "kernel_ms_isolated": ms_kernel_isolated,
                 "algorithmic_bytes_per_launch": bytes_launch}
 
     extras = {}
@@ -244,7 +255,8 @@ def main():
             by = sum(algorithmic_bytes(Px.num_points, cfgx["image"].shape[0], cfgx["image"].shape[1], esz)
                      for Px, cfgx in zip(Ps, problems))
             res = {"evals_per_s": npts / (ms / 100 * 1e-3), "us_per_step": ms / 100 * 1e3, "kernel_us": msk * 1e3,
-                   "roofline_frac": by / (msk * 1e-3) / 1e9 / HBM_PEAK_GBS, "points": int(npts)}
+                   "roofline_frac": by / (msk * 1e-3) / 1e9 / HBM_PEAK_GBS, "points": int(npts),
+                   "point_order_tile_px": Ps[0].point_order}
             if m > 1:  # the production shape of BASELINE config C4: all frame pairs of a GPU solved by one launch sequence
                 Bx.solve(Q, T)
                 tsv = time.perf_counter()
@@ -292,7 +304,7 @@ def main():
                "config": {"workload": desc, "points_per_gpu": int(n_pts), "dt_image": "%dx%d" % (W, H),
                           "parallelism": "independent frame pairs, one per GPU; single RCCL pose all-gather",
                           "tiles": B.info("num_tiles"), "points_per_thread": B.info("points_per_thread"),
-                          "lds_bytes": B.info("lds_bytes")},
+                          "lds_bytes": B.info("lds_bytes"), "point_order_tile_px": P.point_order},
                "roofline": roofline}
         out.update(extras)
         if others:

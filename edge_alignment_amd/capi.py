@@ -29,7 +29,7 @@ EXPORTED = [
     "ea_eval", "ea_eval_points", "ea_cost", "ea_solve",
     "ea_batch_create", "ea_batch_destroy", "ea_batch_count", "ea_batch_eval", "ea_batch_solve",
     "ea_solve_pyramid", "ea_solve_sharded", "ea_tracker_create", "ea_tracker_destroy", "ea_tracker_problem", "ea_tracker_push_frame",
-    "ea_batch_bench_eval", "ea_batch_bench_kernel", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
+    "ea_batch_bench_eval", "ea_batch_bench_kernel", "ea_batch_bench_fold", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
     "ea_problem_set_ref_frame", "ea_problem_set_ref_frame_masked", "ea_problem_set_now_frame", "ea_problem_debug_now_frame",
     "ea_problem_set_ref_frame_canny", "ea_problem_set_now_frame_canny", "ea_problem_debug_now_frame_canny",
     "ea_problem_set_ref_frame_ros", "ea_problem_set_now_frame_ros", "ea_problem_debug_now_frame_ros",
@@ -120,6 +120,7 @@ def load():
     L.ea_batch_solve.argtypes = [vp, C.POINTER(Options), dp, dp, C.POINTER(Summary)]
     L.ea_batch_bench_eval.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp, dp]
     L.ea_batch_bench_kernel.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp]
+    L.ea_batch_bench_fold.argtypes = [vp, C.c_int, C.c_int, dp]
     L.ea_solve_sharded.argtypes = [vp, C.POINTER(Options), ALLREDUCE_FN, vp, dp, dp, C.POINTER(Summary)]
     L.ea_solve_pyramid.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Options), dp, dp, C.POINTER(Summary)]
     L.ea_batch_set_tuning.argtypes = [vp, C.c_char_p, C.c_int]
@@ -515,6 +516,12 @@ class Batch:
         q, t = _f64(q).reshape(-1, 4), _f64(t).reshape(-1, 3)
         ms = C.c_double()
         _check(load().ea_batch_bench_kernel(self._h, _dp(q), _dp(t), warmup, launches, C.byref(ms)))
+        return ms.value
+
+    def bench_fold(self, warmup, launches):
+        """mean ms of the fold kernel over `launches` back-to-back launches (one event pair)"""
+        ms = C.c_double()
+        _check(load().ea_batch_bench_fold(self._h, warmup, launches, C.byref(ms)))
         return ms.value
 
     def set_tuning(self, key, value):

@@ -1008,6 +1008,30 @@ extern "C" int ea_batch_bench_kernel(ea_batch *b, const double *q, const double 
   return EA_OK;
 }
 
+// the same measurement for the fold kernel of ea_batch_eval (ea_reduce_kernel over the rows the last evaluation left)
+extern "C" int ea_batch_bench_fold(ea_batch *b, int warmup, int launches, double *ms_per_launch) {
+  if (!b || !ms_per_launch || launches < 1 || warmup < 0) return fail(EA_ERR_INVALID_ARG, "bad argument");
+  int rc = batch_build(b);
+  if (rc != EA_OK) return rc;
+  const int count = (int)b->probs.size();
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  for (int i = 0; i < warmup; ++i) HIPCHK(launch_reduce(b->d_groups, count, b->d_partials, b->d_out, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipLaunchHostFunc(b->stream, [](void *) { std::this_thread::sleep_for(std::chrono::milliseconds(3)); }, nullptr));
+  HIPCHK(hipEventRecord(e0, b->stream));
+  for (int i = 0; i < launches; ++i) HIPCHK(launch_reduce(b->d_groups, count, b->d_partials, b->d_out, b->stream));
+  HIPCHK(hipEventRecord(e1, b->stream));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  *ms_per_launch = (double)ms / launches;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return EA_OK;
+}
+
 extern "C" int ea_batch_set_tuning(ea_batch *b, const char *key, int value) {
   if (!b || !key) return fail(EA_ERR_INVALID_ARG, "NULL argument");
   const std::string k(key);

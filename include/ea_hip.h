@@ -245,6 +245,8 @@ int ea_batch_bench_eval(ea_batch *b, const double *q, const double *t, int warmu
  * launch (dispatch of the next launch overlaps the running one) -- the figure rocprofv3 --kernel-trace reports. */
 int ea_batch_bench_kernel(ea_batch *b, const double *q, const double *t, int warmup, int launches,
                           double *ms_per_launch);
+/* the same for the fold kernel of ea_batch_eval, over the partial rows the last evaluation left */
+int ea_batch_bench_fold(ea_batch *b, int warmup, int launches, double *ms_per_launch);
 /* tuning knobs: key in {"lds_bytes", "points_per_thread", "use_lds", "xcd_remap", "threads"};
  * value < 0 restores the default */
 int ea_batch_set_tuning(ea_batch *b, const char *key, int value);
