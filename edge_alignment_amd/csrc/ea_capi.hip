@@ -69,6 +69,26 @@ static int fail(int code, const std::string &msg) {
                   std::string(#expr) + ": " + hipGetErrorString(e_));                        \
   } while (0)
 
+// scope guards for the temporaries of the measurement / test hooks, so that an early HIPCHK return frees them
+namespace {
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  template <typename U> U *as() const { return static_cast<U *>(p); }
+};
+struct EventPair {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ~EventPair() {
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+  }
+};
+struct EventList {
+  std::vector<hipEvent_t> ev;
+  ~EventList() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); }
+};
+}  // namespace
+
 struct ea_problem {
   int device = 0;
   int dtype = EA_F64;
@@ -328,10 +348,10 @@ extern "C" int ea_problem_set_points(ea_problem *p, const double *xyz, int64_t n
       for (int64_t i = 0; i < n; ++i) dst[i] = xyz[(ord ? ord[i] : i) * stride + c];
     }
   }
+  p->own_points = true;  // (before the allocations: a failure half-way leaves what was allocated to free_points)
   HIPCHK(hipMalloc(&p->d_x, n * esz));
   HIPCHK(hipMalloc(&p->d_y, n * esz));
   HIPCHK(hipMalloc(&p->d_z, n * esz));
-  p->own_points = true;
   HIPCHK(hipMemcpy(p->d_x, soa.data(), n * esz, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(p->d_y, soa.data() + (size_t)n * esz, n * esz, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(p->d_z, soa.data() + 2 * (size_t)n * esz, n * esz, hipMemcpyHostToDevice));
@@ -934,9 +954,10 @@ extern "C" int ea_batch_bench_eval(ea_batch *b, const double *q, const double *t
   const int count = (int)b->probs.size();
   rc = batch_upload_poses(b, q, t);
   if (rc != EA_OK) return rc;
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0));
-  HIPCHK(hipEventCreate(&e1));
+  EventPair evp;
+  HIPCHK(hipEventCreate(&evp.e0));
+  HIPCHK(hipEventCreate(&evp.e1));
+  const hipEvent_t e0 = evp.e0, e1 = evp.e1;
   auto one_step = [&]() -> int {
     int r = batch_launch_eval(b);
     if (r != EA_OK) return r;
@@ -955,7 +976,9 @@ extern "C" int ea_batch_bench_eval(ea_batch *b, const double *q, const double *t
   if (ms_eval_kernel) {
     // second pass over the same steps: an event pair around every launch of the per-point kernel
     const int m = std::min(steps, 64);
-    std::vector<hipEvent_t> ev(2 * m);
+    EventList evl;
+    evl.ev.assign(2 * (size_t)m, nullptr);
+    std::vector<hipEvent_t> &ev = evl.ev;
     for (auto &e : ev) HIPCHK(hipEventCreate(&e));
     for (int i = 0; i < m; ++i) {
       HIPCHK(hipEventRecord(ev[2 * i], b->stream));
@@ -971,10 +994,7 @@ extern "C" int ea_batch_bench_eval(ea_batch *b, const double *q, const double *t
       sum += k;
     }
     *ms_eval_kernel = sum / m;
-    for (auto &e : ev) (void)hipEventDestroy(e);
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   return EA_OK;
 }
 
@@ -988,9 +1008,10 @@ extern "C" int ea_batch_bench_kernel(ea_batch *b, const double *q, const double 
   if (rc != EA_OK) return rc;
   rc = batch_upload_poses(b, q, t);
   if (rc != EA_OK) return rc;
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0));
-  HIPCHK(hipEventCreate(&e1));
+  EventPair evp;
+  HIPCHK(hipEventCreate(&evp.e0));
+  HIPCHK(hipEventCreate(&evp.e1));
+  const hipEvent_t e0 = evp.e0, e1 = evp.e1;
   for (int i = 0; i < warmup; ++i) if ((rc = batch_launch_eval(b)) != EA_OK) return rc;
   HIPCHK(hipStreamSynchronize(b->stream));
   // hold the stream on a host function while the whole run is enqueued: the launches then execute from the queue,
@@ -1003,8 +1024,6 @@ extern "C" int ea_batch_bench_kernel(ea_batch *b, const double *q, const double 
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, e0, e1));
   *ms_per_launch = (double)ms / launches;
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   return EA_OK;
 }
 
@@ -1014,9 +1033,10 @@ extern "C" int ea_batch_bench_fold(ea_batch *b, int warmup, int launches, double
   int rc = batch_build(b);
   if (rc != EA_OK) return rc;
   const int count = (int)b->probs.size();
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0));
-  HIPCHK(hipEventCreate(&e1));
+  EventPair evp;
+  HIPCHK(hipEventCreate(&evp.e0));
+  HIPCHK(hipEventCreate(&evp.e1));
+  const hipEvent_t e0 = evp.e0, e1 = evp.e1;
   for (int i = 0; i < warmup; ++i) HIPCHK(launch_reduce(b->d_groups, count, b->d_partials, b->d_out, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
   HIPCHK(hipLaunchHostFunc(b->stream, [](void *) { std::this_thread::sleep_for(std::chrono::milliseconds(3)); }, nullptr));
@@ -1027,8 +1047,6 @@ extern "C" int ea_batch_bench_fold(ea_batch *b, int warmup, int launches, double
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, e0, e1));
   *ms_per_launch = (double)ms / launches;
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   return EA_OK;
 }
 
@@ -1096,9 +1114,10 @@ extern "C" int ea_eval_points(ea_problem *p, const double q[4], const double t[3
   if (p->n == 0) return EA_OK;
   rc = batch_upload_poses(b, q, t);
   if (rc != EA_OK) return rc;
-  double *d_r = nullptr, *d_J = nullptr;
-  if (r) HIPCHK(hipMalloc(&d_r, p->n * sizeof(double)));
-  if (J) HIPCHK(hipMalloc(&d_J, p->n * 6 * sizeof(double)));
+  DevBuf buf_r, buf_J;
+  if (r) HIPCHK(hipMalloc(&buf_r.p, p->n * sizeof(double)));
+  if (J) HIPCHK(hipMalloc(&buf_J.p, p->n * 6 * sizeof(double)));
+  double *d_r = buf_r.as<double>(), *d_J = buf_J.as<double>();
   hipError_t e = launch_eval_points(p->dtype, b->d_probs, 0, (int)p->n, b->d_poses, d_r, d_J, corrected, b->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
   if (p->order.empty()) {
@@ -1118,7 +1137,6 @@ extern "C" int ea_eval_points(ea_problem *p, const double q[4], const double t[3
           for (int a = 0; a < 6; ++a) J[(size_t)p->order[(size_t)i] * 6 + a] = tmp[(size_t)i * 6 + a];
     }
   }
-  (void)hipFree(d_r); (void)hipFree(d_J);
   if (e != hipSuccess) return fail(EA_ERR_HIP, hipGetErrorString(e));
   return EA_OK;
 }
@@ -1300,11 +1318,12 @@ extern "C" int ea_selftest_wave_reduce(int device, const float *in, double *out3
   int rc = check_device(device);
   if (rc != EA_OK) return rc;
   HIPCHK(hipSetDevice(device));
-  float *d_in = nullptr, *d_st = nullptr;
-  double *d_o = nullptr;
-  HIPCHK(hipMalloc(&d_in, 32 * 64 * sizeof(float)));
-  HIPCHK(hipMalloc(&d_st, 30 * 64 * sizeof(float)));
-  HIPCHK(hipMalloc(&d_o, 64 * sizeof(double)));
+  DevBuf b_in, b_st, b_o;
+  HIPCHK(hipMalloc(&b_in.p, 32 * 64 * sizeof(float)));
+  HIPCHK(hipMalloc(&b_st.p, 30 * 64 * sizeof(float)));
+  HIPCHK(hipMalloc(&b_o.p, 64 * sizeof(double)));
+  float *d_in = b_in.as<float>(), *d_st = b_st.as<float>();
+  double *d_o = b_o.as<double>();
   HIPCHK(hipMemcpy(d_in, in, 32 * 64 * sizeof(float), hipMemcpyHostToDevice));
   HIPCHK(hipMemset(d_o, 0, 64 * sizeof(double)));
   hipError_t e = launch_selftest_reduce(d_in, d_st, d_st + 16 * 64, d_st + 24 * 64, d_st + 28 * 64, d_o, d_o + 32, nullptr);
@@ -1312,7 +1331,6 @@ extern "C" int ea_selftest_wave_reduce(int device, const float *in, double *out3
   if (e == hipSuccess) e = hipMemcpy(out32, d_o, 32 * sizeof(double), hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(out64, d_o + 32, 32 * sizeof(double), hipMemcpyDeviceToHost);
   if (e == hipSuccess && stages) e = hipMemcpy(stages, d_st, 30 * 64 * sizeof(float), hipMemcpyDeviceToHost);
-  (void)hipFree(d_in); (void)hipFree(d_st); (void)hipFree(d_o);
   if (e != hipSuccess) return fail(EA_ERR_HIP, hipGetErrorString(e));
   return EA_OK;
 }
@@ -1379,10 +1397,10 @@ static int ref_frame_impl(ea_problem *p, const uint8_t *bgr, const uint8_t *mask
   p->version++;
   if (total > 0) {
     const size_t esz = p->dtype == EA_F32 ? 4 : 8;
+    p->own_points = true;
     HIPCHK(hipMalloc(&p->d_x, (size_t)total * esz));
     HIPCHK(hipMalloc(&p->d_y, (size_t)total * esz));
     HIPCHK(hipMalloc(&p->d_z, (size_t)total * esz));
-    p->own_points = true;
     HIPCHK(launch_edge_scatter(p->dtype, d_lap, d_depth, height, width, threshold, d_counts, p->cam.fx, p->cam.fy, p->cam.cx,
                                p->cam.cy, z_scaling, p->d_x, p->d_y, p->d_z, total, nullptr));
     HIPCHK(hipDeviceSynchronize());
@@ -1496,10 +1514,10 @@ extern "C" int ea_problem_set_ref_frame_canny(ea_problem *p, const uint8_t *bgr,
   p->version++;
   if (total > 0) {
     const size_t esz = p->dtype == EA_F32 ? 4 : 8;
+    p->own_points = true;
     HIPCHK(hipMalloc(&p->d_x, (size_t)total * esz));
     HIPCHK(hipMalloc(&p->d_y, (size_t)total * esz));
     HIPCHK(hipMalloc(&p->d_z, (size_t)total * esz));
-    p->own_points = true;
     HIPCHK(launch_edge_scatter(p->dtype, d_edges, d_depth, height, width, 0, d_counts, p->cam.fx, p->cam.fy, p->cam.cx,
                                p->cam.cy, z_scaling, p->d_x, p->d_y, p->d_z, total, nullptr));
     HIPCHK(hipDeviceSynchronize());
@@ -1580,10 +1598,10 @@ extern "C" int ea_problem_set_ref_frame_ros(ea_problem *p, const uint8_t *bgr, c
   p->version++;
   if (total > 0) {
     const size_t esz = p->dtype == EA_F32 ? 4 : 8;
+    p->own_points = true;
     HIPCHK(hipMalloc(&p->d_x, (size_t)total * esz));
     HIPCHK(hipMalloc(&p->d_y, (size_t)total * esz));
     HIPCHK(hipMalloc(&p->d_z, (size_t)total * esz));
-    p->own_points = true;
     HIPCHK(launch_edge_scatter_ros(p->dtype, d_edges, d_depth, height, width, d_counts, p->cam.fx, p->cam.fy, p->cam.cx,
                                    p->cam.cy, p->d_x, p->d_y, p->d_z, total, nullptr));
     HIPCHK(hipDeviceSynchronize());
