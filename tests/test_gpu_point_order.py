@@ -63,3 +63,32 @@ def test_large_point_sets_are_tile_ordered_automatically():
         assert np.array_equal(P.get_points(), cfg["xyz"][:, :3].astype(np.float32).astype(np.float64))
     finally:
         P.close(); S.close()
+
+
+def test_tile_order_with_degenerate_points():
+    """points behind / on the camera plane, far outside the image, with z = 0: the ordering key saturates, nothing else changes"""
+    cfg = synth.config_c2_twin(seed=21, n_points=8000)
+    xyz = cfg["xyz"][:, :3].copy()
+    rng = np.random.default_rng(1)
+    idx = rng.choice(len(xyz), 600, replace=False)
+    xyz[idx[:150], 2] = 0.0            # u, v = inf / nan
+    xyz[idx[150:300], 2] *= -1.0       # behind the camera
+    xyz[idx[300:450], 0] += 50.0       # far right of the image
+    xyz[idx[450:], 1] -= 50.0          # far above it
+    q = synth.quat_from_axis_angle([0.1, 0.7, -0.2], np.deg2rad(0.8))
+    t = np.array([0.01, 0.0, -0.02])
+    P0, P1 = _problem(cfg, capi.EA_F64, 0, xyz), _problem(cfg, capi.EA_F64, 32, xyz)
+    try:
+        assert np.array_equal(P1.get_points(), xyz)
+        r0, J0 = P0.eval_points(q, t)
+        r1, J1 = P1.eval_points(q, t)
+        assert np.array_equal(r0, r1, equal_nan=True) and np.array_equal(J0, J1, equal_nan=True)
+        e0, e1 = P0.eval(q, t), P1.eval(q, t)
+        assert e0["n_invalid"] == e1["n_invalid"]
+        for k in ("cost", "JtJ", "Jtr"):
+            a, b = np.asarray(e0[k]), np.asarray(e1[k])
+            assert np.all(np.isfinite(a)) == np.all(np.isfinite(b))
+            if np.all(np.isfinite(a)):
+                assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max()
+    finally:
+        P0.close(); P1.close()
