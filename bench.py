@@ -82,6 +82,13 @@ def cpu_baseline_all_cores(cfg, loss, budget_s=6.0):
     import threading
     from oracle import ea_oracle as eo
     cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    try:  # a container's CPU quota, when there is one, is the number of cores this process really has
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(round(int(quota) / int(period)))))
+    except Exception:
+        pass
+    cores = min(cores, 16 * max(1, int(os.environ.get("EA_BENCH_GPUS_ON_BOX", "1"))))  # the box's CPU share per GPU
     n = min(cfg["xyz"].shape[0], 50000)
     q, t = np.array([1.0, 0, 0, 0]), np.zeros(3)
     shards = [np.ascontiguousarray(cfg["xyz"][(k * n) // cores:((k + 1) * n) // cores]) for k in range(cores)]

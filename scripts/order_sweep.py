@@ -25,7 +25,7 @@ def run(name, cfgs, dtype, loss, Ts, tunings=((-1, -1),), steps=200):
         for P in Ps: P.close()
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['b32', 'b64', 'c5', 'c3', 'c2']
+    which = sys.argv[1:] or ['b32', 'b64', 'c5', 'c5rand', 'c3', 'c2']
     c2s = [synth.config_c2_twin(seed=100 + i) for i in range(32)]
     if 'b32' in which: run('32xC2 f32', c2s, capi.EA_F32, (capi.LOSS_CAUCHY, 1.0), (0, 8, 16, 32), ((1, 256), (2, 256)))
     if 'b64' in which: run('32xC2 f64', c2s, capi.EA_F64, (capi.LOSS_CAUCHY, 1.0), (0, 8, 16, 32), ((1, 256), (2, 256)))
@@ -33,6 +33,9 @@ if __name__ == '__main__':
         c5 = synth.config_c5()
         run('C5 f32', [c5], capi.EA_F32, (capi.LOSS_TRIVIAL, 1.0), (0, 8, 16, 32, 64, -1), ((-1, -1), (2, 1024), (4, 256)))
         run('C5 f64', [c5], capi.EA_F64, (capi.LOSS_TRIVIAL, 1.0), (0, 16), ((-1, -1),))
+    if 'c5rand' in which:  # the same cloud handed over in random order (worst case for the caller's order)
+        c5r = synth.config_c5(order="random")
+        run('C5 f32, points handed over in RANDOM order', [c5r], capi.EA_F32, (capi.LOSS_TRIVIAL, 1.0), (0, -1), ((-1, -1),))
     if 'c3' in which:
         l0 = synth.config_c3_levels()[0]
         run('C3 level 0 (1280x960, 1.4e5 pts) f32', [l0], capi.EA_F32, (capi.LOSS_CAUCHY, 1.0), (0, 16))
