@@ -246,6 +246,25 @@ def main():
         extras = {"lm_iters_per_s_at_1e5_pts": lm_total, "lm_iterations_per_solve": its / reps,
                   "lm_solve_ms": el / reps * 1e3, "pose_gather_ms": gather_ms,
                   "lm_pose_err_vs_planted": {"rad": err_rot, "m": err_t}}
+        if rank == 0 and world == 1:
+            # the same problem in fp32 (the arithmetic of BASELINE configs C3 / C5; pose tolerance 1e-4 rad / 1e-3 m)
+            try:
+                P2f = capi.Problem(*cfg2["K"], dtype=capi.EA_F32, device=local_rank)
+                P2f.set_points(cfg2["xyz"]); P2f.set_dt_grid(cfg2["grid"]); P2f.set_loss(*loss2)
+                P2f.solve(q0, t0)
+                tsf = time.perf_counter()
+                itsf = 0
+                for _ in range(reps):
+                    qf, tf, sf = P2f.solve(q0, t0)
+                    itsf += sf["num_iterations"]
+                elf = time.perf_counter() - tsf
+                extras["lm_fp32_at_1e5_pts"] = {"iters_per_s": itsf / elf, "solve_ms": elf / reps * 1e3,
+                                                "iterations_per_solve": itsf / reps,
+                                                "pose_err_vs_planted": {"rad": synth.rotation_angle_between(qf, cfg2["q_true"]),
+                                                                        "m": float(np.linalg.norm(tf - cfg2["t_true"]))}}
+                P2f.close()
+            except Exception as e:
+                extras["lm_fp32_at_1e5_pts"] = {"error": repr(e)}
         # the other way to use N GPUs on this path: ONE 1e5-point problem sharded by points, an
         # all-reduce of the 32 accumulator slots per iteration (RCCL when world > 1), the step replicated on every rank
         try:
