@@ -77,6 +77,12 @@ def test_argument_validation_needs_no_device(lib):
     assert lib.ea_problem_set_now_frame(None, None, 480, 640, 35, 1, 1) == -1
     assert lib.ea_problem_set_now_frame_canny(None, None, None, 480, 640, 30.0, 90.0, 1, 0.0, 1.0) == -1
     assert lib.ea_problem_set_now_frame_ros(None, None, 240, 320, 150.0, 100.0) == -1
+    assert lib.ea_problem_set_point_order(None, 16) == -1
+    v = C.c_int()
+    assert lib.ea_problem_get_point_order(None, C.byref(v)) == -1
+    ms = C.c_double()
+    assert lib.ea_batch_bench_fold(None, 1, 1, C.byref(ms)) == -1
+    assert lib.ea_batch_set_tuning(None, b"solve_streams", 2) == -1
     assert b"NULL" in lib.ea_last_error() or b"argument" in lib.ea_last_error()
 
 
