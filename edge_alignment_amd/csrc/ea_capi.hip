@@ -155,7 +155,7 @@ struct ea_batch {
   LMTrace *h_traces = nullptr;
   int *h_progress = nullptr;            // pinned, device-visible: [running x count | evaluations done x count]
   // tuning (-1 = heuristic)
-  int t_lds_bytes = -1, t_ppt = -1, t_use_lds = -1, t_xcd = -1, t_nt = -1, t_streams = -1;
+  int t_lds_bytes = -1, t_ppt = -1, t_use_lds = -1, t_xcd = -1, t_nt = -1, t_streams = -1, t_variant = 0;
   int ppt = 1, nt = 256, lds_bytes = 0, xcd_remap = 1;
   std::vector<ea_batch *> parts;  // sub-batches of the concurrent solve (ea_batch_solve)
   bool built = false;
@@ -591,6 +591,7 @@ static int batch_build(ea_batch *b) {
       term_group.push_back((int)i);
     }
   }
+  any_variant |= b->t_variant;  // a part of a larger batch runs the kernel form the whole batch runs
   b->any_variant = any_variant;
   b->terms_are_groups = terms.size() == b->probs.size() ? 1 : 0;
   // Launch shape, measured on MI355X (profiles/r01_sweep*.txt).  Small problems are latency-bound: one
@@ -901,21 +902,27 @@ extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, 
   // thread.  Inside a batch the evaluation (all CUs busy) and the LM step (one workgroup per problem, pure latency)
   // alternate; with two streams one half's step runs under the other half's evaluation
   // (32 x C2: 0.38 -> 0.32 ms fp32, 0.57 -> 0.46 ms fp64; scripts/split_batch_probe.py).  Every problem's arithmetic
-  // is what it is in a batch of its own.
+  // is what it is in the one-stream solve of the same batch (same launch shape, same chunks, same order of summation).
   int parts = b->t_streams > 0 ? b->t_streams : (count >= 16 ? 2 : 1);
   parts = std::max(1, std::min(parts, std::min(count, 8)));
   std::vector<SolveRun> runs((size_t)parts);
   if (parts == 1) {
     runs[0].b = b;
   } else {
-    int rc = batch_parts(b, parts);
+    // the parts take the launch shape the whole batch resolves to (the heuristics look at the batch's totals), so that
+    // every problem is cut into the same chunks, and summed in the same order, as in the one-stream solve
+    int rc = batch_build(b);
+    if (rc != EA_OK) return rc;
+    rc = batch_parts(b, parts);
     if (rc != EA_OK) return rc;
     int first = 0;
     for (int k = 0; k < parts; ++k) {
       ea_batch *c = b->parts[(size_t)k];
-      if (c->t_lds_bytes != b->t_lds_bytes || c->t_ppt != b->t_ppt || c->t_use_lds != b->t_use_lds || c->t_xcd != b->t_xcd ||
-          c->t_nt != b->t_nt) {
-        c->t_lds_bytes = b->t_lds_bytes; c->t_ppt = b->t_ppt; c->t_use_lds = b->t_use_lds; c->t_xcd = b->t_xcd; c->t_nt = b->t_nt;
+      const int use_lds = b->lds_bytes > 0 ? 1 : 0;
+      if (c->t_lds_bytes != b->t_lds_bytes || c->t_ppt != b->ppt || c->t_use_lds != use_lds || c->t_xcd != b->xcd_remap ||
+          c->t_nt != b->nt || c->t_variant != b->any_variant) {
+        c->t_lds_bytes = b->t_lds_bytes; c->t_ppt = b->ppt; c->t_use_lds = use_lds; c->t_xcd = b->xcd_remap; c->t_nt = b->nt;
+        c->t_variant = b->any_variant;
         c->built = false;
       }
       runs[(size_t)k].b = c;

@@ -1,5 +1,6 @@
 """ea_batch_solve with concurrent sub-batches (tuning key "solve_streams"): every problem's solve is the one it gets in
-a single-stream batch -- same iterates, same summary -- whatever the number of streams."""
+the single-stream solve of the same batch -- same launch shape, same iterates, same summary -- whatever the number of
+streams (the parts inherit the shape the whole batch resolves to)."""
 import numpy as np
 import pytest
 
@@ -39,4 +40,45 @@ def test_concurrent_halves_solve_every_problem_identically(dtype):
     finally:
         B.close()
         for P in Ps:
+            P.close()
+
+
+def test_random_batches_are_stream_invariant():
+    """batch sizes / point counts around the thresholds of the launch-shape heuristics (they look at the batch's
+    totals), both dtypes, a batch that mixes plain and distorted-camera problems"""
+    rng = np.random.default_rng(12345)
+    pool = {}
+
+    def problem(dtype, i, distorted=False):
+        key = (dtype, i, distorted)
+        if key not in pool:
+            cfg = synth.config_c2_twin(seed=500 + i, n_points=int(2000 + 700 * (i % 9)))
+            P = capi.Problem(*cfg["K"], dtype=dtype)
+            P.set_points(cfg["xyz"]); P.set_dt_grid(cfg["grid"]); P.set_loss(capi.LOSS_CAUCHY, 1.0)
+            if distorted:
+                P.set_distortion(1e-3, -2e-4, 1e-4, -1e-4, 0.0)
+            pool[key] = P
+        return pool[key]
+
+    try:
+        for trial in range(10):
+            dtype = capi.EA_F64 if trial % 2 == 0 else capi.EA_F32
+            n = int(rng.integers(16, 41))
+            ids = rng.choice(50, n, replace=False)
+            Ps = [problem(dtype, int(i), distorted=(trial >= 8 and k % 3 == 0)) for k, i in enumerate(ids)]
+            B = capi.Batch(Ps)
+            q0 = np.tile([1.0, 0, 0, 0], (n, 1)) + 0.003 * rng.standard_normal((n, 4))
+            q0 /= np.linalg.norm(q0, axis=1)[:, None]
+            t0 = 0.004 * rng.standard_normal((n, 3))
+            ref = None
+            for streams in (1, 2, 3, 1):
+                B.set_tuning("solve_streams", streams)
+                q, t, s = B.solve(q0, t0)
+                sig = (q.tobytes(), t.tobytes(), tuple((x["why"], x["num_iterations"], x["final_cost"]) for x in s))
+                if ref is None:
+                    ref = sig
+                assert sig == ref, (trial, streams)
+            B.close()
+    finally:
+        for P in pool.values():
             P.close()
