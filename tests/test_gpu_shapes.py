@@ -1,0 +1,49 @@
+"""Every launch shape of the fused evaluation (points per lane x workgroup size x LDS staging) against the CPU oracle at
+point counts on both sides of the chunk boundaries, both dtypes, the three losses, unit and non-unit quaternions.
+Tolerances: fp64 sums 1e-11 relative, fp32 sums 1e-4 relative (file header of test_gpu_parity.py)."""
+import itertools
+
+import numpy as np
+import pytest
+
+from edge_alignment_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300)
+
+
+@pytest.mark.parametrize("dtype_name,tol", [("EA_F64", 1e-11), ("EA_F32", 1e-4)])
+def test_launch_shapes_at_chunk_boundaries(hip, oracle, dtype_name, tol):
+    dtype = getattr(hip, dtype_name)
+    rng = np.random.default_rng(7)
+    q_pl = synth.quat_from_axis_angle([1, 2, 3], np.deg2rad(1.0))
+    base = synth.make_problem(120, 160, 9000, 40, 1, 130.0, 130.0, 79.5, 59.5, planted_q=q_pl,
+                              planted_t=(0.01, -0.005, 0.02), normalize=True)
+    t = np.array([0.03, -0.02, 0.05])
+    k = 0
+    for n in (1, 64, 65, 255, 257, 1023, 1025, 2049, 4097, 8193):
+        xyz = base["xyz"][rng.choice(9000, n, replace=False)]
+        loss = [(0, 1.0), (1, 1.0), (2, 0.3)][k % 3]
+        q = np.array([0.9990482, 0.0261769, -0.0348995, 0.0087265])
+        q /= np.linalg.norm(q)
+        if k % 4 == 3:
+            q = q * 1.003  # non-unit quaternion: the general Jacobian path
+        k += 1
+        e = oracle.OracleProblem(base["grid"], *base["K"], loss=loss[0], loss_a=loss[1]).eval(xyz, q, t)
+        P = hip.Problem(*base["K"], dtype=dtype)
+        P.set_points(xyz); P.set_dt_grid(base["grid"]); P.set_loss(*loss)
+        B = hip.Batch([P])
+        try:
+            for ppt, nt, lds in itertools.product((1, 2, 4), (256, 1024), (0, 1)):
+                B.set_tuning("points_per_thread", ppt); B.set_tuning("threads", nt); B.set_tuning("use_lds", lds)
+                g = B.eval(q.reshape(1, 4), t.reshape(1, 3))
+                where = (n, ppt, nt, lds, loss)
+                assert int(g["n_invalid"][0]) == int(e["n_invalid"]), where
+                slack = 100.0 if n <= 2 else 1.0  # a sum of one or two terms has nothing to average its rounding over
+                assert abs(g["cost"][0] - e["cost"]) <= slack * tol * abs(e["cost"]), where
+                assert _rel(g["JtJ"][0], e["JtJ"]) <= slack * tol and _rel(g["Jtr"][0], e["Jtr"]) <= slack * tol, where
+        finally:
+            B.close(); P.close()
