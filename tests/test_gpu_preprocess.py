@@ -317,3 +317,52 @@ def test_frame_to_frame_tracker(hip, flavour):
             q_prior, t_prior = qm, tm
         (P.set_ref_frame if flavour == 0 else P.set_ref_frame_canny)(bgr, depth)
     T.close(); P.close()
+
+
+def test_random_frame_sizes_all_flavours(hip, frames):
+    """Widths / heights on both sides of the kernels' tile sizes (16, 32, 64, 256), tiny frames, thin strips, dense
+    noise: every producer of the three flavours bit for bit against the restatement; frames with an extent below 3
+    are refused (no 3x3 neighbourhood to speak of)."""
+    pp = frames["pp"]
+    rng = np.random.default_rng(99)
+    sizes = [(3, 3), (4, 9), (7, 33), (31, 31), (32, 32), (33, 65), (65, 63), (3, 300), (300, 3), (129, 255), (130, 257), (17, 513)]
+    sizes += [(int(rng.integers(3, 200)), int(rng.integers(3, 300))) for _ in range(6)]
+    for k, (H, W) in enumerate(sizes):
+        bgr = rng.integers(0, 256, (H, W, 3), dtype=np.uint8) if k % 3 == 0 else _random_frame(100 + k, H, W)
+        depth = rng.integers(0, 30000, (H, W)).astype(np.uint16)
+        depth[rng.random((H, W)) < 0.15] = 0
+        P = hip.Problem(*K, dtype=hip.EA_F64)
+        st = P.set_now_frame(bgr, threshold=35, median=True, normalize=True, debug=True)
+        lap = pp.edge_strength(bgr)
+        mask = pp.median_blur3_u8(np.where(lap > 35, 0, 255).astype(np.uint8))
+        assert np.array_equal(st["lap"], lap) and np.array_equal(st["mask"], mask), (H, W)
+        if (mask == 0).any():
+            assert np.array_equal(st["chamfer"].astype(np.int64), pp.chamfer3x3_fixed(mask == 0)), (H, W)
+            assert np.array_equal(st["dt"], pp.get_distance_transform(bgr)), (H, W)
+        aX, _ = pp.get_aX(bgr, depth, *K)
+        P.set_ref_frame(bgr, depth)
+        assert P.num_points == aX.shape[1] and (P.num_points == 0 or np.array_equal(P.get_points(), aX[:3].T)), (H, W)
+        got = P.set_now_frame_canny(bgr, debug=True)
+        edges = pp.canny_edges_of_frame(bgr)
+        assert np.array_equal(got["edges"], edges), (H, W)
+        if (edges != 0).any():
+            assert np.array_equal(got["chamfer"], pp.chamfer3x3_fixed(edges != 0)), (H, W)
+            assert np.array_equal(got["dt"], pp.get_distance_transform2(bgr)), (H, W)
+        aXc, _ = pp.get_aX_canny(bgr, depth, *K)
+        P.set_ref_frame_canny(bgr, depth)
+        assert P.num_points == aXc.shape[1] and (P.num_points == 0 or np.array_equal(P.get_points(), aXc[:3].T)), (H, W)
+        e2 = pp.canny_u8(bgr, 150.0, 100.0, l2_gradient=True)
+        if (e2 > 0).any():
+            got = P.set_now_frame_ros(bgr, debug=True)
+            assert np.array_equal(got["edges"], e2) and np.array_equal(got["dt"], pp.ros_now_distance_transform(bgr)), (H, W)
+            df = (rng.random((H, W)) * 4.0 + 0.4).astype(np.float32)
+            df[rng.random((H, W)) < 0.2] = 0.0
+            pts, _ = pp.ros_ref_points(bgr, df, *K)
+            P.set_ref_frame_ros(bgr, df)
+            assert P.num_points == pts.shape[1] and np.array_equal(P.get_points(), pts.T), (H, W)
+        P.close()
+    P = hip.Problem(*K, dtype=hip.EA_F64)
+    for (H, W) in [(1, 40), (40, 2)]:
+        with pytest.raises(Exception):
+            P.set_now_frame(np.zeros((H, W, 3), np.uint8))
+    P.close()
