@@ -92,3 +92,65 @@ def test_variant_argument_checks(hip):
     with pytest.raises(hip.EAError):
         P.add_term(P32)  # dtype mismatch
     P.close(); P32.close()
+
+
+def test_random_mixed_batches(hip, oracle):
+    """Batches mixing plain, distorted, second-camera and stereo (two-term) problems of ragged sizes, both launch shapes
+    of the variant kernel, both dtypes: batch evaluation and batch solve against the oracle, problem by problem."""
+    rng = np.random.default_rng(77)
+    for trial in range(6):
+        dtype, tol = (hip.EA_F64, 1e-10) if trial % 2 == 0 else (hip.EA_F32, 2e-4)
+        m = int(rng.integers(3, 7))
+        Ps, Os, clouds, keep = [], [], [], []
+
+        def gpu(fam, K, d, t12):
+            P = _gpu(hip, fam, dtype, K, d, t12)
+            keep.append(P)
+            return P
+
+        for i in range(m):
+            kind = int(rng.integers(0, 4))  # 0 plain, 1 Ex, 2 SecondCam, 3 stereo pair with distortion
+            Qp = synth.quat_from_axis_angle(rng.standard_normal(3), np.deg2rad(rng.uniform(0.3, 1.5)))
+            Tp = rng.uniform(-0.02, 0.02, 3)
+            dist = tuple(rng.uniform(-1, 1, 5) * np.array([0.2, 0.5, 0.005, 0.005, 0.5])) if kind in (1, 3) else None
+            T12r = synth.rigid_4x4(synth.quat_from_axis_angle(rng.standard_normal(3), 0.04), rng.uniform(-0.1, 0.1, 3))
+            fams = synth.make_stereo_problem(120, 160, int(rng.integers(200, 2500)), int(rng.integers(200, 2500)),
+                                             100 * trial + i, K1, K2, T12r, Qp, Tp, distortion=dist)
+            if kind in (0, 1):
+                Ps.append(gpu(fams[0], K1, dist, None))
+                Os.append([oracle.OracleProblem(fams[0]["grid"], *K1, distortion=dist)])
+                clouds.append([fams[0]["xyz"]])
+            elif kind == 2:
+                Ps.append(gpu(fams[1], K2, None, T12r))
+                Os.append([oracle.OracleProblem(fams[1]["grid"], *K2, T12=T12r)])
+                clouds.append([fams[1]["xyz"]])
+            else:
+                P1, P2 = gpu(fams[0], K1, dist, None), gpu(fams[1], K2, dist, T12r)
+                P1.add_term(P2)
+                Ps.append(P1)
+                Os.append([oracle.OracleProblem(fams[0]["grid"], *K1, distortion=dist),
+                           oracle.OracleProblem(fams[1]["grid"], *K2, distortion=dist, T12=T12r)])
+                clouds.append([fams[0]["xyz"], fams[1]["xyz"]])
+        B = hip.Batch(Ps)
+        q = np.tile([1.0, 0, 0, 0], (m, 1)) + 0.004 * rng.standard_normal((m, 4))
+        q /= np.linalg.norm(q, axis=1)[:, None]
+        t = 0.005 * rng.standard_normal((m, 3))
+        try:
+            for ppt in (1, 2):
+                B.set_tuning("points_per_thread", ppt)
+                g = B.eval(q, t)
+                for i in range(m):
+                    e = oracle.eval_terms(Os[i], clouds[i], q[i], t[i], oracle.JAC_JET)
+                    assert int(g["n_invalid"][i]) == int(e["n_invalid"]), (trial, i, ppt)
+                    assert abs(g["cost"][i] - e["cost"]) <= tol * abs(e["cost"]), (trial, i, ppt)
+                    assert _rel(g["JtJ"][i], e["JtJ"]) <= tol and _rel(g["Jtr"][i], e["Jtr"]) <= tol, (trial, i, ppt)
+            if dtype == hip.EA_F64:
+                qs, ts, ss = B.solve(q, t)
+                for i in range(m):
+                    qo, to, so = oracle.solve_terms(Os[i], clouds[i], q[i], t[i])
+                    assert ss[i]["why"] == so["why"] and ss[i]["num_iterations"] == so["num_iterations"], (trial, i)
+                    assert synth.rotation_angle_between(qs[i], qo) < 1e-7 and np.linalg.norm(ts[i] - to) < 1e-7, (trial, i)
+        finally:
+            B.close()
+            for P in keep:
+                P.close()
