@@ -36,3 +36,17 @@ print('2048x1536 set_now_frame %.3f ms' % timeit(lambda: P2.set_now_frame(big), 
 print('2048x1536 set_ref_frame_canny %.3f ms  (n=%d)' % (timeit(lambda: P2.set_ref_frame_canny(big, bigd), 5), P2.num_points))
 print('2048x1536 set_now_frame_canny %.3f ms  (hysteresis launches: %d)' % (timeit(lambda: P2.set_now_frame_canny(big), 5), P2.set_now_frame_canny(big, debug=True)['hysteresis_launches']))
 P.close(); P2.close()
+# frame-to-frame tracker (ea_tracker_*): the whole per-frame pipeline of a sequence -- DT of the new frame, solve of the
+# previous frame's points from the last relative pose, the new frame's points -- on the five bundled grabs, cycled
+frames = [(pp.load_rgb_as_bgr(os.path.join(G, 'rgb_%d.png' % i)), pp.load_depth_u16(os.path.join(G, 'depth_%d.png' % i))) for i in range(1, 6)]
+for flavour, name in ((0, 'Laplacian'), (1, 'Canny')):
+    for dtype, dn in ((capi.EA_F64, 'fp64'), (capi.EA_F32, 'fp32')):
+        T = capi.Tracker(*K, dtype=dtype, flavour=flavour, loss=(capi.LOSS_CAUCHY, 1.0))
+        for bgr, dep in frames: T.push_frame(bgr, dep)
+        n, its, t0 = 0, 0, time.perf_counter()
+        for rep in range(6):
+            for bgr, dep in (frames if rep % 2 == 0 else frames[::-1]):
+                q, t, s = T.push_frame(bgr, dep); n += 1; its += s['num_iterations'] if s else 0
+        el = (time.perf_counter() - t0) / n
+        print('640x480  tracker push_frame, %s flavour, %s: %.3f ms per frame (%.0f frames/s, %.1f LM iterations per frame)' % (name, dn, el * 1e3, 1.0 / el, its / n))
+        T.close()
