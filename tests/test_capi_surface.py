@@ -96,3 +96,15 @@ def test_product_never_imports_the_oracle():
                 if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
                     src = open(os.path.join(dirpath, f)).read()
                     assert not pat.search(src), (dirpath, f, pat.search(src).group(0))
+
+
+def test_header_is_plain_c99(tmp_path):
+    """the boundary is a C ABI: include/ea_hip.h compiles as C99 with -pedantic -Werror, and the plain-C example builds
+    against it and the shared library (no C++, no HIP headers)"""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "ea_hip.h"\nint main(void) { ea_options o; ea_default_options(&o); return o.max_num_iterations > 0 ? 0 : 1; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           "-c", str(src), "-o", str(tmp_path / "hdr.o")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples"), "c_abi_demo"])
+    assert os.path.exists(os.path.join(ROOT, "examples", "c_abi_demo"))

@@ -133,3 +133,23 @@ def test_stereo_call_sequence(binaries, oracle, tmp_path, ex):
     assert synth.rotation_angle_between(q, qo) < 1e-7 and np.linalg.norm(t - to) < 1e-7
     assert int(v[8]) == so["termination"]
     assert "Use Point count = 5000" in out.stderr
+
+
+def test_c_abi_from_plain_c(binaries, hip, bundled_pair, tmp_path):
+    """examples/c_abi_demo.c: C99, gcc, include/ea_hip.h and nothing else.  Same inputs through the C program and through
+    the ctypes stub: the same bits come back."""
+    X = np.ascontiguousarray(bundled_pair["aX"][:3, ::7].T)
+    grid = np.ascontiguousarray(bundled_pair["grids"][3], dtype=np.float64)
+    pts, gr = str(tmp_path / "points.f64"), str(tmp_path / "grid.f64")
+    X.tofile(pts); grid.tofile(gr)
+    K = bundled_pair["K"]
+    out = subprocess.run([os.path.join(binaries, "c_abi_demo"), str(X.shape[0]), str(grid.shape[0]), str(grid.shape[1]),
+                          *[repr(float(k)) for k in K], pts, gr], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    v = [float(x) for x in out.stdout.split()]
+    P = hip.Problem(*K, dtype=hip.EA_F64)
+    P.set_points(X); P.set_dt_grid(grid); P.set_loss(hip.LOSS_CAUCHY, 1.0)
+    q, t, s = P.solve([1.0, 0, 0, 0], [0.0, 0, 0])
+    P.close()
+    assert v[:4] == list(q) and v[4:7] == list(t)
+    assert int(v[7]) == s["num_iterations"] and int(v[8]) == s["termination"] and v[9] == s["final_cost"]
