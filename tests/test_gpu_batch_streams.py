@@ -82,3 +82,51 @@ def test_random_batches_are_stream_invariant():
     finally:
         for P in pool.values():
             P.close()
+
+
+def test_handles_on_different_host_threads():
+    """a handle is not thread-safe, different handles on different host threads are fine --
+    four threads, each with its own problems and batch, solving at the same time, get what a lone thread gets."""
+    import threading
+    n_threads, per = 4, 6
+    sets, refs = [], []
+    for k in range(n_threads):
+        Ps = []
+        for i in range(per):
+            cfg = synth.config_c2_twin(seed=900 + 10 * k + i, n_points=2500 + 300 * i)
+            P = capi.Problem(*cfg["K"], dtype=capi.EA_F64)
+            P.set_points(cfg["xyz"]); P.set_dt_grid(cfg["grid"]); P.set_loss(capi.LOSS_CAUCHY, 1.0)
+            Ps.append(P)
+        sets.append((Ps, capi.Batch(Ps)))
+    q0 = np.tile([1.0, 0, 0, 0], (per, 1)); t0 = np.zeros((per, 3))
+    try:
+        for Ps, B in sets:
+            q, t, s = B.solve(q0, t0)
+            refs.append((q.tobytes(), t.tobytes(), tuple(x["num_iterations"] for x in s)))
+        out = [None] * n_threads
+        errs = []
+
+        def work(k):
+            try:
+                res = []
+                for _ in range(10):
+                    q, t, s = sets[k][1].solve(q0, t0)
+                    res.append((q.tobytes(), t.tobytes(), tuple(x["num_iterations"] for x in s)))
+                    e = sets[k][0][0].eval(q0[0], t0[0])  # single-problem handle of the same thread in between
+                    assert np.isfinite(e["cost"])
+                out[k] = res
+            except Exception as ex:  # surfaced below: an assertion in a thread would otherwise be lost
+                errs.append(repr(ex))
+        th = [threading.Thread(target=work, args=(k,)) for k in range(n_threads)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not errs, errs
+        for k in range(n_threads):
+            assert all(r == refs[k] for r in out[k]), k
+    finally:
+        for Ps, B in sets:
+            B.close()
+            for P in Ps:
+                P.close()
