@@ -111,6 +111,9 @@ struct ea_problem {
   int order_tile = -1, order_tile_used = 0;
   std::vector<int32_t> order;
   void *d_dt = nullptr;
+  size_t dt_cap = 0;   // bytes allocated behind d_dt: a frame of the same size reuses the allocation
+  size_t pts_cap = 0;  // bytes allocated behind each of d_x, d_y, d_z when own_points (hipFree / hipMalloc per frame
+                       // cost more than the whole pre-processing of a 640x480 frame)
   int W = 0, H = 0, pitch = 0;
   uint64_t version = 1;  // bumped by every setter; batches rebuild their descriptors lazily
   ea_batch *self = nullptr;
@@ -232,9 +235,30 @@ static void free_points(ea_problem *p) {
   }
   p->d_x = p->d_y = p->d_z = nullptr;
   p->own_points = false;
+  p->pts_cap = 0;
   p->n = 0;
   p->order.clear();
   p->order_tile_used = 0;
+}
+
+// Room for n points in arrays the problem owns: the previous allocation when it is large enough (and not more than
+// four times too large), a fresh one otherwise.  Leaves the problem without points (n = 0) either way.
+static int reserve_points(ea_problem *p, int64_t n) {
+  const size_t need = (size_t)n * (p->dtype == EA_F32 ? 4 : 8);
+  if (p->own_points && p->pts_cap >= need && p->pts_cap <= 4 * need + 4096) {
+    p->n = 0;
+    p->order.clear();
+    p->order_tile_used = 0;
+    return EA_OK;
+  }
+  free_points(p);
+  if (n == 0) return EA_OK;
+  p->own_points = true;  // (before the allocations: a failure half-way leaves what was allocated to free_points)
+  HIPCHK(hipMalloc(&p->d_x, need));
+  HIPCHK(hipMalloc(&p->d_y, need));
+  HIPCHK(hipMalloc(&p->d_z, need));
+  p->pts_cap = need;
+  return EA_OK;
 }
 
 // Storage order for large point sets: tiles of T x T pixels of the reference frame (the identity-pose projection),
@@ -330,9 +354,8 @@ extern "C" int ea_problem_set_points(ea_problem *p, const double *xyz, int64_t n
   if (n < 0 || n > 0x7fffff00LL) return fail(EA_ERR_INVALID_ARG, "n out of range");
   if (stride < 3) return fail(EA_ERR_INVALID_ARG, "stride_elems must be >= 3");
   HIPCHK(hipSetDevice(p->device));
-  free_points(p);
   p->version++;
-  if (n == 0) return EA_OK;
+  if (n == 0) { free_points(p); return EA_OK; }
   const size_t esz = p->dtype == EA_F32 ? 4 : 8;
   std::vector<unsigned char> soa(3 * (size_t)n * esz);
   std::vector<int32_t> order;
@@ -348,10 +371,10 @@ extern "C" int ea_problem_set_points(ea_problem *p, const double *xyz, int64_t n
       for (int64_t i = 0; i < n; ++i) dst[i] = xyz[(ord ? ord[i] : i) * stride + c];
     }
   }
-  p->own_points = true;  // (before the allocations: a failure half-way leaves what was allocated to free_points)
-  HIPCHK(hipMalloc(&p->d_x, n * esz));
-  HIPCHK(hipMalloc(&p->d_y, n * esz));
-  HIPCHK(hipMalloc(&p->d_z, n * esz));
+  {
+    int rc = reserve_points(p, n);
+    if (rc != EA_OK) return rc;
+  }
   HIPCHK(hipMemcpy(p->d_x, soa.data(), n * esz, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(p->d_y, soa.data() + (size_t)n * esz, n * esz, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(p->d_z, soa.data() + 2 * (size_t)n * esz, n * esz, hipMemcpyHostToDevice));
@@ -387,11 +410,14 @@ extern "C" int ea_problem_set_points_device(ea_problem *p, const void *x, const 
 }
 
 static int alloc_dt(ea_problem *p, int W, int H) {
-  if (p->d_dt) { (void)hipFree(p->d_dt); p->d_dt = nullptr; }
   p->W = W; p->H = H;
   p->pitch = (W + 2 * kImagePad + 3) & ~3;
   const size_t esz = p->dtype == EA_F32 ? 4 : 8;
-  HIPCHK(hipMalloc(&p->d_dt, (size_t)p->pitch * (size_t)(H + 2 * kImagePad) * esz));
+  const size_t need = (size_t)p->pitch * (size_t)(H + 2 * kImagePad) * esz;
+  if (p->d_dt && p->dt_cap >= need && p->dt_cap <= 4 * need) return EA_OK;  // same-size frame: keep the allocation
+  if (p->d_dt) { (void)hipFree(p->d_dt); p->d_dt = nullptr; p->dt_cap = 0; }
+  HIPCHK(hipMalloc(&p->d_dt, need));
+  p->dt_cap = need;
   return EA_OK;
 }
 
@@ -1400,14 +1426,10 @@ static int ref_frame_impl(ea_problem *p, const uint8_t *bgr, const uint8_t *mask
   HIPCHK(launch_edge_count_scan(d_lap, d_depth, height, width, threshold, d_counts, d_total, nullptr));
   int total = 0;
   HIPCHK(hipMemcpy(&total, d_total, sizeof(int), hipMemcpyDeviceToHost));
-  free_points(p);
   p->version++;
+  rc = reserve_points(p, total);
+  if (rc != EA_OK) return rc;
   if (total > 0) {
-    const size_t esz = p->dtype == EA_F32 ? 4 : 8;
-    p->own_points = true;
-    HIPCHK(hipMalloc(&p->d_x, (size_t)total * esz));
-    HIPCHK(hipMalloc(&p->d_y, (size_t)total * esz));
-    HIPCHK(hipMalloc(&p->d_z, (size_t)total * esz));
     HIPCHK(launch_edge_scatter(p->dtype, d_lap, d_depth, height, width, threshold, d_counts, p->cam.fx, p->cam.fy, p->cam.cx,
                                p->cam.cy, z_scaling, p->d_x, p->d_y, p->d_z, total, nullptr));
     HIPCHK(hipDeviceSynchronize());
@@ -1441,11 +1463,8 @@ static int dt_from_mask(ea_problem *p, WsCarver &ws, const uint8_t *d_mask, int 
   float *d_dist_f32 = precise ? reinterpret_cast<float *>(d_dist) : nullptr;
   HIPCHK(launch_chamfer(d_mask, height, width, d_G, d_scan, d_dist, d_dist_f32, d_minmax, nullptr));
   {
-    if (p->d_dt) { (void)hipFree(p->d_dt); p->d_dt = nullptr; }
-    p->W = width; p->H = height;
-    p->pitch = (width + 2 * kImagePad + 3) & ~3;
-    const size_t esz = p->dtype == EA_F32 ? 4 : 8;
-    HIPCHK(hipMalloc(&p->d_dt, (size_t)p->pitch * (size_t)(height + 2 * kImagePad) * esz));
+    int rc = alloc_dt(p, width, height);
+    if (rc != EA_OK) return rc;
   }
   HIPCHK(launch_dt_store(p->dtype, d_dist, d_dist_f32, height, width, d_minmax, normalize, lo, hi, p->d_dt, p->pitch, d_plain,
                          nullptr));
@@ -1517,14 +1536,10 @@ extern "C" int ea_problem_set_ref_frame_canny(ea_problem *p, const uint8_t *bgr,
   HIPCHK(launch_edge_count_scan(d_edges, d_depth, height, width, 0, d_counts, d_total, nullptr));
   int total = 0;
   HIPCHK(hipMemcpy(&total, d_total, sizeof(int), hipMemcpyDeviceToHost));
-  free_points(p);
   p->version++;
+  rc = reserve_points(p, total);
+  if (rc != EA_OK) return rc;
   if (total > 0) {
-    const size_t esz = p->dtype == EA_F32 ? 4 : 8;
-    p->own_points = true;
-    HIPCHK(hipMalloc(&p->d_x, (size_t)total * esz));
-    HIPCHK(hipMalloc(&p->d_y, (size_t)total * esz));
-    HIPCHK(hipMalloc(&p->d_z, (size_t)total * esz));
     HIPCHK(launch_edge_scatter(p->dtype, d_edges, d_depth, height, width, 0, d_counts, p->cam.fx, p->cam.fy, p->cam.cx,
                                p->cam.cy, z_scaling, p->d_x, p->d_y, p->d_z, total, nullptr));
     HIPCHK(hipDeviceSynchronize());
@@ -1601,14 +1616,10 @@ extern "C" int ea_problem_set_ref_frame_ros(ea_problem *p, const uint8_t *bgr, c
   HIPCHK(launch_edge_count_scan(d_edges, nullptr, height, width, 0, d_counts, d_total, nullptr));
   int total = 0;
   HIPCHK(hipMemcpy(&total, d_total, sizeof(int), hipMemcpyDeviceToHost));
-  free_points(p);
   p->version++;
+  rc = reserve_points(p, total);
+  if (rc != EA_OK) return rc;
   if (total > 0) {
-    const size_t esz = p->dtype == EA_F32 ? 4 : 8;
-    p->own_points = true;
-    HIPCHK(hipMalloc(&p->d_x, (size_t)total * esz));
-    HIPCHK(hipMalloc(&p->d_y, (size_t)total * esz));
-    HIPCHK(hipMalloc(&p->d_z, (size_t)total * esz));
     HIPCHK(launch_edge_scatter_ros(p->dtype, d_edges, d_depth, height, width, d_counts, p->cam.fx, p->cam.fy, p->cam.cx,
                                    p->cam.cy, p->d_x, p->d_y, p->d_z, total, nullptr));
     HIPCHK(hipDeviceSynchronize());
