@@ -191,50 +191,71 @@ __global__ void ea_canny_nms_kernel(const int *__restrict__ mag, const uint8_t *
   label[(size_t)v * W + u] = out;
 }
 
-// hysteresis: candidates 8-connected to a strong pixel become strong.  One workgroup owns a 32 x 32 tile (+ halo)
-// in LDS and iterates until the tile is stable; tiles exchange through global memory between launches, the host
-// repeats the launch until no tile reports a change.
-constexpr int kHystTile = 32;
-__global__ __launch_bounds__(256) void ea_canny_hysteresis_kernel(uint8_t *__restrict__ label, int H, int W,
-                                                                  int *__restrict__ changed) {
-  __shared__ uint8_t s_l[(kHystTile + 2) * (kHystTile + 2)];
-  const int x0 = blockIdx.x * kHystTile - 1, y0 = blockIdx.y * kHystTile - 1;
-  for (int i = threadIdx.x; i < (kHystTile + 2) * (kHystTile + 2); i += 256) {
-    const int ly = i / (kHystTile + 2), lx = i - ly * (kHystTile + 2);
-    const int y = y0 + ly, x = x0 + lx;
-    s_l[i] = (y >= 0 && y < H && x >= 0 && x < W) ? label[(size_t)y * W + x] : 1;
+// hysteresis: candidates 8-connected to a strong pixel become strong.  One WAVEFRONT owns a tile of 62 x 62 pixels
+// plus a one-pixel halo as bit masks: lane = image row, bit = image column, one 64-bit word of strong pixels and one of
+// candidates per lane.  A sweep takes the strong pixels of the rows above and below (two lane shifts), widens them by
+// one column either way, and floods the result along the row's runs of candidates with a Kogge-Stone fill (six
+// shift-and-mask steps per direction) -- so a sweep carries "strong" across a whole horizontal run and one row up or
+// down, with no LDS and no barrier, where a per-pixel update needs one pass (and one barrier) per pixel of the chain.
+// Tiles exchange through global memory between launches; the host repeats the launch until no tile reports a change.
+constexpr int kHystTile = 62;
+__device__ __forceinline__ unsigned long long hyst_fill(unsigned long long seed, unsigned long long cand) {
+  unsigned long long g = seed, pr = cand;  // towards higher bits
+  g |= pr & (g << 1);  pr &= pr << 1;
+  g |= pr & (g << 2);  pr &= pr << 2;
+  g |= pr & (g << 4);  pr &= pr << 4;
+  g |= pr & (g << 8);  pr &= pr << 8;
+  g |= pr & (g << 16); pr &= pr << 16;
+  g |= pr & (g << 32);
+  unsigned long long h = seed, pl = cand;  // towards lower bits
+  h |= pl & (h >> 1);  pl &= pl >> 1;
+  h |= pl & (h >> 2);  pl &= pl >> 2;
+  h |= pl & (h >> 4);  pl &= pl >> 4;
+  h |= pl & (h >> 8);  pl &= pl >> 8;
+  h |= pl & (h >> 16); pl &= pl >> 16;
+  h |= pl & (h >> 32);
+  return g | h;
+}
+
+__global__ __launch_bounds__(256) void ea_canny_hysteresis_kernel(uint8_t *__restrict__ label, int H, int W, int tiles_x,
+                                                                  int tiles, int *__restrict__ changed) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);  // wave-uniform
+  if (tile >= tiles) return;
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int x0 = tx * kHystTile - 1, y0 = ty * kHystTile - 1;  // image position of bit 0 / lane 0 (the halo)
+  const int x = x0 + lane;
+  const bool x_in = x >= 0 && x < W;
+  // row r of the tile -> lane r: every lane reads one byte of the row, two ballots make the row's masks
+  unsigned long long S = 0, C = 0;
+  for (int r = 0; r < 64; ++r) {
+    const int y = y0 + r;
+    int v = 1;
+    if (x_in && y >= 0 && y < H) v = label[(size_t)y * W + x];  // (y uniform)
+    const unsigned long long sm = __ballot(v == 2), cm = __ballot(v == 0);
+    if (lane == r) { S = sm; C = cm; }
   }
-  __syncthreads();
-  bool any = false;
+  const unsigned long long S0 = S;
   for (;;) {
-    bool ch = false;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = threadIdx.x + 256 * k;
-      const int ly = 1 + i / kHystTile, lx = 1 + (i & (kHystTile - 1));
-      const int c = ly * (kHystTile + 2) + lx;
-      if (s_l[c] == 0) {
-        const int r = kHystTile + 2;
-        if (s_l[c - r - 1] == 2 || s_l[c - r] == 2 || s_l[c - r + 1] == 2 || s_l[c - 1] == 2 || s_l[c + 1] == 2 ||
-            s_l[c + r - 1] == 2 || s_l[c + r] == 2 || s_l[c + r + 1] == 2) {
-          s_l[c] = 2;
-          ch = true;
-        }
-      }
-    }
-    any = any || ch;
-    if (!__syncthreads_or(ch)) break;
+    unsigned long long up = __shfl_up(S, 1), dn = __shfl_down(S, 1);
+    if (lane == 0) up = 0;
+    if (lane == 63) dn = 0;
+    const unsigned long long n = up | dn | S;
+    const unsigned long long seed = (n | (n << 1) | (n >> 1)) & C;
+    const unsigned long long grown = hyst_fill(seed, C);
+    const bool ch = grown != 0;
+    S |= grown;
+    C &= ~grown;
+    if (!__any(ch)) break;
   }
-  if (__syncthreads_or(any)) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = threadIdx.x + 256 * k;
-      const int ly = 1 + i / kHystTile, lx = 1 + (i & (kHystTile - 1));
-      const int y = y0 + ly, x = x0 + lx;
-      if (y < H && x < W) label[(size_t)y * W + x] = s_l[ly * (kHystTile + 2) + lx];
-    }
-    if (threadIdx.x == 0) atomicOr(changed, 1);
+  const unsigned long long D = S & ~S0;  // what this launch made strong, halo included (a neighbour's pixel: same answer)
+  if (!__any(D != 0)) return;
+  for (int r = 0; r < 64; ++r) {
+    const unsigned long long d = __shfl(D, r);
+    const int y = y0 + r;
+    if (((d >> lane) & 1ull) && x_in && y >= 0 && y < H) label[(size_t)y * W + x] = 2;
   }
+  if (lane == 0) atomicOr(changed, 1);
 }
 
 // labels -> the CV_8U edge map (255 on edges) [AND the optional mask: inputmask > 1] and the DT source mask
@@ -597,12 +618,14 @@ hipError_t launch_canny(const uint8_t *bgr, int H, int W, int low, int high, int
   hipLaunchKernelGGL(ea_canny_nms_kernel, grid, block, 0, s, mag, dir, H, W, low, high, label);
   // hysteresis rounds: four launches per check of the change flag (a launch that changes nothing is ~3 us, a
   // flag read-back is a stream synchronisation)
-  const dim3 tgrid((W + kHystTile - 1) / kHystTile, (H + kHystTile - 1) / kHystTile);
+  const int tiles_x = (W + kHystTile - 1) / kHystTile, tiles = tiles_x * ((H + kHystTile - 1) / kHystTile);
+  const dim3 tgrid((tiles + 3) / 4);
   int rounds = 0;
   for (;;) {
     hipError_t e = hipMemsetAsync(changed, 0, sizeof(int), s);
     if (e != hipSuccess) return e;
-    for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(ea_canny_hysteresis_kernel, tgrid, dim3(256), 0, s, label, H, W, changed);
+    for (int k = 0; k < 4; ++k)
+      hipLaunchKernelGGL(ea_canny_hysteresis_kernel, tgrid, dim3(256), 0, s, label, H, W, tiles_x, tiles, changed);
     int h = 0;
     e = hipMemcpyAsync(&h, changed, sizeof(int), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
