@@ -1494,7 +1494,7 @@ static int run_canny(WsCarver &ws, const uint8_t *d_bgr, const uint8_t *d_keep, 
   int *d_mag = ws.take<int>(np);
   uint8_t *d_dir = ws.take<uint8_t>(np), *d_label = ws.take<uint8_t>(np);
   uint8_t *d_edges = ws.take<uint8_t>(np), *d_inv = ws.take<uint8_t>(np);
-  int *d_changed = ws.take<int>(1);
+  int *d_changed = ws.take<int>(16);  // one change flag per launch of a hysteresis batch
   HIPCHK(launch_canny(d_bgr, height, width, low, high, l2_bgr, d_keep, d_gray, d_mag, d_dir, d_label, d_edges, d_inv,
                       d_changed, rounds_out, nullptr));
   *edges_out = d_edges;

@@ -199,6 +199,7 @@ __global__ void ea_canny_nms_kernel(const int *__restrict__ mag, const uint8_t *
 // down, with no LDS and no barrier, where a per-pixel update needs one pass (and one barrier) per pixel of the chain.
 // Tiles exchange through global memory between launches; the host repeats the launch until no tile reports a change.
 constexpr int kHystTile = 62;
+constexpr int kHystBatch = 8;  // launches enqueued per look at the change flags
 __device__ __forceinline__ unsigned long long hyst_fill(unsigned long long seed, unsigned long long cand) {
   unsigned long long g = seed, pr = cand;  // towards higher bits
   g |= pr & (g << 1);  pr &= pr << 1;
@@ -218,7 +219,11 @@ __device__ __forceinline__ unsigned long long hyst_fill(unsigned long long seed,
 }
 
 __global__ __launch_bounds__(256) void ea_canny_hysteresis_kernel(uint8_t *__restrict__ label, int H, int W, int tiles_x,
-                                                                  int tiles, int *__restrict__ changed) {
+                                                                  int tiles, const int *__restrict__ prev_changed,
+                                                                  int *__restrict__ changed) {
+  // launches are enqueued in batches without a host look in between: once a launch has changed nothing the edge set
+  // is final and the launches queued behind it have nothing to do
+  if (prev_changed && *prev_changed == 0) return;
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);  // wave-uniform
   if (tile >= tiles) return;
@@ -226,15 +231,23 @@ __global__ __launch_bounds__(256) void ea_canny_hysteresis_kernel(uint8_t *__res
   const int x0 = tx * kHystTile - 1, y0 = ty * kHystTile - 1;  // image position of bit 0 / lane 0 (the halo)
   const int x = x0 + lane;
   const bool x_in = x >= 0 && x < W;
-  // row r of the tile -> lane r: every lane reads one byte of the row, two ballots make the row's masks
+  // row r of the tile -> lane r: every lane reads one byte of the row, two ballots make the row's masks.  All 64 loads
+  // are issued before the first ballot (one memory round trip for the tile instead of 64 dependent ones).
+  uint8_t v[64];
+#pragma unroll
+  for (int r = 0; r < 64; ++r) {
+    const int y = min(max(y0 + r, 0), H - 1);  // (uniform; rows outside the image are masked below)
+    v[r] = x_in ? label[(size_t)y * W + x] : (uint8_t)1;
+  }
   unsigned long long S = 0, C = 0;
+#pragma unroll
   for (int r = 0; r < 64; ++r) {
     const int y = y0 + r;
-    int v = 1;
-    if (x_in && y >= 0 && y < H) v = label[(size_t)y * W + x];  // (y uniform)
-    const unsigned long long sm = __ballot(v == 2), cm = __ballot(v == 0);
+    const int vr = (y >= 0 && y < H) ? (int)v[r] : 1;
+    const unsigned long long sm = __ballot(vr == 2), cm = __ballot(vr == 0);
     if (lane == r) { S = sm; C = cm; }
   }
+  if (!__any(C != 0)) return;  // no candidate in the tile: nothing can change
   const unsigned long long S0 = S;
   for (;;) {
     unsigned long long up = __shfl_up(S, 1), dn = __shfl_down(S, 1);
@@ -251,7 +264,8 @@ __global__ __launch_bounds__(256) void ea_canny_hysteresis_kernel(uint8_t *__res
   const unsigned long long D = S & ~S0;  // what this launch made strong, halo included (a neighbour's pixel: same answer)
   if (!__any(D != 0)) return;
   for (int r = 0; r < 64; ++r) {
-    const unsigned long long d = __shfl(D, r);
+    const unsigned long long d = __shfl(D, r);  // (uniform)
+    if (d == 0) continue;
     const int y = y0 + r;
     if (((d >> lane) & 1ull) && x_in && y >= 0 && y < H) label[(size_t)y * W + x] = 2;
   }
@@ -616,23 +630,26 @@ hipError_t launch_canny(const uint8_t *bgr, int H, int W, int low, int high, int
     hipLaunchKernelGGL(ea_sobel_mag_kernel, grid, block, 0, s, gray, H, W, mag, dir);
   }
   hipLaunchKernelGGL(ea_canny_nms_kernel, grid, block, 0, s, mag, dir, H, W, low, high, label);
-  // hysteresis rounds: four launches per check of the change flag (a launch that changes nothing is ~3 us, a
-  // flag read-back is a stream synchronisation)
+  // hysteresis: launches are enqueued eight at a time, each with a change flag of its own; a launch whose predecessor
+  // changed nothing returns at once, and the host reads the eight flags with one stream synchronisation
   const int tiles_x = (W + kHystTile - 1) / kHystTile, tiles = tiles_x * ((H + kHystTile - 1) / kHystTile);
   const dim3 tgrid((tiles + 3) / 4);
   int rounds = 0;
   for (;;) {
-    hipError_t e = hipMemsetAsync(changed, 0, sizeof(int), s);
+    hipError_t e = hipMemsetAsync(changed, 0, kHystBatch * sizeof(int), s);
     if (e != hipSuccess) return e;
-    for (int k = 0; k < 4; ++k)
-      hipLaunchKernelGGL(ea_canny_hysteresis_kernel, tgrid, dim3(256), 0, s, label, H, W, tiles_x, tiles, changed);
-    int h = 0;
-    e = hipMemcpyAsync(&h, changed, sizeof(int), hipMemcpyDeviceToHost, s);
+    for (int k = 0; k < kHystBatch; ++k)
+      hipLaunchKernelGGL(ea_canny_hysteresis_kernel, tgrid, dim3(256), 0, s, label, H, W, tiles_x, tiles,
+                         k == 0 ? (const int *)nullptr : changed + k - 1, changed + k);
+    int h[kHystBatch];
+    e = hipMemcpyAsync(h, changed, kHystBatch * sizeof(int), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return e;
-    rounds += 4;
-    // the flag is the OR over the four launches: it can only be clear when the last one changed nothing either
-    if (!h) break;
+    int quiet = -1;
+    for (int k = 0; k < kHystBatch && quiet < 0; ++k)
+      if (!h[k]) quiet = k;
+    if (quiet >= 0) { rounds += quiet + 1; break; }  // launch `quiet` confirmed the fixed point
+    rounds += kHystBatch;
     // safety net only: a launch that reports a change has grown the edge set, and a chain crosses at least one tile
     // per launch, so the number of tiles bounds the launches
     if (rounds > (int)(((long long)H * W) / 256) + 64) return hipErrorUnknown;
