@@ -132,6 +132,11 @@ struct ea_batch {
   // device
   ProblemDesc *d_probs = nullptr;       // one per term (problem + its additional terms), groups contiguous
   GroupDesc *d_groups = nullptr;         // one per problem (= pose)
+  // descriptors go up from a pinned staging block with asynchronous copies on the batch's stream (a frame pair that
+  // changes its points / DT every solve would otherwise pay two blocking copies per solve)
+  unsigned char *h_desc = nullptr;
+  size_t h_desc_cap = 0;
+  hipEvent_t desc_done = nullptr;
   int nterms = 0, terms_cap = 0;
   int any_variant = 0, terms_are_groups = 1;
   int ntiles = 0, tiles_cap = 0;  // rows of the partial-sum array (one per workgroup with work)
@@ -485,6 +490,9 @@ static void batch_free_device(ea_batch *b) {
   (void)hipFree(b->d_partials); (void)hipFree(b->d_out);
   (void)hipHostFree(b->h_lm_block); (void)hipHostFree(b->h_out);
   (void)hipHostFree(b->h_progress); (void)hipHostFree(b->h_deliver);
+  if (b->h_desc) (void)hipHostFree(b->h_desc);
+  if (b->desc_done) (void)hipEventDestroy(b->desc_done);
+  b->h_desc = nullptr; b->h_desc_cap = 0; b->desc_done = nullptr;
   b->d_probs = nullptr; b->d_groups = nullptr; b->d_poses = nullptr; b->d_partials = nullptr; b->d_traces = nullptr; b->d_cold = nullptr; b->d_lm_block = nullptr;
   b->d_out = nullptr; b->d_states = nullptr; b->d_progress = nullptr;
   b->h_poses = nullptr; b->h_out = nullptr; b->h_states = nullptr; b->h_traces = nullptr; b->h_progress = nullptr;
@@ -681,8 +689,22 @@ static int batch_build(ea_batch *b) {
     HIPCHK(hipMalloc(&b->d_partials, (size_t)b->tiles_cap * kAccSlots * sizeof(double)));
     HIPCHK(hipMemset(b->d_partials, 0, (size_t)b->tiles_cap * kAccSlots * sizeof(double)));
   }
-  HIPCHK(hipMemcpy(b->d_probs, descs.data(), descs.size() * sizeof(ProblemDesc), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(b->d_groups, groups.data(), groups.size() * sizeof(GroupDesc), hipMemcpyHostToDevice));
+  {
+    const size_t pb = descs.size() * sizeof(ProblemDesc), gb = groups.size() * sizeof(GroupDesc);
+    if (!b->desc_done) HIPCHK(hipEventCreateWithFlags(&b->desc_done, hipEventDisableTiming));
+    else HIPCHK(hipEventSynchronize(b->desc_done));  // the staging block is free again (it always is by now)
+    if (b->h_desc_cap < pb + gb) {
+      if (b->h_desc) (void)hipHostFree(b->h_desc);
+      b->h_desc = nullptr;
+      b->h_desc_cap = (pb + gb) * 2 + 1024;
+      HIPCHK(hipHostMalloc(&b->h_desc, b->h_desc_cap));
+    }
+    std::memcpy(b->h_desc, descs.data(), pb);
+    std::memcpy(b->h_desc + pb, groups.data(), gb);
+    HIPCHK(hipMemcpyAsync(b->d_probs, b->h_desc, pb, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->d_groups, b->h_desc + pb, gb, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipEventRecord(b->desc_done, b->stream));
+  }
   // LDS staging of the DT footprint is available but off by default: on MI355X the unaligned 16-byte
   // row loads served by the XCD's L2 beat it at every size measured
   int use_lds = b->t_use_lds < 0 ? 0 : b->t_use_lds;
