@@ -171,7 +171,8 @@ __global__ void ea_sobel_mag_l2_bgr_kernel(const uint8_t *__restrict__ bgr, int 
 
 // non-maximum suppression + double threshold: label 2 = strong, 0 = candidate, 1 = no edge
 __global__ void ea_canny_nms_kernel(const int *__restrict__ mag, const uint8_t *__restrict__ dir, int H, int W, int low,
-                                    int high, uint8_t *__restrict__ label) {
+                                    int high, uint8_t *__restrict__ label, int *__restrict__ flags, int nflags) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < nflags) flags[threadIdx.x] = 0;  // hysteresis change flags
   const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
   if (u >= W) return;
   auto M = [&](int yy, int xx) { return (yy < 0 || yy >= H || xx < 0 || xx >= W) ? 0 : mag[(size_t)yy * W + xx]; };
@@ -290,7 +291,9 @@ __global__ void ea_canny_finish_kernel(const uint8_t *__restrict__ label, const 
 constexpr int kSegRows = 32;
 
 __global__ void ea_column_local_kernel(const uint8_t *__restrict__ mask, int H, int W, int *__restrict__ G,
-                                       int *__restrict__ end_dn /*S x W*/, int *__restrict__ end_up /*S x W*/) {
+                                       int *__restrict__ end_dn /*S x W*/, int *__restrict__ end_up /*S x W*/,
+                                       unsigned int *__restrict__ minmax /* reset here for the row pass two launches on */) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { minmax[0] = 0xffffffffu; minmax[1] = 0u; }
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= W) return;
   const int s = blockIdx.y, y0 = s * kSegRows, y1 = min(H, y0 + kSegRows);
@@ -587,14 +590,10 @@ hipError_t launch_threshold_median(const uint8_t *lap, int H, int W, int thr, in
 // dist_fix (3x3 chamfer, 16.16 fixed point) or, when dist_f32 is given, the exact Euclidean distance in float32
 hipError_t launch_chamfer(const uint8_t *mask, int H, int W, int *G, int *scratch, int *dist_fix, float *dist_f32,
                           unsigned int *minmax, hipStream_t s) {
-  hipError_t e = hipMemsetAsync(minmax, 0xff, sizeof(unsigned int), s);  // min slot = max uint
-  if (e != hipSuccess) return e;
-  e = hipMemsetAsync(minmax + 1, 0, sizeof(unsigned int), s);
-  if (e != hipSuccess) return e;
   const int S = (H + kSegRows - 1) / kSegRows;
   int *end_dn = scratch, *end_up = scratch + (size_t)S * W, *carry_dn = scratch + 2 * (size_t)S * W,
       *carry_up = scratch + 3 * (size_t)S * W;
-  hipLaunchKernelGGL(ea_column_local_kernel, dim3((W + 63) / 64, S), dim3(64), 0, s, mask, H, W, G, end_dn, end_up);
+  hipLaunchKernelGGL(ea_column_local_kernel, dim3((W + 63) / 64, S), dim3(64), 0, s, mask, H, W, G, end_dn, end_up, minmax);
   hipLaunchKernelGGL(ea_column_carry_kernel, dim3((W + 63) / 64), dim3(64), 0, s, end_dn, end_up, H, W, S, carry_dn, carry_up);
   if (dist_f32)
     hipLaunchKernelGGL(ea_edt_row_kernel, dim3(H), dim3(256), (size_t)W * sizeof(int), s, G, carry_dn, carry_up, H, W,
@@ -629,14 +628,15 @@ hipError_t launch_canny(const uint8_t *bgr, int H, int W, int low, int high, int
     hipLaunchKernelGGL(ea_boxblur_gray_kernel, grid, block, 0, s, bgr, H, W, gray);
     hipLaunchKernelGGL(ea_sobel_mag_kernel, grid, block, 0, s, gray, H, W, mag, dir);
   }
-  hipLaunchKernelGGL(ea_canny_nms_kernel, grid, block, 0, s, mag, dir, H, W, low, high, label);
+  hipLaunchKernelGGL(ea_canny_nms_kernel, grid, block, 0, s, mag, dir, H, W, low, high, label, changed, kHystBatch);
   // hysteresis: launches are enqueued eight at a time, each with a change flag of its own; a launch whose predecessor
   // changed nothing returns at once, and the host reads the eight flags with one stream synchronisation
   const int tiles_x = (W + kHystTile - 1) / kHystTile, tiles = tiles_x * ((H + kHystTile - 1) / kHystTile);
   const dim3 tgrid((tiles + 3) / 4);
   int rounds = 0;
   for (;;) {
-    hipError_t e = hipMemsetAsync(changed, 0, kHystBatch * sizeof(int), s);
+    hipError_t e = hipSuccess;
+    if (rounds > 0) e = hipMemsetAsync(changed, 0, kHystBatch * sizeof(int), s);  // (the first batch's flags: zeroed by the NMS kernel)
     if (e != hipSuccess) return e;
     for (int k = 0; k < kHystBatch; ++k)
       hipLaunchKernelGGL(ea_canny_hysteresis_kernel, tgrid, dim3(256), 0, s, label, H, W, tiles_x, tiles,
