@@ -687,7 +687,9 @@ static int batch_build(ea_batch *b) {
     b->d_partials = nullptr;
     b->tiles_cap = b->ntiles + b->ntiles / 4 + 16;
     HIPCHK(hipMalloc(&b->d_partials, (size_t)b->tiles_cap * kAccSlots * sizeof(double)));
-    HIPCHK(hipMemset(b->d_partials, 0, (size_t)b->tiles_cap * kAccSlots * sizeof(double)));
+    // (stream-ordered on the batch's own stream: a null-stream memset is not ordered with a non-blocking stream and may
+    // land after the first evaluation has written its rows)
+    HIPCHK(hipMemsetAsync(b->d_partials, 0, (size_t)b->tiles_cap * kAccSlots * sizeof(double), b->stream));
   }
   {
     const size_t pb = descs.size() * sizeof(ProblemDesc), gb = groups.size() * sizeof(GroupDesc);

@@ -344,6 +344,26 @@ __global__ void ea_column_carry_kernel(const int *__restrict__ end_dn, const int
   }
 }
 
+// min / max of a non-negative float over the workgroup -> two atomics per workgroup (one per LANE, all on the same two
+// words, made the row pass an atomic-throughput kernel: 51 us of which ~40 were the 246 000 same-address atomics)
+__device__ __forceinline__ void block_minmax_atomic(float lmin, float lmax, unsigned int *minmax) {
+  __shared__ float s_mn[16], s_mx[16];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    lmin = fminf(lmin, __shfl_xor(lmin, off));
+    lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+  }
+  const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) { s_mn[wave] = lmin; s_mx[wave] = lmax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < nw; ++w) { lmin = fminf(lmin, s_mn[w]); lmax = fmaxf(lmax, s_mx[w]); }
+    // floats >= 0: the bit pattern orders like the value
+    atomicMin(&minmax[0], __float_as_uint(lmin));
+    atomicMax(&minmax[1], __float_as_uint(lmax));
+  }
+}
+
 __device__ __forceinline__ int chamfer_cost(int dx, int dy) {
   const int mx = max(dx, dy), mn = min(dx, dy);
   return kChamferA * mx + (kChamferB - kChamferA) * mn;
@@ -372,26 +392,29 @@ __global__ void ea_chamfer_row_kernel(const int *__restrict__ G, const int *__re
       const int g = s_g[x];
       if (g < kNoFeature) best = min(best, kChamferA * g);
     }
-    for (int dx = 1; dx < W; ++dx) {
+    // two offsets per trip: the four LDS reads are issued together (a candidate past the bound a*dx >= best cannot
+    // lower the minimum, so looking at it is harmless); one at a time the loop is a chain of LDS round trips
+    for (int dx = 1; dx < W; dx += 2) {
       if ((long long)kChamferA * dx >= best) break;
-      const int xl = x - dx, xr = x + dx;
-      if (xl < 0 && xr >= W) break;
-      if (xl >= 0) {
-        const int g = s_g[xl];
-        if (g < kNoFeature) best = min(best, chamfer_cost(dx, g));
+      if (x - dx < 0 && x + dx >= W) break;
+      int gl[2], gr[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int xl = x - dx - k, xr = x + dx + k;
+        gl[k] = xl >= 0 ? s_g[xl] : kNoFeature;
+        gr[k] = xr < W ? s_g[xr] : kNoFeature;
       }
-      if (xr < W) {
-        const int g = s_g[xr];
-        if (g < kNoFeature) best = min(best, chamfer_cost(dx, g));
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (gl[k] < kNoFeature) best = min(best, chamfer_cost(dx + k, gl[k]));
+        if (gr[k] < kNoFeature) best = min(best, chamfer_cost(dx + k, gr[k]));
       }
     }
     dist_fix[(size_t)y * W + x] = best;
     const float f = (float)((double)best * (1.0 / 65536.0));
     lmin = fminf(lmin, f); lmax = fmaxf(lmax, f);
   }
-  // floats >= 0: the bit pattern orders like the value
-  atomicMin(&minmax[0], __float_as_uint(lmin));
-  atomicMax(&minmax[1], __float_as_uint(lmax));
+  block_minmax_atomic(lmin, lmax, minmax);
 }
 
 // Exact Euclidean variant of the row pass (DIST_MASK_PRECISE): the same per-column distances G, squared cost
@@ -419,26 +442,31 @@ __global__ void ea_edt_row_kernel(const int *__restrict__ G, const int *__restri
       const int g = s_g[x];
       if (g < kNoFeature) { best = (long long)g * g; bg = g; }
     }
-    for (int dx = 1; dx < W; ++dx) {
-      const long long d2 = (long long)dx * dx;
-      if (d2 >= best) break;
-      const int xl = x - dx, xr = x + dx;
-      if (xl < 0 && xr >= W) break;
-      if (xl >= 0) {
-        const int g = s_g[xl];
-        if (g < kNoFeature && d2 + (long long)g * g < best) { best = d2 + (long long)g * g; bdx = dx; bg = g; }
+    // two offsets per trip, reads issued together; the candidates are still examined in the order dx ascending, left
+    // before right, with the strict comparison: the winning (dx, dy) pair -- and with it the float32 rounding of the
+    // result -- is the one the one-at-a-time search finds (a candidate with dx^2 >= best fails the comparison anyway)
+    for (int dx = 1; dx < W; dx += 2) {
+      if ((long long)dx * dx >= best) break;
+      if (x - dx < 0 && x + dx >= W) break;
+      int gl[2], gr[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int xl = x - dx - k, xr = x + dx + k;
+        gl[k] = xl >= 0 ? s_g[xl] : kNoFeature;
+        gr[k] = xr < W ? s_g[xr] : kNoFeature;
       }
-      if (xr < W) {
-        const int g = s_g[xr];
-        if (g < kNoFeature && d2 + (long long)g * g < best) { best = d2 + (long long)g * g; bdx = dx; bg = g; }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const long long d2 = (long long)(dx + k) * (dx + k);
+        if (gl[k] < kNoFeature && d2 + (long long)gl[k] * gl[k] < best) { best = d2 + (long long)gl[k] * gl[k]; bdx = dx + k; bg = gl[k]; }
+        if (gr[k] < kNoFeature && d2 + (long long)gr[k] * gr[k] < best) { best = d2 + (long long)gr[k] * gr[k]; bdx = dx + k; bg = gr[k]; }
       }
     }
     const float f = sqrtf(__fadd_rn((float)((long long)bdx * bdx), (float)((long long)bg * bg)));  // correctly rounded (HIP default); __fsqrt_rn is the native approximation
     dist_f32[(size_t)y * W + x] = f;
     lmin = fminf(lmin, f); lmax = fmaxf(lmax, f);
   }
-  atomicMin(&minmax[0], __float_as_uint(lmin));
-  atomicMax(&minmax[1], __float_as_uint(lmax));
+  block_minmax_atomic(lmin, lmax, minmax);
 }
 
 // dist (16.16 fixed) -> float32 [-> min-max normalised] -> padded image of the problem dtype
@@ -595,11 +623,12 @@ hipError_t launch_chamfer(const uint8_t *mask, int H, int W, int *G, int *scratc
       *carry_up = scratch + 3 * (size_t)S * W;
   hipLaunchKernelGGL(ea_column_local_kernel, dim3((W + 63) / 64, S), dim3(64), 0, s, mask, H, W, G, end_dn, end_up, minmax);
   hipLaunchKernelGGL(ea_column_carry_kernel, dim3((W + 63) / 64), dim3(64), 0, s, end_dn, end_up, H, W, S, carry_dn, carry_up);
+  const int row_threads = std::min(1024, std::max(256, ((W + 63) / 64) * 64));
   if (dist_f32)
-    hipLaunchKernelGGL(ea_edt_row_kernel, dim3(H), dim3(256), (size_t)W * sizeof(int), s, G, carry_dn, carry_up, H, W,
+    hipLaunchKernelGGL(ea_edt_row_kernel, dim3(H), dim3(row_threads), (size_t)W * sizeof(int), s, G, carry_dn, carry_up, H, W,
                        dist_f32, minmax);
   else
-    hipLaunchKernelGGL(ea_chamfer_row_kernel, dim3(H), dim3(256), (size_t)W * sizeof(int), s, G, carry_dn, carry_up, H, W,
+    hipLaunchKernelGGL(ea_chamfer_row_kernel, dim3(H), dim3(row_threads), (size_t)W * sizeof(int), s, G, carry_dn, carry_up, H, W,
                        dist_fix, minmax);
   return hipGetLastError();
 }
