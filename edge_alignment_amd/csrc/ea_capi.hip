@@ -121,6 +121,10 @@ struct ea_problem {
   // scratch for the frame pre-processing kernels (grown on demand, reused across frames)
   unsigned char *ws = nullptr;
   size_t ws_bytes = 0;
+  // what the last producer call left in the workspace: 1 = set_now_frame (Laplacian strength), 2 = set_now_frame_canny
+  // (edge map, no mask), 0 = nothing reusable; with the frame's extent.  The tracker extracts the same frame's edge
+  // points from it instead of uploading and filtering the frame a second time.
+  int ws_now_kind = 0, ws_now_h = 0, ws_now_w = 0;
 };
 
 struct ea_batch {
@@ -1301,6 +1305,9 @@ extern "C" int ea_solve_pyramid(ea_problem *const *levels, int nlevels, const ea
   return EA_OK;
 }
 
+static int ref_points_from_last_now(ea_problem *p, int kind, const uint16_t *depth, int height, int width, double z_scaling,
+                                    int threshold);  // (with the frame producers below)
+
 // ---- frame-to-frame driver (the reference aligns one stored pair, src/ea.cpp:155-200) -------------
 // Every pushed frame is aligned against the previous one: its DT image is produced, the previous frame's edge points
 // are solved against it starting from the last relative pose (constant-velocity prior), then the new frame's edge
@@ -1360,8 +1367,12 @@ extern "C" int ea_tracker_push_frame(ea_tracker *tr, const uint8_t *bgr, const u
   }
   std::memcpy(q_rel, tr->q, sizeof(tr->q));
   std::memcpy(t_rel, tr->t, sizeof(tr->t));
-  rc = tr->flavour == 0 ? ea_problem_set_ref_frame(tr->p, bgr, depth, height, width, z_scaling, 35)
-                        : ea_problem_set_ref_frame_canny(tr->p, bgr, depth, height, width, z_scaling, 30, 90);
+  // the frame's edge strength / edge map is still in the workspace when it has just been the "now" frame
+  if (!(z_scaling > 0.0)) return fail(EA_ERR_INVALID_ARG, "z_scaling must be > 0");
+  rc = ref_points_from_last_now(tr->p, tr->flavour == 0 ? 1 : 2, depth, height, width, z_scaling, tr->flavour == 0 ? 35 : 0);
+  if (rc == EA_ERR_STATE)
+    rc = tr->flavour == 0 ? ea_problem_set_ref_frame(tr->p, bgr, depth, height, width, z_scaling, 35)
+                          : ea_problem_set_ref_frame_canny(tr->p, bgr, depth, height, width, z_scaling, 30, 90);
   if (rc != EA_OK) return rc;
   tr->frames += 1;
   return EA_OK;
@@ -1408,6 +1419,7 @@ struct WsCarver {
 }  // namespace
 
 static int ensure_ws(ea_problem *p, size_t bytes) {
+  p->ws_now_kind = 0;  // every producer starts by calling this: whatever the workspace held is about to be overwritten
   if (p->ws_bytes >= bytes) return EA_OK;
   if (p->ws) { (void)hipFree(p->ws); p->ws = nullptr; p->ws_bytes = 0; }
   HIPCHK(hipMalloc(&p->ws, bytes));
@@ -1455,6 +1467,51 @@ static int ref_frame_impl(ea_problem *p, const uint8_t *bgr, const uint8_t *mask
   if (rc != EA_OK) return rc;
   if (total > 0) {
     HIPCHK(launch_edge_scatter(p->dtype, d_lap, d_depth, height, width, threshold, d_counts, p->cam.fx, p->cam.fy, p->cam.cx,
+                               p->cam.cy, z_scaling, p->d_x, p->d_y, p->d_z, total, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+  }
+  p->n = total;
+  return EA_OK;
+}
+
+// Edge points of the frame the last set_now_frame[_canny] call processed, from what that call left in the workspace
+// (Laplacian strength / Canny edge map): only the depth image goes up, no second upload or filtering of the colour
+// frame.  Same thresholds, same compaction and back-projection as ea_problem_set_ref_frame[_canny] => the same points.
+// Returns EA_ERR_STATE when the workspace does not hold that frame (the caller then takes the full path).
+static int ref_points_from_last_now(ea_problem *p, int kind, const uint16_t *depth, int height, int width, double z_scaling,
+                                    int threshold) {
+  if (p->ws_now_kind != kind || p->ws_now_h != height || p->ws_now_w != width || (int64_t)height * width < 4096)
+    return EA_ERR_STATE;
+  HIPCHK(hipSetDevice(p->device));
+  const size_t np = (size_t)height * width;
+  // the carve of the producer that ran, to find its buffers again
+  WsCarver ws{p->ws};
+  uint8_t *d_bgr = ws.take<uint8_t>(np * 3);
+  uint8_t *d_gray = ws.take<uint8_t>(np);
+  uint8_t *d_edges;
+  if (kind == 1) {
+    d_edges = ws.take<uint8_t>(np);  // d_lap
+  } else {
+    (void)ws.take<int>(np);      // magnitudes
+    (void)ws.take<uint8_t>(np);  // direction classes
+    (void)ws.take<uint8_t>(np);  // labels
+    d_edges = ws.take<uint8_t>(np);
+  }
+  // the colour frame and its gray version are not needed any more: depth and the block counts take their place
+  uint16_t *d_depth = reinterpret_cast<uint16_t *>(d_bgr);
+  const int nblocks = (int)((np + 1023) / 1024);
+  int *d_counts = reinterpret_cast<int *>(d_gray);
+  int *d_total = d_counts + nblocks;
+  p->ws_now_kind = 0;
+  HIPCHK(hipMemcpyAsync(d_depth, depth, np * 2, hipMemcpyHostToDevice, nullptr));
+  HIPCHK(launch_edge_count_scan(d_edges, d_depth, height, width, threshold, d_counts, d_total, nullptr));
+  int total = 0;
+  HIPCHK(hipMemcpy(&total, d_total, sizeof(int), hipMemcpyDeviceToHost));
+  p->version++;
+  int rc = reserve_points(p, total);
+  if (rc != EA_OK) return rc;
+  if (total > 0) {
+    HIPCHK(launch_edge_scatter(p->dtype, d_edges, d_depth, height, width, threshold, d_counts, p->cam.fx, p->cam.fy, p->cam.cx,
                                p->cam.cy, z_scaling, p->d_x, p->d_y, p->d_z, total, nullptr));
     HIPCHK(hipDeviceSynchronize());
   }
@@ -1600,6 +1657,7 @@ static int now_frame_canny(ea_problem *p, const uint8_t *bgr, const uint8_t *mas
   if (edges_out) HIPCHK(hipMemcpy(edges_out, d_edges, np, hipMemcpyDeviceToHost));
   if (chamfer_fix_out) HIPCHK(hipMemcpy(chamfer_fix_out, d_dist, np * 4, hipMemcpyDeviceToHost));
   if (dt_out) HIPCHK(hipMemcpy(dt_out, d_plain, np * 4, hipMemcpyDeviceToHost));
+  if (!mask) { p->ws_now_kind = 2; p->ws_now_h = height; p->ws_now_w = width; }
   return EA_OK;
 }
 
@@ -1715,7 +1773,9 @@ extern "C" int ea_problem_set_now_frame(ea_problem *p, const uint8_t *bgr, int h
   WsCarver ws{p->ws};
   uint8_t *d_bgr = ws.take<uint8_t>((size_t)height * width * 3);
   HIPCHK(hipMemcpyAsync(d_bgr, bgr, (size_t)height * width * 3, hipMemcpyHostToDevice, nullptr));
-  return run_dt(p, ws, d_bgr, height, width, threshold, median, normalize, nullptr, nullptr, nullptr, nullptr);
+  rc = run_dt(p, ws, d_bgr, height, width, threshold, median, normalize, nullptr, nullptr, nullptr, nullptr);
+  if (rc == EA_OK) { p->ws_now_kind = 1; p->ws_now_h = height; p->ws_now_w = width; }
+  return rc;
 }
 
 // stages of the DT producer for parity checks: any output may be NULL
