@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libea_hip.so")
+LIB_PATH = os.environ.get("EA_HIP_LIB") or os.path.join(_HERE, "lib", "libea_hip.so")  # EA_HIP_LIB: A/B against another build
 
 EA_F64, EA_F32 = 0, 1
 LOSS_TRIVIAL, LOSS_CAUCHY, LOSS_HUBER = 0, 1, 2

@@ -20,7 +20,7 @@
 namespace ea {
 hipError_t launch_eval_fused(int dtype, int ppt, int nt, int variant, const ProblemDesc *probs, int nterms, int chunk,
                              int max_chunks, int xcd_remap, const PoseState *poses, double *partials,
-                             int lds_bytes, int terms_are_groups, hipStream_t stream);
+                             int lds_bytes, int terms_are_groups, int buffer_loads, hipStream_t stream);
 hipError_t launch_eval_points(int dtype, const ProblemDesc *probs, int problem, int n, const PoseState *poses,
                               double *r_out, double *J_out, int corrected, hipStream_t stream);
 hipError_t launch_reduce(const GroupDesc *groups, int count, const double *partials, EvalOut *out,
@@ -169,6 +169,7 @@ struct ea_batch {
   // tuning (-1 = heuristic)
   int t_lds_bytes = -1, t_ppt = -1, t_use_lds = -1, t_xcd = -1, t_nt = -1, t_streams = -1, t_variant = 0;
   int ppt = 1, nt = 256, lds_bytes = 0, xcd_remap = 1;
+  int t_buf = -1, buffer_loads = 0;  // raw-buffer addressing of the DT image and the points (needs a < 2 GiB image)
   std::vector<ea_batch *> parts;  // sub-batches of the concurrent solve (ea_batch_solve)
   bool built = false;
 };
@@ -581,6 +582,7 @@ static void fill_desc(const ea_problem *p, ProblemDesc &d) {
   d.fx = p->cam.fx; d.fy = p->cam.fy; d.cx = p->cam.cx; d.cy = p->cam.cy;
   d.loss_a = p->loss_a; d.z_guard = p->z_guard; d.z_eps = p->z_eps;
   d.fxf = (float)d.fx; d.fyf = (float)d.fy; d.cxf = (float)d.cx; d.cyf = (float)d.cy;
+  d.loss_inv_b = 1.0 / (d.loss_a * d.loss_a); d.loss_inv_bf = (float)d.loss_inv_b;
   d.loss_af = (float)d.loss_a; d.z_guardf = (float)d.z_guard; d.z_epsf = (float)d.z_eps;
   d.loss_kind = p->loss_kind; d.rot_transposed = p->rot_transposed;
   d.variant = p->variant;
@@ -607,6 +609,7 @@ static int batch_build(ea_batch *b) {
   }
   (void)sig;
   if (!dirty) return EA_OK;
+  b->built = false;  // until the last allocation and upload below has succeeded
   HIPCHK(hipSetDevice(b->device));
   // terms of a problem follow it; all share its pose
   std::vector<const ea_problem *> terms;
@@ -650,6 +653,11 @@ static int batch_build(ea_batch *b) {
   if (nt == 1024 && b->dtype == EA_F64) ppt = 1;  // 128-VGPR budget at 16 waves/CU
   if (b->dtype == EA_F64 && ppt > 2) ppt = 2;
   if (any_variant) { nt = 256; ppt = std::min(ppt, 2); }  // the variant kernel is built for this shape only
+  // raw-buffer addressing (32-bit byte offsets into the image): on unless an image reaches 2 GiB
+  int buffer_loads = b->t_buf >= 0 ? (b->t_buf ? 1 : 0) : 1;
+  for (const ea_problem *p : terms)
+    if ((size_t)p->pitch * (size_t)(p->H + 2 * kImagePad) * (b->dtype == EA_F32 ? 4 : 8) >= ((size_t)1 << 31)) buffer_loads = 0;
+  b->buffer_loads = buffer_loads;
   b->ppt = ppt;
   b->nt = nt;
   const int64_t chunk = (int64_t)nt * ppt;
@@ -671,11 +679,6 @@ static int batch_build(ea_batch *b) {
     if (k == 0 || term_group[k - 1] != term_group[k]) { g.tile_begin = d.tile_begin; g.term_begin = (int)k; }
     g.tile_end = d.tile_end;
     g.term_end = (int)k + 1;
-  }
-  for (size_t i = 0; i < b->probs.size(); ++i) {
-    uint64_t v = b->probs[i]->version;
-    for (ea_problem *tm : b->probs[i]->terms) v = v * 1000003u + tm->version + 17;
-    b->versions[i] = v;
   }
   b->nterms = (int)terms.size();
   b->ntiles = rows;
@@ -718,6 +721,13 @@ static int batch_build(ea_batch *b) {
   if (lds > 61440) lds = 61440;
   b->lds_bytes = (use_lds && !any_variant) ? lds : 0;
   b->xcd_remap = b->t_xcd < 0 ? 1 : (b->t_xcd ? 1 : 0);
+  // only now is the batch consistent with its problems: a failure above leaves it dirty, so the next call rebuilds
+  // instead of launching on freed or missing buffers
+  for (size_t i = 0; i < b->probs.size(); ++i) {
+    uint64_t v = b->probs[i]->version;
+    for (ea_problem *tm : b->probs[i]->terms) v = v * 1000003u + tm->version + 17;
+    b->versions[i] = v;
+  }
   b->built = true;
   return EA_OK;
 }
@@ -729,7 +739,8 @@ static void host_pose_state(const ea_problem *p, const double *q, const double *
 
 static int batch_launch_eval(ea_batch *b) {
   HIPCHK(launch_eval_fused(b->dtype, b->ppt, b->nt, b->any_variant, b->d_probs, b->nterms, b->chunk, b->max_chunks,
-                           b->xcd_remap, b->d_poses, b->d_partials, b->lds_bytes, b->terms_are_groups, b->stream));
+                           b->xcd_remap, b->d_poses, b->d_partials, b->lds_bytes, b->terms_are_groups, b->buffer_loads,
+                           b->stream));
   return EA_OK;
 }
 
@@ -974,9 +985,9 @@ extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, 
       ea_batch *c = b->parts[(size_t)k];
       const int use_lds = b->lds_bytes > 0 ? 1 : 0;
       if (c->t_lds_bytes != b->t_lds_bytes || c->t_ppt != b->ppt || c->t_use_lds != use_lds || c->t_xcd != b->xcd_remap ||
-          c->t_nt != b->nt || c->t_variant != b->any_variant) {
+          c->t_nt != b->nt || c->t_variant != b->any_variant || c->t_buf != b->buffer_loads) {
         c->t_lds_bytes = b->t_lds_bytes; c->t_ppt = b->ppt; c->t_use_lds = use_lds; c->t_xcd = b->xcd_remap; c->t_nt = b->nt;
-        c->t_variant = b->any_variant;
+        c->t_variant = b->any_variant; c->t_buf = b->buffer_loads;
         c->built = false;
       }
       runs[(size_t)k].b = c;
@@ -1119,6 +1130,7 @@ extern "C" int ea_batch_set_tuning(ea_batch *b, const char *key, int value) {
   else if (k == "use_lds") b->t_use_lds = value;
   else if (k == "xcd_remap") b->t_xcd = value;
   else if (k == "threads") b->t_nt = value;
+  else if (k == "buffer_loads") b->t_buf = value;
   else if (k == "solve_streams") { b->t_streams = value; return EA_OK; }
   else return fail(EA_ERR_INVALID_ARG, "unknown tuning key: " + k);
   b->built = false;
@@ -1134,6 +1146,7 @@ extern "C" int ea_batch_get_info(const ea_batch *b, const char *key, int64_t *va
   else if (k == "xcd_remap") *value = b->xcd_remap;
   else if (k == "chunk") *value = b->chunk;
   else if (k == "threads") *value = b->nt;
+  else if (k == "buffer_loads") *value = b->buffer_loads;
   else if (k == "num_points") { int64_t s = 0; for (auto *p : b->probs) s += p->n; *value = s; }
   else return fail(EA_ERR_INVALID_ARG, "unknown info key: " + k);
   return EA_OK;

@@ -91,7 +91,32 @@ template <> __device__ __forceinline__ double t_rcp<double>(double x) {
 template <typename T> __device__ __forceinline__ T t_log(T x);
 // v_log_f32 is log2 and needs no denormal pre-scaling here: its only caller passes 1 + s / a^2 >= 1
 template <> __device__ __forceinline__ float t_log<float>(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
-template <> __device__ __forceinline__ double t_log<double>(double x) { return log(x); }
+// fp64 log for the Cauchy loss, argument 1 + s / a^2 in [1, inf): frexp to m in [sqrt(1/2), sqrt(2)), then
+// log m = 2 atanh z, z = (m - 1) / (m + 1), |z| <= 0.1716, as the odd series to z^21 (next term < 1e-18 relative).
+// ~33 instructions and ~2 ulp, against ~110 for libm's log (which was a fifth of the fp64 kernel's vector work).
+template <> __device__ __forceinline__ double t_log<double>(double x) {
+  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_exp(x);
+  const bool lo = m < 0.70710678118654752440;
+  m = __builtin_amdgcn_ldexp(m, lo ? 1 : 0);
+  e -= lo ? 1 : 0;
+  const double z = (m - 1.0) * t_rcp<double>(m + 1.0);
+  const double z2 = z * z;
+  double p = 2.0 / 21.0;
+  p = __builtin_fma(p, z2, 2.0 / 19.0);
+  p = __builtin_fma(p, z2, 2.0 / 17.0);
+  p = __builtin_fma(p, z2, 2.0 / 15.0);
+  p = __builtin_fma(p, z2, 2.0 / 13.0);
+  p = __builtin_fma(p, z2, 2.0 / 11.0);
+  p = __builtin_fma(p, z2, 2.0 / 9.0);
+  p = __builtin_fma(p, z2, 2.0 / 7.0);
+  p = __builtin_fma(p, z2, 2.0 / 5.0);
+  p = __builtin_fma(p, z2, 2.0 / 3.0);
+  const double lm = __builtin_fma(z * z2, p, z + z);
+  const double ef = (double)e;
+  // ln 2 split so that e * hi is exact for |e| < 2^11
+  return __builtin_fma(ef, 0.693147180369123816490, __builtin_fma(ef, 1.90821492927058770002e-10, lm));
+}
 
 template <typename T> __device__ __forceinline__ T t_sqrt(T x);
 template <> __device__ __forceinline__ float t_sqrt<float>(float x) { return __builtin_amdgcn_sqrtf(x); }
@@ -126,6 +151,7 @@ template <> struct Uni<double> {
   static __device__ __forceinline__ double cx(const ProblemDesc &pd) { return pd.cx; }
   static __device__ __forceinline__ double cy(const ProblemDesc &pd) { return pd.cy; }
   static __device__ __forceinline__ double loss_a(const ProblemDesc &pd) { return pd.loss_a; }
+  static __device__ __forceinline__ double loss_inv_b(const ProblemDesc &pd) { return pd.loss_inv_b; }
   static __device__ __forceinline__ double z_guard(const ProblemDesc &pd) { return pd.z_guard; }
   static __device__ __forceinline__ double z_eps(const ProblemDesc &pd) { return pd.z_eps; }
   static __device__ __forceinline__ const double *dist(const ProblemDesc &pd) { return pd.dist; }
@@ -143,6 +169,7 @@ template <> struct Uni<float> {
   static __device__ __forceinline__ float cx(const ProblemDesc &pd) { return pd.cxf; }
   static __device__ __forceinline__ float cy(const ProblemDesc &pd) { return pd.cyf; }
   static __device__ __forceinline__ float loss_a(const ProblemDesc &pd) { return pd.loss_af; }
+  static __device__ __forceinline__ float loss_inv_b(const ProblemDesc &pd) { return pd.loss_inv_bf; }
   static __device__ __forceinline__ float z_guard(const ProblemDesc &pd) { return pd.z_guardf; }
   static __device__ __forceinline__ float z_eps(const ProblemDesc &pd) { return pd.z_epsf; }
   static __device__ __forceinline__ const float *dist(const ProblemDesc &pd) { return pd.distf; }
@@ -156,6 +183,7 @@ template <> struct Uni<float> {
 template <typename T>
 struct Proj {
   T bx, by, iz;    // warped point (x, y) and 1 / (b_z + z_eps)
+  T fxz, fyz;      // fx * iz, fy * iz
   T cx_, cy_, cz_; // R a  (= b - t), for the unit-quaternion Jacobian
   T fu, fv;        // fractional parts of (u, v)
   int iu, iv;      // floor(u), floor(v), saturated to [-2, W] / [-2, H]
@@ -175,13 +203,16 @@ __device__ __forceinline__ void project_point(const ProblemDesc &pd, const PoseS
   // ref: utils.h:70-73 — `return false` inside (-0.01, 0.01)
   const bool bad = (zg > T(0)) && (bz < zg) && (bz > -zg);
   const T iz = t_rcp<T>(bz + Uni<T>::z_eps(pd));
-  const T u = t_fma<T>(Uni<T>::fx(pd) * bx, iz, Uni<T>::cx(pd));
-  const T v = t_fma<T>(Uni<T>::fy(pd) * by, iz, Uni<T>::cy(pd));
+  // fx / b_z and fy / b_z serve the projection here and the gradient in jacobian_row
+  const T fxz = Uni<T>::fx(pd) * iz, fyz = Uni<T>::fy(pd) * iz;
+  const T u = t_fma<T>(fxz, bx, Uni<T>::cx(pd));
+  const T v = t_fma<T>(fyz, by, Uni<T>::cy(pd));
   // Texel index saturates: beyond [-2, W] x [-2, H] every tap is the replicated border texel.
   // The fraction stays the true one (Ceres: r - int(floor(r))): with equal taps the spline is
   // constant only while the weights stay O(1).
   const T uf = floor(u), vf = floor(v);
   o.bx = bx; o.by = by; o.iz = iz;
+  o.fxz = fxz; o.fyz = fyz;
   o.cx_ = cxr; o.cy_ = cyr; o.cz_ = czr;
   o.fu = u - uf;
   o.fv = v - vf;
@@ -320,10 +351,10 @@ __device__ __forceinline__ void bicubic(T fu, T fv, RowFn row, T &f, T &Fu, T &F
 
 // rho(s), rho'(s) — ceres loss_function.cc
 template <typename T>
-__device__ __forceinline__ void loss_eval(int kind, T a, T s, T &rho, T &w) {
+__device__ __forceinline__ void loss_eval(int kind, T a, T inv_b, T s, T &rho, T &w) {
   if (kind == 1) {  // Cauchy
     const T b = a * a;
-    const T sum = t_fma<T>(s, t_rcp<T>(b), T(1));
+    const T sum = t_fma<T>(s, inv_b, T(1));
     w = t_rcp<T>(sum);
     rho = b * t_log<T>(sum);
   } else if (kind == 2) {  // Huber
@@ -344,8 +375,8 @@ __device__ __forceinline__ void loss_eval(int kind, T a, T s, T &rho, T &w) {
 template <typename T>
 __device__ __forceinline__ void jacobian_row(const ProblemDesc &pd, const PoseState &ps,
                                              const Proj<T> &pr, T x, T y, T z, T Fu, T Fv, T J[6]) {
-  const T gx = Fu * Uni<T>::fx(pd) * pr.iz;
-  const T gy = Fv * Uni<T>::fy(pd) * pr.iz;
+  const T gx = Fu * pr.fxz;
+  const T gy = Fv * pr.fyz;
   const T gz = -t_fma<T>(gx, pr.bx, gy * pr.by) * pr.iz;
   if (ps.unit_q) {
     // d b / d delta = -2 [R a]x  =>  J_delta = 2 (R a) x g
@@ -498,21 +529,32 @@ __device__ __forceinline__ void wave_reduce32_f32(float (&v)[32]) {
 // (pairing L ^ 16).  The three levels inside a row stay on DPP (row_mirror, row_half_mirror, quad_perm), the last
 // pairing (L ^ 1) is a plain add.  ~125 instructions instead of ~220.
 // On return lanes with even L hold in v[0] the wave total of slot  16 b5 + 8 b4 + 4 b3 + 2 b2 + b1  (b_k = bit k of L).
-__device__ __forceinline__ void swap32_f64(double &a, double &b) {
-  unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
-  unsigned alo = (unsigned)ua, ahi = (unsigned)(ua >> 32), blo = (unsigned)ub, bhi = (unsigned)(ub >> 32);
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 0"
-               : "+v"(alo), "+v"(ahi), "+v"(blo), "+v"(bhi));
-  a = __builtin_bit_cast(double, ((unsigned long long)ahi << 32) | alo);
-  b = __builtin_bit_cast(double, ((unsigned long long)bhi << 32) | blo);
-}
-__device__ __forceinline__ void swap16_f64(double &a, double &b) {
-  unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
-  unsigned alo = (unsigned)ua, ahi = (unsigned)(ua >> 32), blo = (unsigned)ub, bhi = (unsigned)(ub >> 32);
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 0"
-               : "+v"(alo), "+v"(ahi), "+v"(blo), "+v"(bhi));
-  a = __builtin_bit_cast(double, ((unsigned long long)ahi << 32) | alo);
-  b = __builtin_bit_cast(double, ((unsigned long long)bhi << 32) | blo);
+// four pairs of doubles per asm statement: one pair of wait-state s_nops (VALU write -> permlane-swap read, swap
+// write -> VALU read; hipcc cannot see inside the asm) per eight swaps instead of per two
+#define EA_SWAP8(OP)                                                                                        \
+  "s_nop 1\n\t" OP " %0, %8\n\t" OP " %1, %9\n\t" OP " %2, %10\n\t" OP " %3, %11\n\t" OP " %4, %12\n\t" \
+  OP " %5, %13\n\t" OP " %6, %14\n\t" OP " %7, %15\n\ts_nop 0"
+template <int W>  // W = 32: v_permlane32_swap, 16: v_permlane16_swap; a[k] <-> b[k] for k = 0..3 (both dwords)
+__device__ __forceinline__ void swap_f64x4(double *a, double *b) {
+  unsigned al[4], ah[4], bl[4], bh[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned long long ua = __builtin_bit_cast(unsigned long long, a[k]), ub = __builtin_bit_cast(unsigned long long, b[k]);
+    al[k] = (unsigned)ua; ah[k] = (unsigned)(ua >> 32); bl[k] = (unsigned)ub; bh[k] = (unsigned)(ub >> 32);
+  }
+  if constexpr (W == 32)
+    asm volatile(EA_SWAP8("v_permlane32_swap_b32")
+                 : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]), "+v"(al[3]), "+v"(ah[3]),
+                   "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1]), "+v"(bl[2]), "+v"(bh[2]), "+v"(bl[3]), "+v"(bh[3]));
+  else
+    asm volatile(EA_SWAP8("v_permlane16_swap_b32")
+                 : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]), "+v"(al[3]), "+v"(ah[3]),
+                   "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1]), "+v"(bl[2]), "+v"(bh[2]), "+v"(bl[3]), "+v"(bh[3]));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    a[k] = __builtin_bit_cast(double, ((unsigned long long)ah[k] << 32) | al[k]);
+    b[k] = __builtin_bit_cast(double, ((unsigned long long)bh[k] << 32) | bl[k]);
+  }
 }
 
 __device__ __forceinline__ int swap_slot_f64(int lane) {
@@ -521,14 +563,16 @@ __device__ __forceinline__ int swap_slot_f64(int lane) {
 
 __device__ __forceinline__ void wave_reduce32_f64(double (&v)[32], int lane) {
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {  // L ^ 32
-    swap32_f64(v[i], v[i + 16]);
-    v[i] += v[i + 16];
+  for (int i = 0; i < 16; i += 4) {  // L ^ 32
+    swap_f64x4<32>(v + i, v + i + 16);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[i + k] += v[i + k + 16];
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {  // L ^ 16
-    swap16_f64(v[i], v[i + 8]);
-    v[i] += v[i + 8];
+  for (int i = 0; i < 8; i += 4) {  // L ^ 16
+    swap_f64x4<16>(v + i, v + i + 8);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[i + k] += v[i + k + 8];
   }
   // inside a 16-lane row: L ^ 15 (bit 3 picks the half kept), L ^ 7 (bit 2), L ^ 2 (bit 1)
   {
@@ -603,6 +647,46 @@ __device__ __forceinline__ Row4<T> load_row4(GPtr<T> p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// raw-buffer addressing (gfx950 buffer instructions): a lane's address is ONE 32-bit byte offset and the four
+// stencil rows of a point differ only in the instruction's SGPR offset (l * pitch bytes) -- no 64-bit address
+// arithmetic per row (ten v_lshl_add_u64 per point in the flat-address form).  Requires the padded image to be
+// smaller than 2 GiB (checked on the host, which falls back to the flat-address kernels otherwise).
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_raw_buffer(const void *base, unsigned bytes) {
+  // gfx950 raw buffer: stride 0, no swizzle, DATA_FORMAT = 32 (dword 3 = 0x00020000)
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+
+template <typename T> __device__ __forceinline__ T buf_load_elem(__amdgpu_buffer_rsrc_t r, int voff);
+template <> __device__ __forceinline__ float buf_load_elem<float>(__amdgpu_buffer_rsrc_t r, int voff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+}
+template <> __device__ __forceinline__ double buf_load_elem<double>(__amdgpu_buffer_rsrc_t r, int voff) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0));
+}
+
+template <typename T> __device__ __forceinline__ Row4<T> buf_load_row4(__amdgpu_buffer_rsrc_t r, int voff, int soff);
+template <> __device__ __forceinline__ Row4<float> buf_load_row4<float>(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  // (whole-vector bit casts: __builtin_bit_cast of a single element of the loaded vector, `v.x`, comes out of
+  // ROCm 7.2's hipcc as four reads of the same dword)
+  const f32x4_t v = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+  Row4<float> o;
+  o.p0 = v[0]; o.p1 = v[1]; o.p2 = v[2]; o.p3 = v[3];
+  return o;
+}
+template <> __device__ __forceinline__ Row4<double> buf_load_row4<double>(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  const f64x2_t a = __builtin_bit_cast(f64x2_t, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+  const f64x2_t b = __builtin_bit_cast(f64x2_t, __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16, soff, 0));
+  Row4<double> o;
+  o.p0 = a[0]; o.p1 = a[1]; o.p2 = b[0]; o.p3 = b[1];
+  return o;
+}
+
+// ------------------------------------------------------------------------------------------------
 // fused evaluation kernel: residual + Jacobian + loss + JtJ/Jtr/cost partials, one row per workgroup
 //
 // grid = (8 * ceil(chunks/8), problems).  Workgroup (c, p) owns points [c*chunk, (c+1)*chunk) of
@@ -616,7 +700,7 @@ constexpr int kHdrBytes = kRedBytes + kMaxWaves * 16;  // + bbox words, keeps th
 // One workgroup's share of an evaluation: NT lanes x PPT points -> the workgroup's partial row.
 // X/Y/Z hold the lane's points (lanes past `count` carry a copy of the chunk's last point); the return value is
 // slot `my_slot` of the row (0 when my_slot < 0).  `ps` may live in global memory (scalar loads) or LDS.
-template <typename T, int PPT, int MODE, int NT, bool VAR>
+template <typename T, int PPT, int MODE, int NT, bool VAR, bool BUF>
 __device__ __forceinline__ double fused_chunk(const ProblemDesc &pd, const PoseState &ps, const T (&X)[PPT],
                                               const T (&Y)[PPT], const T (&Z)[PPT], int count, double *s_red,
                                               int *s_box, T *s_tile, int lds_texels, int my_slot) {
@@ -627,8 +711,10 @@ __device__ __forceinline__ double fused_chunk(const ProblemDesc &pd, const PoseS
   const int wave = tid >> 6;
   const int pitch = pd.pitch;
   const GPtr<T> gimg = (GPtr<T>)(static_cast<const T *>(pd.dt) + (size_t)kImagePad * (size_t)pitch + kImagePad);
+  const __amdgpu_buffer_rsrc_t rimg =
+      make_raw_buffer(pd.dt, BUF ? (unsigned)pitch * (unsigned)(pd.H + 2 * kImagePad) * (unsigned)sizeof(T) : 0u);
   const int loss_kind = pd.loss_kind;
-  const T loss_a = Uni<T>::loss_a(pd);
+  const T loss_a = Uni<T>::loss_a(pd), loss_inv_b = Uni<T>::loss_inv_b(pd);
 
   T acc[28];
   int n_bad = 0;
@@ -653,6 +739,7 @@ __device__ __forceinline__ double fused_chunk(const ProblemDesc &pd, const PoseS
         pr[k].xdx = T(1); pr[k].xdy = T(0); pr[k].ydx = T(0); pr[k].ydy = T(1);
       } else {
         pr[k].bx = T(0); pr[k].by = T(0);
+        pr[k].fxz = T(0); pr[k].fyz = T(0);
       }
     }
     if (USE_LDS && valid[k]) {
@@ -710,6 +797,11 @@ __device__ __forceinline__ double fused_chunk(const ProblemDesc &pd, const PoseS
       const int stride = tw;
       bicubic<T>(pr[k].fu, pr[k].fv,
                  [&](int l) { return *reinterpret_cast<const Row4<T> *>(base + l * stride); }, f, Fu, Fv);
+    } else if constexpr (BUF) {
+      // byte offset of texel (iv - 1, iu - 1) in the padded image; iv, iu >= -2 keeps it non-negative
+      const int voff = ((pr[k].iv + (kImagePad - 1)) * pitch + (pr[k].iu + (kImagePad - 1))) * (int)sizeof(T);
+      bicubic<T>(pr[k].fu, pr[k].fv,
+                 [&](int l) { return buf_load_row4<T>(rimg, voff, l * pitch * (int)sizeof(T)); }, f, Fu, Fv);
     } else {
       const GPtr<T> base = gimg + ((ptrdiff_t)(pr[k].iv - 1) * pitch + (pr[k].iu - 1));
       bicubic<T>(pr[k].fu, pr[k].fv,
@@ -719,7 +811,7 @@ __device__ __forceinline__ double fused_chunk(const ProblemDesc &pd, const PoseS
     if constexpr (VAR) jacobian_row_var<T>(pd, ps, pr[k], Fu, Fv, J);
     else jacobian_row<T>(pd, ps, pr[k], X[k], Y[k], Z[k], Fu, Fv, J);
     T rho, w;
-    loss_eval<T>(loss_kind, loss_a, f * f, rho, w);
+    loss_eval<T>(loss_kind, loss_a, loss_inv_b, f * f, rho, w);
     w = valid[k] ? w : T(0);
     rho = valid[k] ? rho : T(0);
     const T wr = w * f;
@@ -769,7 +861,7 @@ __device__ __forceinline__ double fused_chunk(const ProblemDesc &pd, const PoseS
 
 // NT = workgroup size (256 or 1024).  1024 = one workgroup per CU: four times fewer partial rows
 // to fold afterwards at the same points-per-lane latency.
-template <typename T, int PPT, int MODE, int NT, bool VAR>
+template <typename T, int PPT, int MODE, int NT, bool VAR, bool BUF>
 __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
     const ProblemDesc *__restrict__ probs, const PoseState *__restrict__ poses,
     double *__restrict__ partials, int chunk, int chunks_per_xcd, int xcd_remap, int lds_texels,
@@ -802,17 +894,29 @@ __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
   const GPtr<T> pz = (GPtr<T>)(static_cast<const T *>(pd.z) + start);
   // coalesced point loads; lanes past the end of the chunk re-read its last point
   T X[PPT], Y[PPT], Z[PPT];
+  if constexpr (BUF) {
+    // the chunk's points as three raw buffers: one 32-bit offset per lane serves all three loads
+    const __amdgpu_buffer_rsrc_t rx = make_raw_buffer((const T *)px, (unsigned)count * (unsigned)sizeof(T));
+    const __amdgpu_buffer_rsrc_t ry = make_raw_buffer((const T *)py, (unsigned)count * (unsigned)sizeof(T));
+    const __amdgpu_buffer_rsrc_t rz = make_raw_buffer((const T *)pz, (unsigned)count * (unsigned)sizeof(T));
 #pragma unroll
-  for (int k = 0; k < PPT; ++k) {
-    const int j = tid + k * NT;
-    const int jj = min(j, count - 1);
-    X[k] = px[jj]; Y[k] = py[jj]; Z[k] = pz[jj];
+    for (int k = 0; k < PPT; ++k) {
+      const int poff = min(tid + k * NT, count - 1) * (int)sizeof(T);
+      X[k] = buf_load_elem<T>(rx, poff); Y[k] = buf_load_elem<T>(ry, poff); Z[k] = buf_load_elem<T>(rz, poff);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const int j = tid + k * NT;
+      const int jj = min(j, count - 1);
+      X[k] = px[jj]; Y[k] = py[jj]; Z[k] = pz[jj];
+    }
   }
 #ifdef EA_STAMPS
   asm volatile("" ::"v"(X[0]), "v"(Y[0]), "v"(Z[0]));
 #endif
   EA_STAMP(2);  // points arrived
-  const double sum = fused_chunk<T, PPT, MODE, NT, VAR>(pd, ps, X, Y, Z, count, s_red, s_box, s_tile, lds_texels,
+  const double sum = fused_chunk<T, PPT, MODE, NT, VAR, BUF>(pd, ps, X, Y, Z, count, s_red, s_box, s_tile, lds_texels,
                                                            tid < kAccSlots ? tid : -1);
   if (tid < kAccSlots) partials[(size_t)(pd.tile_begin + c) * kAccSlots + tid] = sum;
 #ifdef EA_STAMPS
@@ -853,7 +957,7 @@ __global__ __launch_bounds__(kBlockThreads) void ea_eval_points_kernel(
     T sc = T(1);
     if (corrected) {
       T rho, w;
-      loss_eval<T>(pd.loss_kind, Uni<T>::loss_a(pd), f * f, rho, w);
+      loss_eval<T>(pd.loss_kind, Uni<T>::loss_a(pd), Uni<T>::loss_inv_b(pd), f * f, rho, w);
       sc = t_sqrt<T>(w);
     }
     if (r_out) r_out[i] = (double)(sc * f);
@@ -879,7 +983,7 @@ __global__ __launch_bounds__(kBlockThreads) void ea_eval_points_kernel(
   T sc = T(1);
   if (corrected) {
     T rho, w;
-    loss_eval<T>(pd.loss_kind, Uni<T>::loss_a(pd), f * f, rho, w);
+    loss_eval<T>(pd.loss_kind, Uni<T>::loss_a(pd), Uni<T>::loss_inv_b(pd), f * f, rho, w);
     sc = t_sqrt<T>(w);
   }
   if (r_out) r_out[i] = (double)(sc * f);
@@ -1088,16 +1192,20 @@ __global__ void ea_pad_image_kernel(const T *__restrict__ src, int H, int W, T *
 
 hipError_t launch_eval_fused(int dtype, int ppt, int nt, int variant, const ProblemDesc *probs, int nterms, int chunk,
                              int max_chunks, int xcd_remap, const PoseState *poses, double *partials,
-                             int lds_bytes, int terms_are_groups, hipStream_t stream) {
+                             int lds_bytes, int terms_are_groups, int buffer_loads, hipStream_t stream) {
   if (nterms <= 0 || max_chunks <= 0) return hipSuccess;
   const int chunks_per_xcd = (max_chunks + 7) / 8;
   const dim3 grid(xcd_remap ? chunks_per_xcd * 8 : max_chunks, nterms);
   const int esz = dtype == 1 ? 4 : 8;
   const int lds_texels = lds_bytes > 0 ? lds_bytes / esz : 0;
   const size_t shmem = (size_t)kHdrBytes + (size_t)lds_texels * esz;
-#define EA_LAUNCH(T, P, L, N, V)                                                                \
-  hipLaunchKernelGGL((ea_eval_fused_kernel<T, P, L, N, V>), grid, dim3(N), shmem, stream, probs, \
+#define EA_LAUNCH_B(T, P, L, N, V, B)                                                              \
+  hipLaunchKernelGGL((ea_eval_fused_kernel<T, P, L, N, V, B>), grid, dim3(N), shmem, stream, probs, \
                      poses, partials, chunk, chunks_per_xcd, xcd_remap, lds_texels, terms_are_groups)
+#define EA_LAUNCH(T, P, L, N, V)                                                                   \
+  do {                                                                                             \
+    if (buffer_loads && (L) == 0) EA_LAUNCH_B(T, P, 0, N, V, true); else EA_LAUNCH_B(T, P, L, N, V, false); \
+  } while (0)
 #define EA_LAUNCH_L(T, P, N)                                                          \
   do {                                                                                \
     if (lds_texels > 0) EA_LAUNCH(T, P, 1, N, false); else EA_LAUNCH(T, P, 0, N, false); \
@@ -1117,6 +1225,7 @@ hipError_t launch_eval_fused(int dtype, int ppt, int nt, int variant, const Prob
   }
 #undef EA_LAUNCH_L
 #undef EA_LAUNCH
+#undef EA_LAUNCH_B
   return hipGetLastError();
 }
 

@@ -36,8 +36,10 @@ struct ProblemDesc {
   int32_t pitch;          // elements per padded row
   double fx, fy, cx, cy;
   double loss_a, z_guard, z_eps;
+  double loss_inv_b;             // 1 / loss_a^2 (uniform: formed once on the host, not per lane)
   float fxf, fyf, cxf, cyf;
   float loss_af, z_guardf, z_epsf;
+  float loss_inv_bf;
   int32_t loss_kind;
   int32_t rot_transposed;
   int32_t tile_begin, tile_end;  // this term's rows in the partial-sum array (one per workgroup)

@@ -45,5 +45,20 @@ def test_launch_shapes_at_chunk_boundaries(hip, oracle, dtype_name, tol):
                 slack = 100.0 if n <= 2 else 1.0  # a sum of one or two terms has nothing to average its rounding over
                 assert abs(g["cost"][0] - e["cost"]) <= slack * tol * abs(e["cost"]), where
                 assert _rel(g["JtJ"][0], e["JtJ"]) <= slack * tol and _rel(g["Jtr"][0], e["Jtr"]) <= slack * tol, where
+            # the flat-address form of the row loads (the fallback for images of 2 GiB and more; raw-buffer addressing
+            # is the default and was what ran above)
+            assert B.info("buffer_loads") == 1
+            B.set_tuning("use_lds", 0); B.set_tuning("buffer_loads", 0)
+            for nt in (256, 1024):
+                B.set_tuning("threads", nt)
+                for ppt in (1, 2, 4):
+                    B.set_tuning("points_per_thread", ppt)
+                    g = B.eval(q.reshape(1, 4), t.reshape(1, 3))
+                    where = (n, "flat", nt, ppt, loss)
+                    assert B.info("buffer_loads") == 0, where
+                    assert int(g["n_invalid"][0]) == int(e["n_invalid"]), where
+                    slack = 100.0 if n <= 2 else 1.0
+                    assert abs(g["cost"][0] - e["cost"]) <= slack * tol * abs(e["cost"]), where
+                    assert _rel(g["JtJ"][0], e["JtJ"]) <= slack * tol and _rel(g["Jtr"][0], e["Jtr"]) <= slack * tol, where
         finally:
             B.close(); P.close()
