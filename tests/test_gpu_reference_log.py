@@ -1,0 +1,67 @@
+"""The reference's only recorded solve (standalone/README.md:26-71) against the HIP path.
+
+The log: 1482 residual blocks (= ceil(44457 / 30): frame 1, stride 30, standalone_edge_align.cpp:267), CauchyLoss(1),
+identity start, LM defaults; 30 iterations, every step successful, CONVERGENCE on the function tolerance, cost
+8.743202 -> 0.5418352, final YPR = (-0.32, 1.52, 2.50) deg, t = (-0.01, 0.00, -0.05) m.  Its inputs are not stated; of
+the bundled frames only B = 5 lands on that pose (scripts/readme_log_sweep.py: B = 2, 3, 4 end 1-2 deg away), and no
+combination of B, edge threshold, median filter, blur, channel order and distance-transform mask reproduces the printed
+costs (closest initial cost with the shipped parameters: 9.4515; profiles/r02_readme_log_sweep.txt) -- the log predates the
+shipped pre-processing or OpenCV's differs from its restatement.  So the test pins what the log does pin: the block
+count, the step pattern and the pose to the digits it prints, here through the device pipeline end to end (raw frames ->
+GPU edge points and GPU distance transform -> device LM), and the device solve against the oracle's on the same inputs."""
+import os
+
+import numpy as np
+import pytest
+
+from edge_alignment_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+K = (525.0, 525.0, 319.5, 239.5)
+
+
+def _ypr_deg(q):
+    R = synth.quat_to_R(q)
+    return np.array([np.degrees(np.arctan2(R[1, 0], R[0, 0])),
+                     np.degrees(np.arctan2(-R[2, 0], np.hypot(R[2, 1], R[2, 2]))),
+                     np.degrees(np.arctan2(R[2, 1], R[2, 2]))])
+
+
+@pytest.mark.parametrize("dtype_name", ["EA_F64", "EA_F32"])
+def test_readme_log_through_the_device_pipeline(hip, oracle, dtype_name):
+    from oracle import preprocess_np as pp
+    G = os.path.join(ROOT, "tests", "golden", "rgbd")
+    imA = pp.load_rgb_as_bgr(os.path.join(G, "rgb_1.png"))
+    dA = pp.load_depth_u16(os.path.join(G, "depth_1.png"))
+    imB = pp.load_rgb_as_bgr(os.path.join(G, "rgb_5.png"))
+    dtype = getattr(hip, dtype_name)
+    # producers on the device (utils.cpp:201-281 get_aX, :38-83 get_distance_transform)
+    F = hip.Problem(*K, dtype=hip.EA_F64)
+    n = F.set_ref_frame(imA, dA, z_scaling=5000.0)
+    assert n == 44457                                   # README.md:34 through ceil(n / 30)
+    X = F.get_points()[::30].copy()                     # standalone_edge_align.cpp:267 `i += 30`
+    assert X.shape[0] == 1482                           # README.md:31-35 "Residual blocks 1482"
+    F.close()
+    P = hip.Problem(*K, dtype=dtype)
+    P.set_points(X)
+    P.set_now_frame(imB)
+    P.set_loss(hip.LOSS_CAUCHY, 1.0)                    # :272 new CauchyLoss(1.)
+    q, t, s = P.solve([1, 0, 0, 0], [0, 0, 0])          # :261-262 identity, :282-286 LM defaults
+    # the log's step pattern (README.md:53-55, :68)
+    assert s["termination"] == hip.CONVERGENCE and s["why"] == "function_tolerance"
+    assert s["num_unsuccessful_steps"] == 0
+    assert 20 <= s["num_successful_steps"] <= 35       # the log: 30
+    assert s["final_cost"] < 0.1 * s["initial_cost"]   # the log: 8.74 -> 0.54
+    # the pose, to the two decimals the log prints (README.md:70) plus the spread of the unreproducible pre-processing
+    assert np.abs(_ypr_deg(q) - np.array([-0.32, 1.52, 2.50])).max() < 0.15
+    assert np.abs(t - np.array([-0.01, 0.00, -0.05])).max() < 0.006
+    # and the same solve by the oracle on the device-produced inputs
+    O = oracle.OracleProblem(pp.grid_view_of_image(P.get_dt()), *K)
+    qo, to, so = O.solve(X, [1, 0, 0, 0], [0, 0, 0])
+    if dtype == hip.EA_F64:
+        assert s["num_iterations"] == so["num_iterations"]
+        assert synth.rotation_angle_between(q, qo) < 1e-7 and np.linalg.norm(t - to) < 1e-7
+    else:
+        assert synth.rotation_angle_between(q, qo) < 1e-4 and np.linalg.norm(t - to) < 1e-3  # north_star bar
+    P.close()
