@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EA_HIP_LIB") or os.path.join(_HERE, "lib", "libea_hip.so")  # EA_HIP_LIB: A/B against another build
 
 EA_F64, EA_F32 = 0, 1
+EA_OK, EA_ERR_INVALID_ARG, EA_ERR_HIP, EA_ERR_NO_DEVICE, EA_ERR_STATE, EA_ERR_ALLOC = 0, -1, -2, -3, -4, -5
 LOSS_TRIVIAL, LOSS_CAUCHY, LOSS_HUBER = 0, 1, 2
 CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
 STRATEGY_LM, STRATEGY_DOGLEG = 0, 1
@@ -28,8 +29,8 @@ EXPORTED = [
     "ea_problem_set_loss", "ea_problem_set_flavour", "ea_problem_num_points",
     "ea_eval", "ea_eval_points", "ea_cost", "ea_solve",
     "ea_batch_create", "ea_batch_destroy", "ea_batch_count", "ea_batch_eval", "ea_batch_solve",
-    "ea_solve_pyramid", "ea_solve_sharded", "ea_tracker_create", "ea_tracker_destroy", "ea_tracker_problem", "ea_tracker_push_frame",
-    "ea_batch_bench_eval", "ea_batch_bench_kernel", "ea_batch_bench_fold", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
+    "ea_solve_pyramid", "ea_solve_sharded", "ea_solve_sharded_device", "ea_tracker_create", "ea_tracker_destroy", "ea_tracker_problem", "ea_tracker_push_frame",
+    "ea_batch_bench_eval", "ea_batch_bench_steps", "ea_batch_bench_kernel", "ea_batch_bench_fold", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
     "ea_problem_set_ref_frame", "ea_problem_set_ref_frame_masked", "ea_problem_set_now_frame", "ea_problem_debug_now_frame",
     "ea_problem_set_ref_frame_canny", "ea_problem_set_now_frame_canny", "ea_problem_debug_now_frame_canny",
     "ea_problem_set_ref_frame_ros", "ea_problem_set_now_frame_ros", "ea_problem_debug_now_frame_ros",
@@ -45,6 +46,7 @@ class EAError(RuntimeError):
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_void_p)
+DEVICE_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)
 
 
 class Camera(C.Structure):
@@ -61,7 +63,8 @@ class Options(C.Structure):
                 ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
                 ("max_num_consecutive_invalid_steps", C.c_int),
                 ("jacobi_scaling", C.c_int), ("strategy", C.c_int),
-                ("minimizer_progress_to_stdout", C.c_int), ("iterations_per_sync", C.c_int)]
+                ("minimizer_progress_to_stdout", C.c_int), ("iterations_per_sync", C.c_int),
+                ("solve_timeout_ms", C.c_double)]
 
 
 class Summary(C.Structure):
@@ -119,9 +122,11 @@ def load():
     L.ea_batch_eval.argtypes = [vp, dp, dp, dp, dp, dp, i64p]
     L.ea_batch_solve.argtypes = [vp, C.POINTER(Options), dp, dp, C.POINTER(Summary)]
     L.ea_batch_bench_eval.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp, dp]
+    L.ea_batch_bench_steps.argtypes = [vp, C.c_int]
     L.ea_batch_bench_kernel.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp]
     L.ea_batch_bench_fold.argtypes = [vp, C.c_int, C.c_int, dp]
     L.ea_solve_sharded.argtypes = [vp, C.POINTER(Options), ALLREDUCE_FN, vp, dp, dp, C.POINTER(Summary)]
+    L.ea_solve_sharded_device.argtypes = [vp, C.POINTER(Options), DEVICE_ALLREDUCE_FN, vp, vp, dp, dp, C.POINTER(Summary)]
     L.ea_solve_pyramid.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Options), dp, dp, C.POINTER(Summary)]
     L.ea_batch_set_tuning.argtypes = [vp, C.c_char_p, C.c_int]
     L.ea_batch_get_info.argtypes = [vp, C.c_char_p, i64p]
@@ -359,6 +364,28 @@ class Problem:
         _check(load().ea_solve_sharded(self._h, C.byref(o), cb, None, _dp(q), _dp(t), C.byref(s)))
         return q, t, summary_to_dict(s)
 
+    def solve_sharded_device(self, q, t, enqueue_allreduce, device_sums_ptr, **opts):
+        """ea_solve_sharded_device: `device_sums_ptr` = address of 32 doubles of device memory the caller owns;
+        `enqueue_allreduce(stream_ptr)` must enqueue, on that HIP stream, the in-place sum of those 32 doubles over all
+        ranks and return without waiting (edge_alignment_amd.dist.make_device_allreduce)."""
+        q = _f64(q).reshape(4).copy()
+        t = _f64(t).reshape(3).copy()
+        o = default_options(**opts)
+        s = Summary()
+
+        def _cb(_buf, _count, stream, _user):
+            try:
+                enqueue_allreduce(stream or 0)
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = DEVICE_ALLREDUCE_FN(_cb)
+        _check(load().ea_solve_sharded_device(self._h, C.byref(o), cb, None, C.c_void_p(int(device_sums_ptr)), _dp(q), _dp(t),
+                                              C.byref(s)))
+        return q, t, summary_to_dict(s)
+
     def get_points(self):
         n = self.num_points
         xyz = np.zeros((n, 3))
@@ -510,6 +537,10 @@ class Batch:
         _check(load().ea_batch_bench_eval(self._h, _dp(q), _dp(t), warmup, steps, C.byref(ms_total),
                                           C.byref(ms_kernel) if kernel_pass else None))
         return ms_total.value, (ms_kernel.value if kernel_pass else None)
+
+    def bench_steps(self, steps):
+        """`steps` x (fused evaluation + fold) at the poses already on the device, then a stream sync: the timed region"""
+        _check(load().ea_batch_bench_steps(self._h, int(steps)))
 
     def bench_kernel(self, q, t, warmup, launches):
         """mean ms of the per-point kernel over `launches` back-to-back launches (one event pair)"""

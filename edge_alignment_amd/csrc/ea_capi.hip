@@ -15,6 +15,7 @@
 
 #include "../../include/ea_hip.h"
 #include "ea_lm.h"
+#include "ea_spin.h"
 #include "ea_types.h"
 
 namespace ea {
@@ -169,9 +170,14 @@ struct ea_batch {
   // tuning (-1 = heuristic)
   int t_lds_bytes = -1, t_ppt = -1, t_use_lds = -1, t_xcd = -1, t_nt = -1, t_streams = -1, t_variant = 0;
   int ppt = 1, nt = 256, lds_bytes = 0, xcd_remap = 1;
+  int t_test_stall_ms = 0;  // test hook: hold the stream on a host function for this long at the start of a solve
   int t_buf = -1, buffer_loads = 0;  // raw-buffer addressing of the DT image and the points (needs a < 2 GiB image)
   std::vector<ea_batch *> parts;  // sub-batches of the concurrent solve (ea_batch_solve)
   bool built = false;
+  bool needs_drain = false;     // a solve gave up on its deadline with launches still queued: synchronise before reuse
+  hipEvent_t round_done = nullptr;  // behind the last step kernel of a round of ea_solve_sharded_device
+  GroupDesc *d_one_row = nullptr;  // {0, 1, 0, 1}: "one partial row" for the step kernel of ea_solve_sharded_device
+  bool poses_uploaded = false;  // d_poses holds caller-supplied poses (ea_batch_bench_steps re-evaluates at them)
 };
 
 static int check_device(int device) {
@@ -221,6 +227,7 @@ extern "C" void ea_default_options(ea_options *o) {
   o->strategy = EA_STRATEGY_LM;
   o->minimizer_progress_to_stdout = 0;
   o->iterations_per_sync = 0;
+  o->solve_timeout_ms = 0.0;
 }
 
 // ---- problem ------------------------------------------------------------------------------------
@@ -491,6 +498,8 @@ extern "C" int ea_problem_set_flavour(ea_problem *p, double z_guard, double z_ep
 // ---- batch --------------------------------------------------------------------------------------
 
 static void batch_free_device(ea_batch *b) {
+  (void)hipFree(b->d_one_row); b->d_one_row = nullptr;
+  if (b->round_done) { (void)hipEventDestroy(b->round_done); b->round_done = nullptr; }
   (void)hipFree(b->d_probs); (void)hipFree(b->d_groups); (void)hipFree(b->d_lm_block); (void)hipFree(b->d_cold);
   (void)hipFree(b->d_partials); (void)hipFree(b->d_out);
   (void)hipHostFree(b->h_lm_block); (void)hipHostFree(b->h_out);
@@ -549,6 +558,11 @@ extern "C" int ea_batch_create(ea_batch **out, ea_problem *const *problems, int 
     b->h_states = reinterpret_cast<LMState *>(b->h_lm_block + c * sizeof(PoseState));
     b->h_traces = reinterpret_cast<LMTrace *>(b->h_lm_block + c * (sizeof(PoseState) + sizeof(LMState)));
   }
+  if (e == hipSuccess) {  // traces and states are read back row by row: never hand out uninitialised memory
+    e = hipMemset(b->d_lm_block, 0, lm_bytes);
+    std::memset(b->h_lm_block, 0, lm_bytes);
+    std::memset(b->h_deliver, 0, c * (sizeof(LMState) + sizeof(LMTrace)));
+  }
   if (e != hipSuccess) {
     batch_free_device(b);
     (void)hipStreamDestroy(b->stream);
@@ -599,6 +613,11 @@ static void fill_desc(const ea_problem *p, ProblemDesc &d) {
 
 // (re)build descriptors when any problem (or one of its terms) changed
 static int batch_build(ea_batch *b) {
+  if (b->needs_drain) {  // launches of an abandoned solve may still be queued on (or stuck in) the stream
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    b->needs_drain = false;
+  }
   uint64_t sig = 0;
   bool dirty = !b->built;
   for (size_t i = 0; i < b->probs.size(); ++i) {
@@ -748,6 +767,7 @@ static int batch_upload_poses(ea_batch *b, const double *q, const double *t) {
   const int count = (int)b->probs.size();
   for (int i = 0; i < count; ++i) host_pose_state(b->probs[i], q + 4 * i, t + 3 * i, &b->h_poses[i]);
   HIPCHK(hipMemcpyAsync(b->d_poses, b->h_poses, count * sizeof(PoseState), hipMemcpyHostToDevice, b->stream));
+  b->poses_uploaded = true;
   return EA_OK;
 }
 
@@ -789,11 +809,12 @@ static void fill_summary(const LMState &s, const LMTrace &tr, int64_t npts, doub
   out->num_iterations = s.iteration;
   out->num_successful_steps = s.num_successful;
   out->num_unsuccessful_steps = s.num_unsuccessful;
-  out->initial_cost = tr.it_cost[0];
-  out->final_cost = s.cost;
+  const bool no_start = s.why == EA_WHY_INITIAL_EVAL_FAILED;  // no trace row exists: costs as Ceres leaves them (-1)
+  out->initial_cost = no_start ? -1.0 : tr.it_cost[0];
+  out->final_cost = no_start ? -1.0 : s.cost;
   out->num_point_evals = (int64_t)s.num_evals * npts;
   out->total_time_ms = ms;
-  const int ni = std::min(s.iteration + 1, (int)EA_MAX_TRACE);
+  const int ni = no_start ? 0 : std::min(s.iteration + 1, (int)EA_MAX_TRACE);
   for (int i = 0; i < ni; ++i) {
     out->it_cost[i] = tr.it_cost[i];
     out->it_cost_change[i] = tr.it_cost_change[i];
@@ -815,9 +836,12 @@ struct SolveRun {
   ea_batch *b = nullptr;
   int first = 0;  // index of the run's first problem in the caller's arrays
   int count = 0, enq = 0, budget = 0, ahead = 2;
+  int seen = 0;   // evaluations the device had completed at the last look (progress = this moved, or a pair went out)
   unsigned spins = 0;
-  bool done = false, fetch = false;
+  bool done = false, fetch = false, moved = false;
 };
+
+static double resolve_timeout_ms(const ea_options &o) { return o.solve_timeout_ms == 0.0 ? 5000.0 : o.solve_timeout_ms; }
 
 static int solve_start(SolveRun &r, const ea_options &o, const LMOptions &lo, const double *q, const double *t) {
   ea_batch *b = r.b;
@@ -830,11 +854,14 @@ static int solve_start(SolveRun &r, const ea_options &o, const LMOptions &lo, co
     b->h_progress[i] = 1;          // running
     b->h_progress[count + i] = 0;  // evaluations completed
   }
+  if (b->t_test_stall_ms > 0)  // (tests/test_gpu_robustness.py: a device that shows no progress must trip the deadline)
+    HIPCHK(hipLaunchHostFunc(b->stream, [](void *ms) { std::this_thread::sleep_for(std::chrono::milliseconds((intptr_t)ms)); },
+                             (void *)(intptr_t)b->t_test_stall_ms));
   HIPCHK(hipMemcpyAsync(b->d_lm_block, b->h_lm_block, (size_t)count * (sizeof(PoseState) + sizeof(LMState)),
                         hipMemcpyHostToDevice, b->stream));
   r.ahead = o.iterations_per_sync > 0 ? o.iterations_per_sync : 2;  // measured: 2 beats 1, 3, 4, 6 by 1-3 %
   r.budget = o.max_num_iterations + 2;  // every pair consumes at least one iteration
-  r.enq = 0; r.spins = 0; r.done = false; r.fetch = false;
+  r.enq = 0; r.spins = 0; r.seen = 0; r.done = false; r.fetch = false; r.moved = true;
   return EA_OK;
 }
 
@@ -849,7 +876,8 @@ static int solve_pump(SolveRun &r, const LMOptions &lo) {
     any = any || (__atomic_load_n(&b->h_progress[i], __ATOMIC_ACQUIRE) != 0);
     done = std::max(done, __atomic_load_n(&b->h_progress[count + i], __ATOMIC_ACQUIRE));
   }
-  if (!any) { r.done = true; return EA_OK; }
+  if (!any) { r.done = true; r.moved = true; return EA_OK; }
+  if (done != r.seen) { r.seen = done; r.moved = true; }
   if (r.enq < r.budget && r.enq - done < r.ahead) {
     int rc = batch_launch_eval(b);
     if (rc != EA_OK) return rc;
@@ -857,6 +885,7 @@ static int solve_pump(SolveRun &r, const LMOptions &lo) {
                           b->d_progress, b->dv_states, b->dv_traces, b->stream));
     ++r.enq;
     r.spins = 0;
+    r.moved = true;
   } else if (r.enq >= r.budget) {
     HIPCHK(hipStreamSynchronize(b->stream));
     for (int i = 0; i < count; ++i)
@@ -914,7 +943,7 @@ static void solve_report(const SolveRun &r, const ea_options &o, double ms, doub
     if (summaries) fill_summary(s, tr, npts, ms, &summaries[i]);
     if (o.minimizer_progress_to_stdout) {
       std::printf("problem %d\niter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n", r.first + i);
-      const int ni = std::min(s.iteration + 1, (int)kTrace);
+      const int ni = s.why == EA_WHY_INITIAL_EVAL_FAILED ? 0 : std::min(s.iteration + 1, (int)kTrace);
       for (int it = 0; it < ni; ++it)
         std::printf("%4d  %.6e  % .2e    %.2e   %.2e  % .2e  %.2e\n", it, tr.it_cost[it], tr.it_cost_change[it],
                     tr.it_gradient_max_norm[it], tr.it_step_norm[it], tr.it_relative_decrease[it], tr.it_radius[it]);
@@ -999,15 +1028,29 @@ extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, 
     int rc = solve_start(r, o, lo, q + 4 * r.first, t + 3 * r.first);
     if (rc != EA_OK) return rc;
   }
+  // The host polls pinned progress words; a deadline bounds the wait: if the device shows no progress (no evaluation
+  // completed, nothing to enqueue) for solve_timeout_ms, give up with an error instead of spinning for ever on a kernel
+  // that never lowers its flag.  The batches are marked for a drain before their next use.
+  SpinWait wait(resolve_timeout_ms(o));
   for (;;) {
-    bool all_done = true;
+    bool all_done = true, moved = false;
     for (SolveRun &r : runs) {
       if (r.done) continue;
+      r.moved = false;
       int rc = solve_pump(r, lo);
       if (rc != EA_OK) return rc;
+      moved = moved || r.moved;
       all_done = all_done && r.done;
     }
     if (all_done) break;
+    if (moved) wait.progress();
+    else if (wait.poll()) {
+      for (SolveRun &r : runs) r.b->needs_drain = true;
+      b->needs_drain = true;
+      char msg[160];
+      std::snprintf(msg, sizeof msg, "solve deadline: no progress on the device for %.0f ms (ea_options.solve_timeout_ms)", wait.timeout_ms());
+      return fail(EA_ERR_HIP, msg);
+    }
   }
   for (SolveRun &r : runs) {
     int rc = solve_collect(r, o, summaries != nullptr);
@@ -1067,6 +1110,20 @@ extern "C" int ea_batch_bench_eval(ea_batch *b, const double *q, const double *t
     }
     *ms_eval_kernel = sum / m;
   }
+  return EA_OK;
+}
+
+extern "C" int ea_batch_bench_steps(ea_batch *b, int steps) {
+  if (!b || steps < 1) return fail(EA_ERR_INVALID_ARG, "bad argument");
+  int rc = batch_build(b);
+  if (rc != EA_OK) return rc;
+  if (!b->poses_uploaded) return fail(EA_ERR_STATE, "no poses uploaded yet (ea_batch_bench_eval or ea_batch_eval first)");
+  const int count = (int)b->probs.size();
+  for (int i = 0; i < steps; ++i) {
+    if ((rc = batch_launch_eval(b)) != EA_OK) return rc;
+    HIPCHK(launch_reduce(b->d_groups, count, b->d_partials, b->d_out, b->stream));
+  }
+  HIPCHK(hipStreamSynchronize(b->stream));
   return EA_OK;
 }
 
@@ -1131,6 +1188,7 @@ extern "C" int ea_batch_set_tuning(ea_batch *b, const char *key, int value) {
   else if (k == "xcd_remap") b->t_xcd = value;
   else if (k == "threads") b->t_nt = value;
   else if (k == "buffer_loads") b->t_buf = value;
+  else if (k == "test_stall_ms") { b->t_test_stall_ms = value; return EA_OK; }
   else if (k == "solve_streams") { b->t_streams = value; return EA_OK; }
   else return fail(EA_ERR_INVALID_ARG, "unknown tuning key: " + k);
   b->built = false;
@@ -1296,6 +1354,95 @@ extern "C" int ea_solve_sharded(ea_problem *p, const ea_options *opt_in, ea_allr
   return EA_OK;
 }
 
+// The point-sharded solve with the exchange kept on the stream: evaluation -> fold into the
+// caller's device buffer -> the caller's collective, enqueued on the batch's stream -> the device step kernel reading
+// that buffer as "one partial row".  The state machine is the device one of ea_solve; the host only enqueues rounds of
+// iterations and looks at the pinned progress word between rounds.  Every rank sees the same sums, hence the same
+// state after every iteration, hence stops after the same round: the collectives match up without any extra
+// communication.
+extern "C" int ea_solve_sharded_device(ea_problem *p, const ea_options *opt_in, ea_device_allreduce_fn allreduce, void *user,
+                                       double *device_sums, double q[4], double t[3], ea_summary *summary) {
+  if (!p || !allreduce || !device_sums || !q || !t) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  const auto t0 = std::chrono::steady_clock::now();
+  ea_options o;
+  if (opt_in) o = *opt_in; else ea_default_options(&o);
+  if (o.max_num_iterations < 0) return fail(EA_ERR_INVALID_ARG, "max_num_iterations < 0");
+  if (o.strategy != EA_STRATEGY_LM && o.strategy != EA_STRATEGY_DOGLEG)
+    return fail(EA_ERR_INVALID_ARG, "unknown trust-region strategy");
+  ea_batch *b = nullptr;
+  int rc = self_batch(p, &b);
+  if (rc != EA_OK) return rc;
+  LMOptions lo;
+  lo.max_num_iterations = o.max_num_iterations;
+  lo.function_tolerance = o.function_tolerance;
+  lo.gradient_tolerance = o.gradient_tolerance;
+  lo.parameter_tolerance = o.parameter_tolerance;
+  lo.initial_trust_region_radius = o.initial_trust_region_radius;
+  lo.max_trust_region_radius = o.max_trust_region_radius;
+  lo.min_trust_region_radius = o.min_trust_region_radius;
+  lo.min_relative_decrease = o.min_relative_decrease;
+  lo.min_lm_diagonal = o.min_lm_diagonal;
+  lo.max_lm_diagonal = o.max_lm_diagonal;
+  lo.max_num_consecutive_invalid_steps = o.max_num_consecutive_invalid_steps;
+  lo.jacobi_scaling = o.jacobi_scaling;
+  lo.strategy = o.strategy;
+  SolveRun r;
+  r.b = b;
+  rc = solve_start(r, o, lo, q, t);  // builds the batch, uploads pose + state, arms the progress words
+  if (rc != EA_OK) return rc;
+  if (!b->round_done) HIPCHK(hipEventCreateWithFlags(&b->round_done, hipEventDisableTiming));
+  if (!b->d_one_row) {
+    const GroupDesc one = {0, 1, 0, 1};
+    HIPCHK(hipMalloc(&b->d_one_row, sizeof(GroupDesc)));
+    HIPCHK(hipMemcpy(b->d_one_row, &one, sizeof(one), hipMemcpyHostToDevice));
+  }
+  const int round = o.iterations_per_sync > 0 ? o.iterations_per_sync : 4;
+  const double timeout_ms = resolve_timeout_ms(o);
+  bool finished = false;
+  while (!finished && r.enq < r.budget) {
+    for (int k = 0; k < round && r.enq < r.budget; ++k) {
+      rc = batch_launch_eval(b);  // (an empty shard launches nothing; its fold below yields zeros)
+      if (rc != EA_OK) return rc;
+      HIPCHK(launch_reduce(b->d_groups, 1, b->d_partials, reinterpret_cast<EvalOut *>(device_sums), b->stream));
+      if (allreduce(device_sums, kAccSlots, (void *)b->stream, user) != 0) {
+        b->needs_drain = true;
+        return fail(EA_ERR_STATE, "the all-reduce callback reported a failure");
+      }
+      HIPCHK(launch_lm_step(b->d_one_row, 1, device_sums, b->d_poses, b->d_states, b->d_cold, b->d_traces, lo, b->d_progress,
+                            b->dv_states, b->dv_traces, b->stream));
+      ++r.enq;
+    }
+    // Wait for the whole round (an event behind its last step kernel), THEN look at the flag: the decision to go on must
+    // be the same on every rank, so it may only depend on the state after a complete round, never on how far this
+    // rank's device happened to be when the host looked.
+    HIPCHK(hipEventRecord(b->round_done, b->stream));
+    SpinWait wait(timeout_ms);
+    int seen = -1;
+    for (;;) {
+      const hipError_t qe = hipEventQuery(b->round_done);
+      if (qe == hipSuccess) break;
+      if (qe != hipErrorNotReady) { b->needs_drain = true; return fail(EA_ERR_HIP, hipGetErrorString(qe)); }
+      const int done = __atomic_load_n(&b->h_progress[1], __ATOMIC_ACQUIRE);
+      if (done != seen) { seen = done; wait.progress(); }
+      else if (wait.poll()) {
+        b->needs_drain = true;
+        return fail(EA_ERR_HIP, "sharded solve deadline: no progress on the device (is every rank taking part in the collective?)");
+      }
+    }
+    finished = __atomic_load_n(&b->h_progress[0], __ATOMIC_ACQUIRE) == 0;
+  }
+  // launches of the last round that found the solve finished return at once, their collectives still run (on every rank
+  // alike); the caller's buffer must outlive them
+  HIPCHK(hipStreamSynchronize(b->stream));
+  r.fetch = !finished;
+  r.done = true;
+  rc = solve_collect(r, o, summary != nullptr);
+  if (rc != EA_OK) return rc;
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  solve_report(r, o, ms, q, t, summary);
+  return EA_OK;
+}
+
 // Coarse-to-fine driver (BASELINE config C3; the reference has no pyramid -- SURVEY 8f row 4): levels[0] is the finest
 // level; the solve starts on levels[nlevels-1] and carries the pose down level by level.  Every level is a complete
 // problem (its own points, DT image and intrinsics scaled by the caller).  A level that fails (termination FAILURE)
@@ -1358,9 +1505,15 @@ extern "C" int ea_tracker_push_frame(ea_tracker *tr, const uint8_t *bgr, const u
                                      double z_scaling, const ea_options *opt, double q_rel[4], double t_rel[3],
                                      ea_summary *summary, int *aligned) {
   if (!tr || !bgr || !depth || !q_rel || !t_rel) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  // every argument is checked before the tracker's problem is touched: a rejected call leaves the tracker as it was
+  if (!(z_scaling > 0.0)) return fail(EA_ERR_INVALID_ARG, "z_scaling must be > 0");
+  if (height < 1 || width < 1) return fail(EA_ERR_INVALID_ARG, "bad frame extent");
   int rc = EA_OK;
   if (aligned) *aligned = 0;
   if (summary) std::memset(summary, 0, sizeof(*summary));
+  double q_new[4], t_new[3];
+  std::memcpy(q_new, tr->q, sizeof(q_new));
+  std::memcpy(t_new, tr->t, sizeof(t_new));
   if (tr->frames > 0 && ea_problem_num_points(tr->p) > 0) {
     rc = tr->flavour == 0 ? ea_problem_set_now_frame(tr->p, bgr, height, width, 35, 1, 1)
                           : ea_problem_set_now_frame_canny(tr->p, bgr, nullptr, height, width, 30, 90, 1, 0.0, 1.0);
@@ -1372,21 +1525,30 @@ extern "C" int ea_tracker_push_frame(ea_tracker *tr, const uint8_t *bgr, const u
     rc = ea_solve(tr->p, opt, q, t, &s);
     if (rc != EA_OK) return rc;
     if (s.termination != EA_FAILURE) {
-      std::memcpy(tr->q, q, sizeof(q));
-      std::memcpy(tr->t, t, sizeof(t));
+      std::memcpy(q_new, q, sizeof(q));
+      std::memcpy(t_new, t, sizeof(t));
     }
     if (summary) *summary = s;
     if (aligned) *aligned = 1;
   }
-  std::memcpy(q_rel, tr->q, sizeof(tr->q));
-  std::memcpy(t_rel, tr->t, sizeof(tr->t));
   // the frame's edge strength / edge map is still in the workspace when it has just been the "now" frame
-  if (!(z_scaling > 0.0)) return fail(EA_ERR_INVALID_ARG, "z_scaling must be > 0");
   rc = ref_points_from_last_now(tr->p, tr->flavour == 0 ? 1 : 2, depth, height, width, z_scaling, tr->flavour == 0 ? 35 : 0);
   if (rc == EA_ERR_STATE)
     rc = tr->flavour == 0 ? ea_problem_set_ref_frame(tr->p, bgr, depth, height, width, z_scaling, 35)
                           : ea_problem_set_ref_frame_canny(tr->p, bgr, depth, height, width, z_scaling, 30, 90);
-  if (rc != EA_OK) return rc;
+  if (rc != EA_OK) {
+    // the DT image is the new frame's but no reference came out of it: drop the stale reference so that the next push
+    // starts a fresh chain instead of aligning frame k-1's points against frame k+2 from an advanced prior
+    (void)reserve_points(tr->p, 0);
+    tr->p->version++;
+    tr->frames = 0;
+    return rc;
+  }
+  // prior and frame count advance only with the new reference in place
+  std::memcpy(tr->q, q_new, sizeof(q_new));
+  std::memcpy(tr->t, t_new, sizeof(t_new));
+  std::memcpy(q_rel, tr->q, sizeof(tr->q));
+  std::memcpy(t_rel, tr->t, sizeof(tr->t));
   tr->frames += 1;
   return EA_OK;
 }

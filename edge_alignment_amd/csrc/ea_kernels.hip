@@ -1092,6 +1092,7 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_step_kernel(
 #endif
   const GroupDesc gd = groups[p];
   const int running = states[p].running;
+  const int evals_before = states[p].num_evals;  // (a register copy: the LDS copy is rewritten by lane 0 below)
   const double state_word = tid < kStateWords ? reinterpret_cast<const double *>(states + p)[tid] : 0.0;
   if (!running) return;  // uniform
   EA_LM_STAMP(1, ev_);
@@ -1102,7 +1103,7 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_step_kernel(
   // the host only uses this counter to decide how far ahead to enqueue: posted by another wavefront before the
   // arithmetic, so the PCIe write is neither the last thing the kernel waits for nor in lane 0's memory counter
   if (tid == 64)
-    __hip_atomic_store(progress + gridDim.x + p, s_st.num_evals + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(progress + gridDim.x + p, evals_before + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   LMPending pend;
   double acc[kAccSlots];
   if (tid == 0) {

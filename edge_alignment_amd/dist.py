@@ -33,6 +33,36 @@ def make_allreduce(world_size, device="cpu"):
     return allreduce
 
 
+def make_device_allreduce(world_size, device):
+    """The on-stream exchange of Problem.solve_sharded_device: returns (sums, enqueue) where `sums` is a torch tensor of
+    32 doubles on `device` (the buffer the library folds into and the step kernel reads) and `enqueue(stream_ptr)`
+    enqueues the in-place all-reduce of it on the library's HIP stream -- torch.distributed under an ExternalStream:
+    ProcessGroupNCCL orders its RCCL call behind the work already on that stream and makes the stream wait for the
+    result, all on the device, no host synchronisation.  world_size 1: nothing to enqueue.  With a CPU backend (gloo)
+    the tensor is staged through the host under a stream synchronisation (the protocol, not the speed, is what a
+    gloo rehearsal on one GPU checks)."""
+    import torch
+    import torch.distributed as dist
+    sums = torch.zeros(32, dtype=torch.float64, device=device)
+    if world_size == 1:
+        return sums, (lambda stream_ptr: None)
+    backend = dist.get_backend()
+    streams = {}
+
+    def enqueue(stream_ptr):
+        ext = streams.get(stream_ptr)
+        if ext is None:
+            ext = streams[stream_ptr] = torch.cuda.ExternalStream(int(stream_ptr), device=sums.device)
+        with torch.cuda.stream(ext):
+            if backend == "nccl":
+                dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+            else:
+                h = sums.cpu()  # orders behind the fold on `ext`
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                sums.copy_(h)
+    return sums, enqueue
+
+
 def shard_indices(n_items, rank, world_size):
     """problem i -> rank (i mod world_size)"""
     return list(range(rank, n_items, world_size))
@@ -64,3 +94,72 @@ def gather_poses(q_local, t_local, status_local, n_total, rank, world_size, devi
         t[idx] = out[r, :len(idx), 4:7]
         st[idx] = out[r, :len(idx), 7]
     return q, t, st
+
+
+def shard_block(n_items, rank, world_size):
+    """contiguous block of problems per rank (BASELINE C4: 256 frame pairs, 32 per GPU): rank r owns
+    [r n / W, (r+1) n / W)"""
+    return list(range((rank * n_items) // world_size, ((rank + 1) * n_items) // world_size))
+
+
+class PoseGather:
+    """The one collective of the batch mode, as a reusable object: a pinned host staging block and two device tensors
+    allocated ONCE; gather() is one host-to-device copy of m x 8 doubles, ONE all_gather_into_tensor (RCCL over xGMI
+    when the backend is "nccl") and one copy back.  Blocks of `m` problems per rank, global order = rank-major."""
+
+    def __init__(self, m, world_size, device="cpu"):
+        import torch
+        self.m, self.world, self.device = int(m), int(world_size), device
+        self.host = torch.zeros((self.m, 8), dtype=torch.float64)
+        if str(device) != "cpu":
+            self.host = self.host.pin_memory()
+        self.send = torch.zeros((self.m, 8), dtype=torch.float64, device=device)
+        self.recv = torch.zeros((self.world * self.m, 8), dtype=torch.float64, device=device)
+
+    def gather(self, q_local, t_local, status_local):
+        """-> (q (W m, 4), t (W m, 3), status (W m,)) on every rank"""
+        import torch
+        import torch.distributed as dist
+        h = self.host.numpy()
+        h[:, 0:4] = np.asarray(q_local, dtype=np.float64).reshape(self.m, 4)
+        h[:, 4:7] = np.asarray(t_local, dtype=np.float64).reshape(self.m, 3)
+        h[:, 7] = np.asarray(status_local, dtype=np.float64).reshape(self.m)
+        self.send.copy_(self.host, non_blocking=True)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.recv, self.send)
+        else:
+            self.recv.copy_(self.send)
+        out = self.recv.cpu().numpy()
+        return out[:, 0:4].copy(), out[:, 4:7].copy(), out[:, 7].copy()
+
+
+def run_c4(rank, world_size, build_and_solve, per_gpu=32, device="cpu", total=None, repeats=1):
+    """BASELINE config C4 as a run shape: every rank takes its block of `per_gpu` frame-pair problems
+    (synth.config_c4_specs), solves them with ONE batched solve (`build_and_solve(specs) -> (solve_fn, info)`,
+    solve_fn() -> (q, t, summaries) -- ea_batch_solve on the GPU, a CPU stand-in in the gloo test), then ONE
+    all-gather of the per_gpu x 8 doubles.  Returns a dict of timings and the gathered poses (global order)."""
+    import time
+    from . import synth
+    total = total if total is not None else per_gpu * world_size
+    specs_all = synth.config_c4_specs(total=total)
+    mine = shard_block(total, rank, world_size)
+    assert len(mine) == per_gpu, "C4 shards evenly: %d problems over %d ranks" % (total, world_size)
+    solve_fn, info = build_and_solve([specs_all[i] for i in mine])
+    pg = PoseGather(per_gpu, world_size, device=device)
+    q, t, ss = solve_fn()  # warm-up (descriptor upload, first-touch)
+    pg.gather(q, t, [s["termination"] for s in ss])
+    t0 = time.perf_counter()
+    for _ in range(repeats):
+        q, t, ss = solve_fn()
+    solve_s = (time.perf_counter() - t0) / repeats
+    t1 = time.perf_counter()
+    qa, ta, sa = pg.gather(q, t, [s["termination"] for s in ss])
+    gather_s = time.perf_counter() - t1
+    its = sum(s["num_iterations"] for s in ss)
+    evals = sum(s.get("num_point_evals", 0) for s in ss)
+    out = dict(info)
+    out.update({"pairs_per_gpu": per_gpu, "pairs_total": total, "solve_ms": solve_s * 1e3,
+                "lm_iters_per_s_per_gpu": its / solve_s, "evals_per_s_per_gpu": evals / solve_s,
+                "iterations_mean": its / per_gpu, "pose_gather_ms": gather_s * 1e3,
+                "converged": int(sum(1 for s in ss if s["termination"] == 0))})
+    return out, (qa, ta, sa)

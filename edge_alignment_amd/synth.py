@@ -168,3 +168,40 @@ def make_stereo_problem(H, W, n1, n2, seed, K1, K2, T12, planted_q, planted_t, d
         a = (b - Tcam[:3, 3]) @ Tcam[:3, :3]   # a = R^T (b - t)
         out.append(dict(xyz=a, grid=pr["grid"], image=pr["image"], K=K))
     return out
+
+
+# ---- BASELINE config C4: 256 frame pairs, 32 per GPU ----------------------------------------------------------------
+# TUM fr1_desk is not available offline: the 256 problems are the 20 ordered pairs of the five bundled grabs
+# (standalone/rgb-d, copied to tests/golden/rgbd as fixtures) x 12-13 seeded initial-pose perturbations (rotation <= 1
+# degree, translation <= 2 cm, seed 4).  Problem i = pair (i mod 20), perturbation (i div 20); perturbation 0 is the
+# identity start of the reference's drivers.
+
+C4_TOTAL = 256
+TUM_K = (525.0, 525.0, 319.5, 239.5)  # standalone_edge_align.cpp:151-160
+
+
+def load_bundled_frames(directory):
+    """{1..5: (bgr uint8 HxWx3 as cv::imread returns it, depth uint16 HxW)} from tests/golden/rgbd (PIL)."""
+    import os
+    from PIL import Image
+    out = {}
+    for k in range(1, 6):
+        rgb = np.asarray(Image.open(os.path.join(directory, "rgb_%d.png" % k)).convert("RGB"), dtype=np.uint8)
+        dep = np.asarray(Image.open(os.path.join(directory, "depth_%d.png" % k))).astype(np.uint16)
+        out[k] = (np.ascontiguousarray(rgb[:, :, ::-1]), np.ascontiguousarray(dep))
+    return out
+
+
+def config_c4_specs(total=C4_TOTAL, seed=4):
+    """[(ref frame, now frame, q0 (4,), t0 (3,))] for problems 0..total-1, identical on every rank."""
+    pairs = [(a, b) for a in range(1, 6) for b in range(1, 6) if a != b]
+    rng = np.random.default_rng(seed)
+    n_pert = (total + len(pairs) - 1) // len(pairs)
+    perts = [(np.array([1.0, 0, 0, 0]), np.zeros(3))]
+    for _ in range(1, n_pert):
+        axis = rng.normal(size=3)
+        q = quat_from_axis_angle(axis, np.deg2rad(rng.uniform(0.0, 1.0)))
+        d = rng.normal(size=3)
+        perts.append((q, d / np.linalg.norm(d) * rng.uniform(0.0, 0.02)))
+    return [(pairs[i % len(pairs)][0], pairs[i % len(pairs)][1], perts[i // len(pairs)][0].copy(), perts[i // len(pairs)][1].copy())
+            for i in range(total)]

@@ -86,6 +86,8 @@ typedef struct {
   int strategy;                       /* EA_STRATEGY_LM (LEVENBERG_MARQUARDT) | EA_STRATEGY_DOGLEG */
   int minimizer_progress_to_stdout;   /* 0 */
   int iterations_per_sync;            /* device LM iterations enqueued between host checks; 0 = default */
+  double solve_timeout_ms;            /* a solve whose device side shows no progress for this long returns EA_ERR_HIP
+                                         instead of spinning for ever; 0 = default (5000 ms), < 0 = no deadline */
 } ea_options;
 
 #define EA_MAX_TRACE 128
@@ -204,6 +206,17 @@ int ea_solve(ea_problem *p, const ea_options *opt, double q[4], double t[3], ea_
 typedef int (*ea_allreduce_fn)(double *buf, int count, void *user);
 int ea_solve_sharded(ea_problem *p, const ea_options *opt, ea_allreduce_fn allreduce, void *user, double q[4], double t[3],
                      ea_summary *summary);
+/* The same solve with the exchange kept ON THE STREAM ("no host round-trip"): per iteration
+ * the library enqueues, on one HIP stream, fused evaluation -> fold into `device_sums` (32 doubles of DEVICE memory owned
+ * by the caller, e.g. the storage of a torch tensor) -> `allreduce(device_sums, 32, stream, user)`, which must ENQUEUE an
+ * in-place sum over all ranks on that stream (RCCL: ncclAllReduce on it, or torch.distributed under an ExternalStream)
+ * and return without waiting -> the trust-region step kernel, which reads `device_sums`.  Iterations are enqueued in
+ * rounds of opt->iterations_per_sync (default 4); the host looks at the device's progress word once per round, and since
+ * every rank computes the same state from the same sums, every rank stops after the same round: the number of
+ * collectives enqueued is identical on all ranks.  `hip_stream` is the hipStream_t as a void pointer. */
+typedef int (*ea_device_allreduce_fn)(void *device_buf, int count, void *hip_stream, void *user);
+int ea_solve_sharded_device(ea_problem *p, const ea_options *opt, ea_device_allreduce_fn allreduce, void *user,
+                            double *device_sums, double q[4], double t[3], ea_summary *summary);
 
 /* Coarse-to-fine driver (BASELINE config C3; the reference has no pyramid): levels[0] = finest.
  * Solves levels[nlevels-1] first and carries q, t down level by level; every level is a complete problem with its own
@@ -241,13 +254,19 @@ int ea_batch_solve(ea_batch *b, const ea_options *opt, double *q, double *t,
  * dominant per-point kernel alone (events around each launch in a second pass). */
 int ea_batch_bench_eval(ea_batch *b, const double *q, const double *t, int warmup, int steps,
                         double *ms_total, double *ms_eval_kernel);
+/* The timed region of bench.py and nothing else: `steps` x (fused evaluation + fold) enqueued on the batch's stream at the
+ * poses the last ea_batch_bench_eval / ea_batch_eval uploaded, then a stream synchronisation.  No pose upload, no event
+ * creation, no allocation inside: whoever brackets this call with a wall clock times exactly K steps (round 1's bracket
+ * contained ~70 us of setup, a third of a 20-step run).  EA_ERR_STATE when no poses have been uploaded yet. */
+int ea_batch_bench_steps(ea_batch *b, int steps);
 /* `launches` of the per-point kernel queued back to back between ONE event pair: average execution window per
  * launch (dispatch of the next launch overlaps the running one) -- the figure rocprofv3 --kernel-trace reports. */
 int ea_batch_bench_kernel(ea_batch *b, const double *q, const double *t, int warmup, int launches,
                           double *ms_per_launch);
 /* the same for the fold kernel of ea_batch_eval, over the partial rows the last evaluation left */
 int ea_batch_bench_fold(ea_batch *b, int warmup, int launches, double *ms_per_launch);
-/* tuning knobs: key in {"lds_bytes", "points_per_thread", "use_lds", "xcd_remap", "threads"};
+/* tuning knobs: key in {"lds_bytes", "points_per_thread", "use_lds", "xcd_remap", "threads", "buffer_loads",
+ * "solve_streams"};
  * value < 0 restores the default */
 int ea_batch_set_tuning(ea_batch *b, const char *key, int value);
 int ea_batch_get_info(const ea_batch *b, const char *key, int64_t *value);

@@ -54,7 +54,8 @@ def lm_host_shim():
     so = os.path.join(out_dir, "libea_lm_host.so")
     src = os.path.join(ROOT, "tests", "lm_host_shim.cpp")
     deps = [src, os.path.join(ROOT, "edge_alignment_amd", "csrc", "ea_lm.h"),
-            os.path.join(ROOT, "edge_alignment_amd", "csrc", "ea_types.h")]
+            os.path.join(ROOT, "edge_alignment_amd", "csrc", "ea_types.h"),
+            os.path.join(ROOT, "edge_alignment_amd", "csrc", "ea_spin.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                                "-I", os.path.join(ROOT, "edge_alignment_amd", "csrc"), "-o", so, src])

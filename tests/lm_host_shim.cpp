@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include "ea_lm.h"
+#include "ea_spin.h"
 
 extern "C" {
 
@@ -51,5 +52,9 @@ void ea_lm_host_pose_state(const double x[7], int rot_transposed, double R[9], d
   std::memcpy(G, ps.G, sizeof(ps.G));
   *unit_q = ps.unit_q;
 }
+
+// the bounded wait of the solve loop (edge_alignment_amd/csrc/ea_spin.h) on a flag the test controls:
+// 0 = the flag was lowered, 1 = the deadline passed
+int ea_test_spin_until_zero(const volatile int *flag, double timeout_ms) { return ea::spin_until_zero(flag, timeout_ms); }
 
 }  // extern "C"

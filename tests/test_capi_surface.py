@@ -36,7 +36,7 @@ def test_struct_layouts_match_the_header(lib):
     from edge_alignment_amd import capi
     # sizes as laid out by the C compiler for include/ea_hip.h
     assert C.sizeof(capi.Camera) == 32
-    assert C.sizeof(capi.Options) == 4 + 4 + 9 * 8 + 4 * 4 + 2 * 4
+    assert C.sizeof(capi.Options) == 4 + 4 + 9 * 8 + 4 * 4 + 2 * 4 + 8  # + solve_timeout_ms
     assert C.sizeof(capi.Summary) == 5 * 4 + 4 + 2 * 8 + 8 + 8 + 6 * 8 * capi.MAX_TRACE + 4 * capi.MAX_TRACE
     o = capi.default_options()
     assert (o.max_num_iterations, o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance) == (50, 1e-6, 1e-10, 1e-8)

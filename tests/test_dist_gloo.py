@@ -116,3 +116,68 @@ def test_point_sharded_solve_world2(tmp_path, lm_host_shim, oracle):
     q, t, s = oracle.OracleProblem(pr["grid"], *pr["K"]).solve(pr["xyz"], [1, 0, 0, 0], [0, 0, 0])
     assert r0["it"] == s["num_iterations"]
     assert np.abs(r0["x"][:4] - q).max() < 1e-10 and np.abs(r0["x"][4:] - t).max() < 1e-10
+
+
+# ---- BASELINE config C4 as bench.py runs it: a block of frame pairs per rank, one batched solve, ONE all-gather from
+# preallocated tensors (edge_alignment_amd.dist.run_c4 / PoseGather).  On CPU the batched solve is the oracle on small
+# planted stand-ins keyed by the C4 specification (frame pair, start pose); the sharding, the start poses, the gather
+# and the global order are the code bench.py runs over RCCL.
+
+def _c4_standin(spec):
+    from edge_alignment_amd import synth
+    a, b, q0, t0 = spec
+    return synth.make_problem(60, 80, 250, 12, 1000 + 10 * a + b, 65.0, 65.0, 39.5, 29.5,
+                              planted_q=synth.quat_from_axis_angle([a, b, 1], np.deg2rad(0.4)),
+                              planted_t=(0.001 * a, -0.001 * b, 0.002), normalize=True)
+
+
+def _c4_worker(rank, world, port, per_gpu, out_dir):
+    import torch.distributed as dist
+    from edge_alignment_amd import dist as ead
+    from oracle import ea_oracle as eo
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+
+    def build_and_solve(specs):
+        probs = [_c4_standin(sp) for sp in specs]
+
+        def solve():
+            qs, ts, ss = [], [], []
+            for pr, sp in zip(probs, specs):
+                q, t, s = eo.OracleProblem(pr["grid"], *pr["K"]).solve(pr["xyz"], sp[2], sp[3])
+                qs.append(q); ts.append(t); ss.append(s)
+            return np.array(qs), np.array(ts), ss
+        return solve, {"dtype": "f64"}
+    res, (q, t, st) = ead.run_c4(rank, world, build_and_solve, per_gpu=per_gpu, device="cpu")
+    assert res["pairs_total"] == per_gpu * world and res["converged"] == per_gpu
+    np.savez(os.path.join(out_dir, "c4_rank%d.npz" % rank), q=q, t=t, st=st)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_c4_run_shape_world2(tmp_path):
+    import torch.multiprocessing as mp
+    from edge_alignment_amd import dist as ead, synth
+    world, per_gpu = 2, 3
+    assert ead.shard_block(6, 0, 2) == [0, 1, 2] and ead.shard_block(6, 1, 2) == [3, 4, 5]
+    specs = synth.config_c4_specs(total=per_gpu * world)
+    assert specs == [] or (np.array_equal(specs[0][2], [1, 0, 0, 0]) and not np.any(specs[0][3]))  # identity start first
+    full = synth.config_c4_specs()
+    assert len(full) == 256 and len({(a, b) for a, b, _, _ in full}) == 20
+    ang = [synth.rotation_angle_between(q, [1, 0, 0, 0]) for _, _, q, _ in full]
+    assert max(ang) <= np.deg2rad(1.0) + 1e-12 and max(np.linalg.norm(t) for _, _, _, t in full) <= 0.02 + 1e-12
+    mp.spawn(_c4_worker, args=(world, _free_port(), per_gpu, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "c4_rank0.npz"), np.load(tmp_path / "c4_rank1.npz")
+    assert np.array_equal(r0["q"], r1["q"]) and np.array_equal(r0["t"], r1["t"]) and np.array_equal(r0["st"], r1["st"])
+    assert r0["q"].shape == (6, 4)
+    for i, sp in enumerate(specs):  # global order = specification order
+        a, b = sp[0], sp[1]
+        assert synth.rotation_angle_between(r0["q"][i], synth.quat_from_axis_angle([a, b, 1], np.deg2rad(0.4))) < 1e-5
+        assert np.linalg.norm(r0["t"][i] - np.array([0.001 * a, -0.001 * b, 0.002])) < 1e-5
+        assert r0["st"][i] == 0
+
+
+def test_pose_gather_single_rank_is_a_copy():
+    from edge_alignment_amd import dist as ead
+    pg = ead.PoseGather(2, 1)
+    q, t, st = pg.gather([[1, 0, 0, 0], [0, 1, 0, 0]], [[1, 2, 3], [4, 5, 6]], [0, 2])
+    assert q.tolist() == [[1, 0, 0, 0], [0, 1, 0, 0]] and t.tolist() == [[1, 2, 3], [4, 5, 6]] and st.tolist() == [0, 2]

@@ -1,0 +1,73 @@
+"""Error paths of the device solve that need a GPU: the deadline of the host's wait, a failed initial evaluation, the
+tracker's all-or-nothing push."""
+import numpy as np
+import pytest
+
+from edge_alignment_amd import synth
+
+pytestmark = pytest.mark.gpu
+Q0, T0 = np.array([1.0, 0, 0, 0]), np.zeros(3)
+
+
+def _problem(hip, n=4000, dtype=None):
+    pr = synth.make_problem(120, 160, n, 40, 1, 130.0, 130.0, 79.5, 59.5,
+                            planted_q=synth.quat_from_axis_angle([1, 2, 3], np.deg2rad(1.0)),
+                            planted_t=(0.01, -0.005, 0.02), normalize=True)
+    P = hip.Problem(*pr["K"], dtype=dtype if dtype is not None else hip.EA_F64)
+    P.set_points(pr["xyz"]); P.set_dt_grid(pr["grid"])
+    return P, pr
+
+
+def test_solve_deadline_returns_an_error_and_the_batch_recovers(hip):
+    """A stream that makes no progress (held on a host function here; a kernel that never lowers its flag in the
+    field) trips ea_options.solve_timeout_ms: EA_ERR_HIP with a message, not a hung process.  The batch drains the
+    abandoned launches before its next use and then solves as if nothing had happened."""
+    P, pr = _problem(hip)
+    B = hip.Batch([P])
+    q_ref, t_ref, s_ref = B.solve(Q0, T0)
+    B.set_tuning("test_stall_ms", 300)
+    with pytest.raises(hip.EAError) as ei:
+        B.solve(Q0, T0, solve_timeout_ms=30.0)
+    assert ei.value.code == hip.EA_ERR_HIP and "deadline" in str(ei.value)
+    B.set_tuning("test_stall_ms", 0)
+    q, t, s = B.solve(Q0, T0)                       # drains the stalled launches first
+    assert np.array_equal(q, q_ref) and np.array_equal(t, t_ref)
+    assert s[0]["num_iterations"] == s_ref[0]["num_iterations"]
+    B.set_tuning("test_stall_ms", 40)
+    q, t, s = B.solve(Q0, T0, solve_timeout_ms=-1.0)  # no deadline: waits the stall out
+    assert np.array_equal(q, q_ref)
+    B.close(); P.close()
+
+
+def test_failed_initial_evaluation_reports_defined_costs(hip):
+    """utils.h:70-73: a block whose point lands inside |z| < 0.01 returns false; at the start pose Ceres fails the solve.
+    No trace row exists then: the summary carries Ceres' -1 costs, not whatever the trace buffer held before."""
+    P, pr = _problem(hip)
+    q_ok, t_ok, s_ok = P.solve(Q0, T0)              # leaves a full trace behind in the batch's buffers
+    assert s_ok["termination"] == hip.CONVERGENCE
+    xyz = pr["xyz"].copy()
+    xyz[7] = [0.1, 0.2, 0.001]                      # b_z inside the guard band at the identity pose
+    P.set_points(xyz)
+    q, t, s = P.solve(Q0, T0)
+    assert s["termination"] == hip.FAILURE and s["why"] == "initial_eval_failed"
+    assert s["initial_cost"] == -1.0 and s["final_cost"] == -1.0 and s["num_iterations"] == 0
+    assert np.array_equal(q, Q0) and np.array_equal(t, T0)
+    P.close()
+
+
+def test_tracker_push_is_all_or_nothing(hip):
+    """A push rejected for its arguments leaves the tracker exactly as it was (round 1 checked z_scaling after it had
+    replaced the DT image and advanced the prior)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fr = synth.load_bundled_frames(os.path.join(root, "tests", "golden", "rgbd"))
+    TA, TB = hip.Tracker(*synth.TUM_K), hip.Tracker(*synth.TUM_K)
+    for k in (1, 2):
+        ra = TA.push_frame(fr[k][0], fr[k][1])
+        rb = TB.push_frame(fr[k][0], fr[k][1])
+    with pytest.raises(hip.EAError):
+        TA.push_frame(fr[3][0], fr[3][1], z_scaling=0.0)      # rejected before anything is touched
+    ra = TA.push_frame(fr[3][0], fr[3][1])
+    rb = TB.push_frame(fr[3][0], fr[3][1])
+    assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1])
+    TA.close(); TB.close()

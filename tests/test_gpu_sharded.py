@@ -75,3 +75,74 @@ def test_sharded_solve_two_ranks(hip, tmp_path):
     assert r0["it"] == s["num_iterations"]
     assert np.abs(r0["q"] - q).max() < 1e-10 and np.abs(r0["t"] - t).max() < 1e-10
     assert r0["cost"] == pytest.approx(s["final_cost"], rel=1e-10)
+
+
+# ---- the exchange kept on the stream: ea_solve_sharded_device (evaluation -> fold into the caller's device buffer ->
+# the caller's collective enqueued on the library's stream -> the device step kernel reading that buffer)
+
+def test_sharded_device_single_rank_equals_device_solve(hip):
+    """world size 1: nothing to enqueue; evaluation, fold, step all stay on the device and must take the decisions of
+    ea_solve (the rows are folded by the fold kernel instead of the step kernel: sums equal to rounding)."""
+    import torch
+    from edge_alignment_amd import dist as ead
+    cfg = _problem()
+    for dtype, tol in ((hip.EA_F64, 1e-10), (hip.EA_F32, 1e-6)):
+        P = hip.Problem(*cfg["K"], dtype=dtype)
+        P.set_points(cfg["xyz"]); P.set_dt_grid(cfg["grid"]); P.set_loss(hip.LOSS_CAUCHY, 1.0)
+        q, t, s = P.solve(Q0, T0)
+        sums, enqueue = ead.make_device_allreduce(1, torch.device("cuda", 0))
+        calls = []
+        def enq(stream):
+            calls.append(stream); enqueue(stream)
+        for per_sync in (0, 1, 3):
+            del calls[:]
+            q2, t2, s2 = P.solve_sharded_device(Q0, T0, enq, sums.data_ptr(), iterations_per_sync=per_sync)
+            assert s2["num_iterations"] == s["num_iterations"] and s2["why"] == s["why"], per_sync
+            assert np.abs(q - q2).max() < tol and np.abs(t - t2).max() < tol
+            assert s2["it_cost"] == pytest.approx(s["it_cost"], rel=1e-9 if dtype == hip.EA_F64 else 1e-5)
+            rnd = per_sync or 4
+            evals = s["num_iterations"] + 1
+            assert len(calls) == -(-evals // rnd) * rnd     # whole rounds: the count every rank reaches alike
+            assert len(set(calls)) == 1                     # one stream
+        q3, t3, s3 = P.solve_sharded_device(Q0, T0, enq, sums.data_ptr(), strategy=hip.STRATEGY_DOGLEG, max_num_iterations=25)
+        q4, t4, s4 = P.solve(Q0, T0, strategy=hip.STRATEGY_DOGLEG, max_num_iterations=25)
+        assert s3["num_iterations"] == s4["num_iterations"] and np.abs(q3 - q4).max() < tol
+        P.close()
+
+
+def _device_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    from edge_alignment_amd import capi, dist as ead
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    cfg = _problem()
+    X = cfg["xyz"][ead.shard_slice(cfg["xyz"].shape[0], rank, world)]
+    P = capi.Problem(*cfg["K"], dtype=capi.EA_F64, device=0)   # both ranks share the one GPU of the test box
+    P.set_points(X); P.set_dt_grid(cfg["grid"]); P.set_loss(capi.LOSS_CAUCHY, 1.0)
+    sums, enqueue = ead.make_device_allreduce(world, torch.device("cuda", 0))
+    n = [0]
+    def enq(stream):
+        n[0] += 1; enqueue(stream)
+    q, t, s = P.solve_sharded_device(Q0, T0, enq, sums.data_ptr(), solve_timeout_ms=20000.0)
+    np.savez(os.path.join(out_dir, "d%d.npz" % rank), q=q, t=t, it=s["num_iterations"], cost=s["final_cost"], calls=n[0])
+    P.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_device_two_ranks(hip, tmp_path):
+    """Two gloo ranks on the one GPU: the collective is staged through the host here (gloo has no device path), the
+    protocol is the RCCL one -- whole rounds, the same number of collectives on every rank, lockstep iterates."""
+    import torch.multiprocessing as mp
+    cfg = _problem()
+    P = hip.Problem(*cfg["K"], dtype=hip.EA_F64)
+    P.set_points(cfg["xyz"]); P.set_dt_grid(cfg["grid"]); P.set_loss(hip.LOSS_CAUCHY, 1.0)
+    q, t, s = P.solve(Q0, T0)
+    P.close()
+    mp.spawn(_device_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "d0.npz"), np.load(tmp_path / "d1.npz")
+    assert np.array_equal(r0["q"], r1["q"]) and np.array_equal(r0["t"], r1["t"]) and r0["it"] == r1["it"]   # lockstep
+    assert r0["calls"] == r1["calls"]                                                                       # collectives match
+    assert r0["it"] == s["num_iterations"]
+    assert np.abs(r0["q"] - q).max() < 1e-10 and np.abs(r0["t"] - t).max() < 1e-10
+    assert r0["cost"] == pytest.approx(s["final_cost"], rel=1e-10)

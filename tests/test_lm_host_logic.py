@@ -114,3 +114,27 @@ def test_pose_state_general_derivative_matches_jet(lm_host_shim, oracle):
     x[:4] = q / np.linalg.norm(q)
     lm_host_shim.ea_lm_host_pose_state(x.ctypes.data_as(dp), 0, R.ctypes.data_as(dp), G.ctypes.data_as(dp), C.byref(u))
     assert u.value == 1
+
+
+def test_solve_wait_has_a_deadline(lm_host_shim):
+    """ea_batch_solve / ea_solve_sharded_device poll pinned flags that a step kernel lowers; the wait is bounded
+    (ea_options.solve_timeout_ms, edge_alignment_amd/csrc/ea_spin.h): a flag that is never lowered costs an error after
+    the budget instead of a hung process, a flag lowered in time ends the wait at once, a negative budget waits on."""
+    import ctypes as C
+    import threading
+    import time
+    fn = lm_host_shim.ea_test_spin_until_zero
+    fn.argtypes = [C.POINTER(C.c_int), C.c_double]
+    flag = C.c_int(1)
+    t0 = time.perf_counter()
+    assert fn(C.byref(flag), 60.0) == 1          # the stubbed never-finishing flag
+    el = time.perf_counter() - t0
+    assert 0.05 <= el < 2.0, el
+    flag.value = 1
+    threading.Timer(0.05, lambda: setattr(flag, "value", 0)).start()
+    t0 = time.perf_counter()
+    assert fn(C.byref(flag), 5000.0) == 0        # lowered in time
+    assert time.perf_counter() - t0 < 2.0
+    flag.value = 1
+    threading.Timer(0.15, lambda: setattr(flag, "value", 0)).start()
+    assert fn(C.byref(flag), -1.0) == 0          # no deadline: waits for the flag however long it takes
