@@ -122,7 +122,7 @@ def load():
     L.ea_batch_eval.argtypes = [vp, dp, dp, dp, dp, dp, i64p]
     L.ea_batch_solve.argtypes = [vp, C.POINTER(Options), dp, dp, C.POINTER(Summary)]
     L.ea_batch_bench_eval.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp, dp]
-    L.ea_batch_bench_steps.argtypes = [vp, C.c_int]
+    L.ea_batch_bench_steps.argtypes = [vp, C.c_int, dp]
     L.ea_batch_bench_kernel.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp]
     L.ea_batch_bench_fold.argtypes = [vp, C.c_int, C.c_int, dp]
     L.ea_solve_sharded.argtypes = [vp, C.POINTER(Options), ALLREDUCE_FN, vp, dp, dp, C.POINTER(Summary)]
@@ -538,9 +538,13 @@ class Batch:
                                           C.byref(ms_kernel) if kernel_pass else None))
         return ms_total.value, (ms_kernel.value if kernel_pass else None)
 
-    def bench_steps(self, steps):
+    def bench_steps(self, steps, host_times=False):
         """`steps` x (fused evaluation + fold) at the poses already on the device, then a stream sync: the timed region"""
-        _check(load().ea_batch_bench_steps(self._h, int(steps)))
+        if host_times:
+            us = np.zeros(2)
+            _check(load().ea_batch_bench_steps(self._h, int(steps), _dp(us)))
+            return us
+        _check(load().ea_batch_bench_steps(self._h, int(steps), None))
 
     def bench_kernel(self, q, t, warmup, launches):
         """mean ms of the per-point kernel over `launches` back-to-back launches (one event pair)"""

@@ -559,7 +559,9 @@ extern "C" int ea_batch_create(ea_batch **out, ea_problem *const *problems, int 
     b->h_traces = reinterpret_cast<LMTrace *>(b->h_lm_block + c * (sizeof(PoseState) + sizeof(LMState)));
   }
   if (e == hipSuccess) {  // traces and states are read back row by row: never hand out uninitialised memory
-    e = hipMemset(b->d_lm_block, 0, lm_bytes);
+    // (on the batch's own stream: a null-stream memset is not ordered with this non-blocking stream and could land
+    // after the first solve's upload -- states wiped to "not running", the host waiting for a flag nobody lowers)
+    e = hipMemsetAsync(b->d_lm_block, 0, lm_bytes, b->stream);
     std::memset(b->h_lm_block, 0, lm_bytes);
     std::memset(b->h_deliver, 0, c * (sizeof(LMState) + sizeof(LMTrace)));
   }
@@ -1113,17 +1115,23 @@ extern "C" int ea_batch_bench_eval(ea_batch *b, const double *q, const double *t
   return EA_OK;
 }
 
-extern "C" int ea_batch_bench_steps(ea_batch *b, int steps) {
+extern "C" int ea_batch_bench_steps(ea_batch *b, int steps, double *host_us) {
   if (!b || steps < 1) return fail(EA_ERR_INVALID_ARG, "bad argument");
   int rc = batch_build(b);
   if (rc != EA_OK) return rc;
   if (!b->poses_uploaded) return fail(EA_ERR_STATE, "no poses uploaded yet (ea_batch_bench_eval or ea_batch_eval first)");
   const int count = (int)b->probs.size();
+  const auto t0 = std::chrono::steady_clock::now();
   for (int i = 0; i < steps; ++i) {
     if ((rc = batch_launch_eval(b)) != EA_OK) return rc;
     HIPCHK(launch_reduce(b->d_groups, count, b->d_partials, b->d_out, b->stream));
   }
+  const auto t1 = std::chrono::steady_clock::now();
   HIPCHK(hipStreamSynchronize(b->stream));
+  if (host_us) {
+    host_us[0] = std::chrono::duration<double, std::micro>(t1 - t0).count();
+    host_us[1] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
+  }
   return EA_OK;
 }
 

@@ -258,7 +258,7 @@ int ea_batch_bench_eval(ea_batch *b, const double *q, const double *t, int warmu
  * poses the last ea_batch_bench_eval / ea_batch_eval uploaded, then a stream synchronisation.  No pose upload, no event
  * creation, no allocation inside: whoever brackets this call with a wall clock times exactly K steps (round 1's bracket
  * contained ~70 us of setup, a third of a 20-step run).  EA_ERR_STATE when no poses have been uploaded yet. */
-int ea_batch_bench_steps(ea_batch *b, int steps);
+int ea_batch_bench_steps(ea_batch *b, int steps, double *host_us /* nullable: [0] enqueue, [1] wait, microseconds */);
 /* `launches` of the per-point kernel queued back to back between ONE event pair: average execution window per
  * launch (dispatch of the next launch overlaps the running one) -- the figure rocprofv3 --kernel-trace reports. */
 int ea_batch_bench_kernel(ea_batch *b, const double *q, const double *t, int warmup, int launches,

@@ -13,6 +13,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_brings_the_gpu_up_first():
+    """PyTorch-ROCm bundles its own HIP/HSA runtime: in a process that uses both (the on-stream collective of
+    ea_solve_sharded_device, bench.py) torch has to initialise the GPU before libea_hip.so does, or torch's runtime finds
+    no device afterwards (scripts/order_probe.py).  No GPU: nothing happens."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (test infrastructure).  Built on demand with gcc."""

@@ -38,8 +38,8 @@ def test_readme_log_through_the_device_pipeline(hip, oracle, dtype_name):
     dtype = getattr(hip, dtype_name)
     # producers on the device (utils.cpp:201-281 get_aX, :38-83 get_distance_transform)
     F = hip.Problem(*K, dtype=hip.EA_F64)
-    n = F.set_ref_frame(imA, dA, z_scaling=5000.0)
-    assert n == 44457                                   # README.md:34 through ceil(n / 30)
+    F.set_ref_frame(imA, dA, z_scaling=5000.0)
+    assert F.num_points == 44457                                 # README.md:34 through ceil(n / 30)
     X = F.get_points()[::30].copy()                     # standalone_edge_align.cpp:267 `i += 30`
     assert X.shape[0] == 1482                           # README.md:31-35 "Residual blocks 1482"
     F.close()

@@ -113,6 +113,7 @@ def test_sharded_device_single_rank_equals_device_solve(hip):
 def _device_worker(rank, world, port, out_dir):
     import torch
     import torch.distributed as dist
+    torch.cuda.init()  # before libea_hip touches the device (conftest.py `hip`)
     from edge_alignment_amd import capi, dist as ead
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     cfg = _problem()
