@@ -34,6 +34,7 @@ EXPORTED = [
     "ea_problem_set_ref_frame", "ea_problem_set_ref_frame_masked", "ea_problem_set_now_frame", "ea_problem_debug_now_frame",
     "ea_problem_set_ref_frame_canny", "ea_problem_set_now_frame_canny", "ea_problem_debug_now_frame_canny",
     "ea_problem_set_ref_frame_ros", "ea_problem_set_now_frame_ros", "ea_problem_debug_now_frame_ros",
+    "ea_problem_set_ref_frame_ros_scaled", "ea_problem_set_now_frame_ros_scaled", "ea_resize_half",
     "ea_problem_get_points", "ea_problem_get_dt",
     "ea_problem_set_distortion", "ea_problem_set_second_camera", "ea_problem_add_term", "ea_problem_clear_terms",
 ]
@@ -144,6 +145,9 @@ def load():
     L.ea_problem_set_ref_frame_masked.argtypes = [vp, u8p, u8p, u16p, C.c_int, C.c_int, C.c_double, C.c_int]
     L.ea_problem_set_ref_frame_ros.argtypes = [vp, u8p, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_double, C.c_double]
     L.ea_problem_set_now_frame_ros.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_double, C.c_double]
+    L.ea_problem_set_ref_frame_ros_scaled.argtypes = [vp, u8p, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
+    L.ea_problem_set_now_frame_ros_scaled.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
+    L.ea_resize_half.argtypes = [C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]
     L.ea_problem_debug_now_frame_ros.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_double, C.c_double, u8p, C.POINTER(C.c_float)]
     L.ea_problem_set_ref_frame_canny.argtypes = [vp, u8p, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
     L.ea_problem_set_now_frame_canny.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double]
@@ -323,20 +327,25 @@ class Problem:
                                                        dt.ctypes.data_as(C.POINTER(C.c_float)), C.byref(rounds)))
         return dict(edges=edges, chamfer=cham, dt=dt, hysteresis_launches=rounds.value)
 
-    def set_ref_frame_ros(self, bgr, depth_f32, t1=150.0, t2=100.0):
-        """SolveEA::setRefFrame on the GPU (ref: src/SolveEA.cpp:29-82)"""
+    def set_ref_frame_ros(self, bgr, depth_f32, t1=150.0, t2=100.0, halvings=0):
+        """SolveEA::setRefFrame on the GPU (ref: src/SolveEA.cpp:29-82); halvings > 0: the frames are full resolution and
+        the node's cv::resize x0.5 (NaN -> 0 on depth first, src/ea.cpp:38, :56-62) runs on the device that many times"""
         bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
         depth_f32 = np.ascontiguousarray(depth_f32, dtype=np.float32)
         H, W = depth_f32.shape
         assert bgr.shape == (H, W, 3)
-        _check(load().ea_problem_set_ref_frame_ros(self._h, bgr.ctypes.data_as(C.POINTER(C.c_uint8)),
-                                                   depth_f32.ctypes.data_as(C.POINTER(C.c_float)), H, W, t1, t2))
+        _check(load().ea_problem_set_ref_frame_ros_scaled(self._h, bgr.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                          depth_f32.ctypes.data_as(C.POINTER(C.c_float)), H, W, int(halvings), t1, t2))
 
-    def set_now_frame_ros(self, bgr, t1=150.0, t2=100.0, debug=False):
-        """SolveEA::setNowFrame on the GPU (ref: src/SolveEA.cpp:86-119)"""
+    def set_now_frame_ros(self, bgr, t1=150.0, t2=100.0, debug=False, halvings=0):
+        """SolveEA::setNowFrame on the GPU (ref: src/SolveEA.cpp:86-119); halvings as in set_ref_frame_ros"""
         bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
         H, W = bgr.shape[:2]
         u8 = C.POINTER(C.c_uint8)
+        if halvings:
+            assert not debug
+            _check(load().ea_problem_set_now_frame_ros_scaled(self._h, bgr.ctypes.data_as(u8), H, W, int(halvings), t1, t2))
+            return None
         if not debug:
             _check(load().ea_problem_set_now_frame_ros(self._h, bgr.ctypes.data_as(u8), H, W, t1, t2))
             return None
@@ -566,6 +575,21 @@ class Batch:
         v = C.c_int64()
         _check(load().ea_batch_get_info(self._h, key.encode(), C.byref(v)))
         return v.value
+
+
+def resize_half(img, nan_to_zero=False, device=0):
+    """cv::resize(img, dst, Size(), 0.5, 0.5) on the device (ea_resize_half): uint8 H x W x 3 or float32 H x W"""
+    img = np.ascontiguousarray(img)
+    if img.dtype == np.uint8:
+        assert img.ndim == 3 and img.shape[2] == 3
+        kind, out = 0, np.zeros((img.shape[0] // 2, img.shape[1] // 2, 3), np.uint8)
+    else:
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        assert img.ndim == 2
+        kind, out = (1 if nan_to_zero else 2), np.zeros((img.shape[0] // 2, img.shape[1] // 2), np.float32)
+    _check(load().ea_resize_half(device, kind, img.ctypes.data_as(C.c_void_p), img.shape[0], img.shape[1],
+                                 out.ctypes.data_as(C.c_void_p)))
+    return out
 
 
 def selftest_wave_reduce(values, device=0):

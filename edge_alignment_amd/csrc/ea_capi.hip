@@ -33,6 +33,9 @@ hipError_t launch_pad_image(int dtype, const void *src, int H, int W, void *dst,
 hipError_t launch_selftest_reduce(const float *in, float *a, float *b, float *c, float *d, double *o32, double *o64,
                                   hipStream_t stream);
 // ea_preprocess.hip
+hipError_t launch_resize_half_bgr8(const uint8_t *src, int H, int W, uint8_t *dst, hipStream_t s);
+hipError_t launch_resize_half_f32(const float *src, int H, int W, float *dst, int nan_to_zero, hipStream_t s);
+hipError_t launch_nan_to_zero(float *img, size_t n, hipStream_t s);
 hipError_t launch_edge_strength(const uint8_t *bgr, int H, int W, uint8_t *gray, uint8_t *lap, hipStream_t s);
 hipError_t launch_threshold_median(const uint8_t *lap, int H, int W, int thr, int median, uint8_t *mask, hipStream_t s);
 hipError_t launch_chamfer(const uint8_t *mask, int H, int W, int *G, int *scratch, int *dist_fix, float *dist_f32,
@@ -122,6 +125,9 @@ struct ea_problem {
   // scratch for the frame pre-processing kernels (grown on demand, reused across frames)
   unsigned char *ws = nullptr;
   size_t ws_bytes = 0;
+  // full-resolution frames on their way to a half-resolution level (ea_problem_set_*_frame_ros_scaled)
+  unsigned char *stage = nullptr;
+  size_t stage_bytes = 0;
   // what the last producer call left in the workspace: 1 = set_now_frame (Laplacian strength), 2 = set_now_frame_canny
   // (edge map, no mask), 0 = nothing reusable; with the frame's extent.  The tracker extracts the same frame's edge
   // points from it instead of uploading and filtering the frame a second time.
@@ -317,6 +323,7 @@ extern "C" void ea_problem_destroy(ea_problem *p) {
   free_points(p);
   if (p->d_dt) (void)hipFree(p->d_dt);
   if (p->ws) (void)hipFree(p->ws);
+  if (p->stage) (void)hipFree(p->stage);
   delete p;
 }
 
@@ -1855,12 +1862,61 @@ static void ros_thresholds(double t1, double t2, int *low, int *high) {
   *high = (int)std::floor(hi);
 }
 
+// Frames as the ROS callbacks receive them -> the resolution the node works at, on the device: `halvings` times
+// (depth: NaN -> 0, then) cv::resize(..., 0.5, 0.5) (src/ea.cpp:38, :56-62).  bgr / depth: host, full_h x full_w; the
+// results land in d_bgr / d_depth (device, full >> halvings).  halvings = 0: a plain upload.
+static int stage_scaled(ea_problem *p, const uint8_t *bgr, const float *depth, int full_h, int full_w, int halvings,
+                        uint8_t *d_bgr, float *d_depth) {
+  const size_t np = (size_t)full_h * full_w;
+  if (halvings == 0) {
+    HIPCHK(hipMemcpyAsync(d_bgr, bgr, np * 3, hipMemcpyHostToDevice, nullptr));
+    if (depth) HIPCHK(hipMemcpyAsync(d_depth, depth, np * 4, hipMemcpyHostToDevice, nullptr));
+    return EA_OK;
+  }
+  // stage: [bgr full | depth full | bgr half | depth half] (the ping-pong partner of the full-size pair)
+  const size_t need = np * 3 + np * 4 + np / 4 * 3 + np / 4 * 4 + 1024;
+  if (p->stage_bytes < need) {
+    if (p->stage) { (void)hipFree(p->stage); p->stage = nullptr; p->stage_bytes = 0; }
+    HIPCHK(hipMalloc(&p->stage, need));
+    p->stage_bytes = need;
+  }
+  WsCarver st{p->stage};
+  uint8_t *bgr_a = st.take<uint8_t>(np * 3), *bgr_b = nullptr;
+  float *dep_a = st.take<float>(np), *dep_b = nullptr;
+  bgr_b = st.take<uint8_t>(np / 4 * 3);
+  dep_b = st.take<float>(np / 4);
+  HIPCHK(hipMemcpyAsync(bgr_a, bgr, np * 3, hipMemcpyHostToDevice, nullptr));
+  if (depth) HIPCHK(hipMemcpyAsync(dep_a, depth, np * 4, hipMemcpyHostToDevice, nullptr));
+  int h = full_h, w = full_w;
+  for (int k = 0; k < halvings; ++k) {
+    const bool last = k == halvings - 1;
+    uint8_t *bo = last ? d_bgr : bgr_b;
+    float *dp = last ? d_depth : dep_b;
+    HIPCHK(launch_resize_half_bgr8(bgr_a, h, w, bo, nullptr));
+    if (depth) HIPCHK(launch_resize_half_f32(dep_a, h, w, dp, /*nan_to_zero=*/k == 0 ? 1 : 0, nullptr));
+    std::swap(bgr_a, bgr_b); std::swap(dep_a, dep_b);
+    h /= 2; w /= 2;
+  }
+  return EA_OK;
+}
+
+static int check_scaled_args(int height, int width, int halvings) {
+  if (halvings < 0 || halvings > 8) return fail(EA_ERR_INVALID_ARG, "halvings out of range");
+  if ((height % (1 << halvings)) != 0 || (width % (1 << halvings)) != 0)
+    return fail(EA_ERR_INVALID_ARG, "frame extent must be divisible by 2^halvings");
+  return EA_OK;
+}
+
 // SolveEA::setRefFrame (src/SolveEA.cpp:29-82): every edge pixel, depth CV_32F in metres, Z == 0 -> 1.0
-extern "C" int ea_problem_set_ref_frame_ros(ea_problem *p, const uint8_t *bgr, const float *depth, int height, int width,
-                                            double threshold1, double threshold2) {
-  int rc = check_frame_args(p, bgr, height, width);
+extern "C" int ea_problem_set_ref_frame_ros_scaled(ea_problem *p, const uint8_t *bgr, const float *depth, int full_height,
+                                                   int full_width, int halvings, double threshold1, double threshold2) {
+  int rc = check_frame_args(p, bgr, full_height, full_width);
   if (rc != EA_OK) return rc;
   if (!depth) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  rc = check_scaled_args(full_height, full_width, halvings);
+  if (rc != EA_OK) return rc;
+  const int height = full_height >> halvings, width = full_width >> halvings;
+  if (height < 3 || width < 3) return fail(EA_ERR_INVALID_ARG, "image extent out of range");
   HIPCHK(hipSetDevice(p->device));
   rc = ensure_ws(p, frame_ws_bytes(height, width));
   if (rc != EA_OK) return rc;
@@ -1871,8 +1927,8 @@ extern "C" int ea_problem_set_ref_frame_ros(ea_problem *p, const uint8_t *bgr, c
   const int nblocks = (int)((np + 1023) / 1024);
   int *d_counts = ws.take<int>(nblocks + 1);
   int *d_total = d_counts + nblocks;
-  HIPCHK(hipMemcpyAsync(d_bgr, bgr, np * 3, hipMemcpyHostToDevice, nullptr));
-  HIPCHK(hipMemcpyAsync(d_depth, depth, np * 4, hipMemcpyHostToDevice, nullptr));
+  rc = stage_scaled(p, bgr, depth, full_height, full_width, halvings, d_bgr, d_depth);
+  if (rc != EA_OK) return rc;
   int lo, hi;
   ros_thresholds(threshold1, threshold2, &lo, &hi);
   uint8_t *d_edges, *d_inv;
@@ -1893,12 +1949,21 @@ extern "C" int ea_problem_set_ref_frame_ros(ea_problem *p, const uint8_t *bgr, c
   return EA_OK;
 }
 
+extern "C" int ea_problem_set_ref_frame_ros(ea_problem *p, const uint8_t *bgr, const float *depth, int height, int width,
+                                            double threshold1, double threshold2) {
+  return ea_problem_set_ref_frame_ros_scaled(p, bgr, depth, height, width, 0, threshold1, threshold2);
+}
+
 // SolveEA::setNowFrame (src/SolveEA.cpp:86-119): Canny -> 255 - edges -> distanceTransform(L2, DIST_MASK_PRECISE) ->
 // normalize to [0, 255].  An image without a single edge has no defined result upstream either: EA_ERR_STATE.
-extern "C" int ea_problem_debug_now_frame_ros(ea_problem *p, const uint8_t *bgr, int height, int width, double threshold1,
-                                              double threshold2, uint8_t *edges_out, float *dt_out) {
-  int rc = check_frame_args(p, bgr, height, width);
+static int now_frame_ros_impl(ea_problem *p, const uint8_t *bgr, int full_height, int full_width, int halvings,
+                              double threshold1, double threshold2, uint8_t *edges_out, float *dt_out) {
+  int rc = check_frame_args(p, bgr, full_height, full_width);
   if (rc != EA_OK) return rc;
+  rc = check_scaled_args(full_height, full_width, halvings);
+  if (rc != EA_OK) return rc;
+  const int height = full_height >> halvings, width = full_width >> halvings;
+  if (height < 3 || width < 3) return fail(EA_ERR_INVALID_ARG, "image extent out of range");
   HIPCHK(hipSetDevice(p->device));
   rc = ensure_ws(p, frame_ws_bytes(height, width));
   if (rc != EA_OK) return rc;
@@ -1907,7 +1972,8 @@ extern "C" int ea_problem_debug_now_frame_ros(ea_problem *p, const uint8_t *bgr,
   uint8_t *d_bgr = ws.take<uint8_t>(np * 3);
   const int nblocks = (int)((np + 1023) / 1024);
   int *d_counts = ws.take<int>(nblocks + 1);
-  HIPCHK(hipMemcpyAsync(d_bgr, bgr, np * 3, hipMemcpyHostToDevice, nullptr));
+  rc = stage_scaled(p, bgr, nullptr, full_height, full_width, halvings, d_bgr, nullptr);
+  if (rc != EA_OK) return rc;
   int lo, hi;
   ros_thresholds(threshold1, threshold2, &lo, &hi);
   uint8_t *d_edges, *d_inv;
@@ -1926,9 +1992,41 @@ extern "C" int ea_problem_debug_now_frame_ros(ea_problem *p, const uint8_t *bgr,
   return EA_OK;
 }
 
+extern "C" int ea_problem_debug_now_frame_ros(ea_problem *p, const uint8_t *bgr, int height, int width, double threshold1,
+                                              double threshold2, uint8_t *edges_out, float *dt_out) {
+  return now_frame_ros_impl(p, bgr, height, width, 0, threshold1, threshold2, edges_out, dt_out);
+}
+
 extern "C" int ea_problem_set_now_frame_ros(ea_problem *p, const uint8_t *bgr, int height, int width, double threshold1,
                                             double threshold2) {
-  return ea_problem_debug_now_frame_ros(p, bgr, height, width, threshold1, threshold2, nullptr, nullptr);
+  return now_frame_ros_impl(p, bgr, height, width, 0, threshold1, threshold2, nullptr, nullptr);
+}
+
+extern "C" int ea_problem_set_now_frame_ros_scaled(ea_problem *p, const uint8_t *bgr, int full_height, int full_width,
+                                                   int halvings, double threshold1, double threshold2) {
+  return now_frame_ros_impl(p, bgr, full_height, full_width, halvings, threshold1, threshold2, nullptr, nullptr);
+}
+
+// The half-resolution step by itself (host in, host out) for parity checks and for callers that build pyramid levels of
+// their own: kind 0 = bgr8 (height x width x 3 bytes), 1 = float32 with NaN -> 0 first (the depth callback, src/ea.cpp:56-62),
+// 2 = float32 as is.  dst: (height / 2) x (width / 2) of the same element type.
+extern "C" int ea_resize_half(int device, int kind, const void *src, int height, int width, void *dst) {
+  if (!src || !dst) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  if (kind < 0 || kind > 2) return fail(EA_ERR_INVALID_ARG, "kind must be 0 (bgr8), 1 (float32, NaN -> 0) or 2 (float32)");
+  if (height < 2 || width < 2 || (height & 1) || (width & 1) || (int64_t)height * width > 0x3fffffff)
+    return fail(EA_ERR_INVALID_ARG, "frame extent must be even and in range");
+  int rc = check_device(device);
+  if (rc != EA_OK) return rc;
+  HIPCHK(hipSetDevice(device));
+  const size_t np = (size_t)height * width, es = kind == 0 ? 3 : 4;
+  DevBuf a, b;
+  HIPCHK(hipMalloc(&a.p, np * es));
+  HIPCHK(hipMalloc(&b.p, np / 4 * es));
+  HIPCHK(hipMemcpy(a.p, src, np * es, hipMemcpyHostToDevice));
+  if (kind == 0) HIPCHK(launch_resize_half_bgr8(a.as<uint8_t>(), height, width, b.as<uint8_t>(), nullptr));
+  else HIPCHK(launch_resize_half_f32(a.as<float>(), height, width, b.as<float>(), kind == 1 ? 1 : 0, nullptr));
+  HIPCHK(hipMemcpy(dst, b.p, np / 4 * es, hipMemcpyDeviceToHost));
+  return EA_OK;
 }
 
 extern "C" int ea_problem_set_now_frame_canny(ea_problem *p, const uint8_t *bgr, const uint8_t *mask, int height, int width,

@@ -599,7 +599,62 @@ __global__ void ea_edge_scatter_ros_kernel(const uint8_t *__restrict__ edges, co
   X[off] = (T)x; Y[off] = (T)y; Z[off] = (T)z;
 }
 
+// ---- half-resolution level: cv::resize(src, dst, cv::Size(), 0.5, 0.5) as the ROS callbacks apply it to the bgr8 colour
+// frame and to the float depth frame after NaN -> 0 (ref: src/ea.cpp:38, :56-62).  At an exact factor of two OpenCV's
+// INTER_LINEAR resize is the 2 x 2 area mean (cv::resize switches to its fast area path; the bilinear weights are 1/2, 1/2
+// anyway): 8-bit channels (a + b + c + d + 2) >> 2, float 0.25f * (((a + b) + c) + d) in the order of the generic loop.
+__global__ void ea_resize_half_bgr8_kernel(const uint8_t *__restrict__ src, int H2, int W2, uint8_t *__restrict__ dst) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;  // destination column x channel
+  const int y = blockIdx.y;
+  if (x >= W2 * 3) return;
+  const int u = x / 3, c = x - 3 * u;
+  const size_t sp = (size_t)W2 * 2 * 3;  // source pitch in bytes
+  const uint8_t *r0 = src + (size_t)(2 * y) * sp + (size_t)(2 * u) * 3 + c;
+  const uint8_t *r1 = r0 + sp;
+  dst[(size_t)y * W2 * 3 + x] = (uint8_t)(((int)r0[0] + (int)r0[3] + (int)r1[0] + (int)r1[3] + 2) >> 2);
+}
+
+__global__ void ea_resize_half_f32_kernel(const float *__restrict__ src, int H2, int W2, float *__restrict__ dst,
+                                          int nan_to_zero) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= W2) return;
+  const size_t sp = (size_t)W2 * 2;
+  const float *r0 = src + (size_t)(2 * y) * sp + 2 * x;
+  const float *r1 = r0 + sp;
+  float a = r0[0], b = r0[1], c = r1[0], d = r1[1];
+  if (nan_to_zero) {  // depth.setTo(0, depth != depth) before the resize (src/ea.cpp:56-58)
+    a = (a != a) ? 0.0f : a; b = (b != b) ? 0.0f : b; c = (c != c) ? 0.0f : c; d = (d != d) ? 0.0f : d;
+  }
+  dst[(size_t)y * W2 + x] = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(a, b), c), d), 0.25f);
+}
+
+__global__ void ea_nan_to_zero_kernel(float *__restrict__ img, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const float v = img[i]; if (v != v) img[i] = 0.0f; }
+}
+
 // ---- launchers ----------------------------------------------------------------------------------
+
+hipError_t launch_resize_half_bgr8(const uint8_t *src, int H, int W, uint8_t *dst, hipStream_t s) {
+  const int H2 = H / 2, W2 = W / 2;
+  dim3 block(256), grid((W2 * 3 + 255) / 256, H2);
+  hipLaunchKernelGGL(ea_resize_half_bgr8_kernel, grid, block, 0, s, src, H2, W2, dst);
+  return hipGetLastError();
+}
+
+hipError_t launch_resize_half_f32(const float *src, int H, int W, float *dst, int nan_to_zero, hipStream_t s) {
+  const int H2 = H / 2, W2 = W / 2;
+  dim3 block(256), grid((W2 + 255) / 256, H2);
+  hipLaunchKernelGGL(ea_resize_half_f32_kernel, grid, block, 0, s, src, H2, W2, dst, nan_to_zero);
+  return hipGetLastError();
+}
+
+hipError_t launch_nan_to_zero(float *img, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(ea_nan_to_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, img, n);
+  return hipGetLastError();
+}
+
 
 hipError_t launch_edge_strength(const uint8_t *bgr, int H, int W, uint8_t *gray, uint8_t *lap, hipStream_t s) {
   dim3 block(256), grid((W + 255) / 256, H);

@@ -6,8 +6,8 @@
 //     problem.AddResidualBlock(cost, new CauchyLoss(1.), b_quat_a, b_t_a);
 // The functor no longer computes anything per call through dual numbers: it carries the block's
 // constants, and ceres::Solve (facade, ceres/ceres.h) evaluates all blocks at once in the gfx950
-// kernels behind include/ea_hip.h.  operator()<double> is kept for host-side spot checks and
-// follows the reference text line by line (utils.h:48-80).
+// kernels behind include/ea_hip.h.  The templated operator() is kept, instantiable for double and for ceres::Jet, for
+// host-side spot checks; it follows the reference text line by line (utils.h:48-80).
 #pragma once
 #include "ceres/ceres.h"
 
@@ -19,17 +19,24 @@ class EAResidue {
             const double a_Xy, const double a_Xz, const Interpolator &__interpolated_a)
       : interp_a(__interpolated_a), fx(fx), fy(fy), cx(cx), cy(cy), a_Xx(a_Xx), a_Xy(a_Xy), a_Xz(a_Xz) {}
 
-  // scalar evaluation (no derivatives) — host-side probe only
-  bool operator()(const double *const quat, const double *const t, double *residue) const {
-    const double w = quat[0], x = quat[1], y = quat[2], z = quat[3];
-    const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
-                         2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
-                         2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
-    const double bx = R[0] * a_Xx + R[1] * a_Xy + R[2] * a_Xz + t[0];
-    const double by = R[3] * a_Xx + R[4] * a_Xy + R[5] * a_Xz + t[1];
-    const double bz = R[6] * a_Xx + R[7] * a_Xy + R[8] * a_Xz + t[2];
-    if (bz < 0.01 && bz > -0.01) return false;
-    interp_a.Evaluate(fx * bx / bz + cx, fy * by / bz + cy, &residue[0]);
+  // The reference's call operator, `template <typename T>` as upstream (utils.h:47-80): b = R(q) a + t with Eigen's
+  // un-normalised toRotationMatrix formula written out (:51-53), the |b_z| < 0.01 guard (:70-73), pinhole (:74-75), the
+  // interpolator (:77).  T = double samples the DT on the host; T = ceres::Jet<double, 7> also yields d r / d (q, t).
+  // A host-side probe: ceres::Solve never calls it, every block is evaluated by the gfx950 kernels.
+  template <typename T>
+  bool operator()(const T *const quat, const T *const t, T *residue) const {
+    const T w = quat[0], x = quat[1], y = quat[2], z = quat[3];
+    const T one(1.0), two(2.0);
+    const T R[9] = {one - two * (y * y + z * z), two * (x * y - w * z), two * (x * z + w * y),
+                    two * (x * y + w * z), one - two * (x * x + z * z), two * (y * z - w * x),
+                    two * (x * z - w * y), two * (y * z + w * x), one - two * (x * x + y * y)};
+    const T bx = R[0] * T(a_Xx) + R[1] * T(a_Xy) + R[2] * T(a_Xz) + t[0];
+    const T by = R[3] * T(a_Xx) + R[4] * T(a_Xy) + R[5] * T(a_Xz) + t[1];
+    const T bz = R[6] * T(a_Xx) + R[7] * T(a_Xy) + R[8] * T(a_Xz) + t[2];
+    if (bz < T(0.01) && bz > T(-0.01)) return false;
+    const T _u = T(fx) * bx / bz + T(cx);
+    const T _v = T(fy) * by / bz + T(cy);
+    interp_a.Evaluate(_u, _v, &residue[0]);
     return true;
   }
 

@@ -21,7 +21,9 @@
 
 #include "../../../include/ea_hip.h"
 #include "cubic_interpolation.h"
+#include "jet.h"
 #include "loss_function.h"
+#include "rotation.h"
 
 namespace ceres {
 

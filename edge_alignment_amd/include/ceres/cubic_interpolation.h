@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <cmath>
 
+#include "jet.h"
+
 namespace ceres {
 
 template <typename T, int kDataDimension = 1, bool kRowMajor = true, bool kInterleaved = true>
@@ -49,6 +51,16 @@ class BiCubicInterpolator {
     }
     Spline(fk[0], fk[1], fk[2], fk[3], r - row, f, dfdr);
     if (dfdc) Spline(dk[0], dk[1], dk[2], dk[3], r - row, dfdc, nullptr);
+  }
+
+  // the overload Ceres provides for automatic differentiation: value from the scalar parts, derivatives by the chain
+  // rule through dfdr, dfdc (ceres/cubic_interpolation.h, BiCubicInterpolator::Evaluate(const JetT&, const JetT&, JetT*))
+  template <typename T, int N>
+  void Evaluate(const Jet<T, N> &r, const Jet<T, N> &c, Jet<T, N> *f) const {
+    double frc, dfdr, dfdc;
+    Evaluate(static_cast<double>(r.a), static_cast<double>(c.a), &frc, &dfdr, &dfdc);
+    f->a = T(frc);
+    for (int i = 0; i < N; ++i) f->v[i] = T(dfdr) * r.v[i] + T(dfdc) * c.v[i];
   }
 
  private:

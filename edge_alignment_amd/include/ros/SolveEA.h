@@ -1,28 +1,30 @@
 // ros/SolveEA.h — drop-in for include/SolveEA.h:36-71 + src/SolveEA.cpp of kuwt/edge_alignment.
 //
-// Public surface kept: SolveEA(), setRefFrame(rgb, depth), setNowFrame(rgb, depth),
-// setAsCERESProblem(), _verify3dPts(), _sampleCERESProblem()  (src/ea.cpp:184-191 calls them in
-// that order).  The cv::Mat overloads exist only when OpenCV headers are present (they are not in
-// this image) and keep upstream's OpenCV calls.  The raw-buffer overloads of setRefFrame / setNowFrame
-// (bgr8 + float32 depth, what the cv::Mat arguments hold) run the same pre-processing on the GPU
-// (ea_problem_set_ref_frame_ros / ea_problem_set_now_frame_ros: Canny(150, 100, 3, true) on the 3-channel
-// image, DIST_MASK_PRECISE, normalisation to [0, 255], Z == 0 -> 1) and feed the same members.
-// setAsCERESProblem() — the residual blocks, the loss, the parameterisation and the DOGLEG solve
-// (src/SolveEA.cpp:124-216) — runs on the GPU through the ceres:: facade.
-// Upstream never returns the pose (App. D 4): getPose()/summary() are additions.
+// Public surface kept: SolveEA(), setRefFrame(rgb, depth), setNowFrame(rgb, depth), setAsCERESProblem(),
+// _verify3dPts(), _sampleCERESProblem()  (src/ea.cpp:184-191 calls them in that order).
+//
+// Frames stay on the device.  setRefFrame / setNowFrame hand the frame to the GPU producers
+// (ea_problem_set_ref_frame_ros / ea_problem_set_now_frame_ros: Canny(150, 100, 3, true) on the 3-channel image, every
+// edge pixel back-projected with Z == 0 -> 1; 255 - edges -> DIST_MASK_PRECISE -> [0, 255]) of ONE ea_problem this
+// object owns; the edge points and the distance transform are written where the solve reads them, and
+// setAsCERESProblem() — upstream's residual blocks, NULL loss, quaternion parameterisation and DOGLEG solve with 25
+// iterations (src/SolveEA.cpp:124-216) — is one ea_solve on that problem.  Nothing is copied back to the host between
+// the three calls (round 1 read points and DT back and uploaded them again through the ceres:: facade).
+//
+// The frame arguments are templates over "anything shaped like a cv::Mat" (.data, .rows, .cols, .isContinuous()):
+// with OpenCV present `setRefFrame(const cv::Mat&, const cv::Mat&)` binds to them unchanged; this header needs no OpenCV.
+// rgb: bgr8 (CV_8UC3), depth: float32 metres (CV_32F), NaN already zeroed by the caller as upstream's callback does.
+// With halvings() > 0 the frames are taken at the resolution the ROS callbacks RECEIVE them and the node's
+// cv::resize(..., 0.5, 0.5) (src/ea.cpp:38, :56-62: NaN -> 0 first on depth) runs on the device too.
+//
+// setRefPoints / setNowDistanceTransform keep the host-data path (list_edge_ref / now_dist_transform_eig filled by the
+// caller): those go through the ceres:: facade as upstream's setAsCERESProblem body does.
+// Upstream never returns the pose: getPose() / summary() are additions.
 #pragma once
 #include <cstdio>
 #include <vector>
 
 #include "EAResidue.h"
-
-#if defined(__has_include)
-#if __has_include(<opencv2/core/core.hpp>) && __has_include(<opencv2/imgproc/imgproc.hpp>)
-#include <opencv2/core/core.hpp>
-#include <opencv2/imgproc/imgproc.hpp>
-#define EA_HAVE_OPENCV 1
-#endif
-#endif
 
 class SolveEA {
  public:
@@ -38,82 +40,63 @@ class SolveEA {
     K.m[0] = fx; K.m[4] = fy; K.m[2] = cx; K.m[5] = cy; K.m[8] = 1.0;
     q_[0] = 1; q_[1] = q_[2] = q_[3] = 0; t_[0] = t_[1] = t_[2] = 0;
   }
+  ~SolveEA() { if (dev_) ea_problem_destroy(dev_); }
+  SolveEA(const SolveEA &) = delete;
+  SolveEA &operator=(const SolveEA &) = delete;
 
-#ifdef EA_HAVE_OPENCV
-  // src/SolveEA.cpp:29-82
-  void setRefFrame(const cv::Mat &rgb, const cv::Mat &depth) {
-    cv::Mat edge;
-    cv::Canny(rgb, edge, 150, 100, 3, true);
-    std::vector<double> pts;
-    for (int yy = 0; yy < rgb.rows; yy++)
-      for (int xx = 0; xx < rgb.cols; xx++)
-        if (edge.at<uchar>(yy, xx) > 0) {
-          double Z = depth.at<float>(yy, xx);
-          Z = (Z == 0) ? 1.0 : Z;
-          pts.push_back(Z * (xx - cx) / fx); pts.push_back(Z * (yy - cy) / fy); pts.push_back(Z);
-        }
-    setRefPoints(pts.data(), (int)(pts.size() / 3));
+  // src/SolveEA.cpp:29-82 / :86-119 with cv::Mat-shaped arguments
+  template <typename Mat>
+  void setRefFrame(const Mat &rgb, const Mat &depth) {
+    if (!rgb.isContinuous() || !depth.isContinuous()) { std::fprintf(stderr, "SolveEA::setRefFrame: continuous frames expected\n"); return; }
+    if (!setRefFrame(reinterpret_cast<const unsigned char *>(rgb.data), reinterpret_cast<const float *>(depth.data), rgb.rows, rgb.cols))
+      std::fprintf(stderr, "SolveEA::setRefFrame: %s\n", ea_last_error());
   }
-  // src/SolveEA.cpp:86-119
-  void setNowFrame(const cv::Mat &rgb, const cv::Mat & /*depth*/) {
-    cv::Mat edge, dist;
-    cv::Canny(rgb, edge, 150, 100, 3, true);
-    edge = 255 - edge;
-    cv::distanceTransform(edge, dist, cv::DIST_L2, cv::DIST_MASK_PRECISE);
-    cv::normalize(dist, dist, 0.0, 255.0, cv::NORM_MINMAX);
-    std::vector<double> colmajor((size_t)dist.rows * dist.cols);
-    for (int c = 0; c < dist.cols; ++c)
-      for (int r = 0; r < dist.rows; ++r) colmajor[(size_t)c * dist.rows + r] = dist.at<float>(r, c);
-    setNowDistanceTransform(colmajor.data(), dist.rows, dist.cols);
+  template <typename Mat>
+  void setNowFrame(const Mat &rgb, const Mat &depth) {
+    if (!rgb.isContinuous()) { std::fprintf(stderr, "SolveEA::setNowFrame: continuous frame expected\n"); return; }
+    if (!setNowFrame(reinterpret_cast<const unsigned char *>(rgb.data), reinterpret_cast<const float *>(depth.data), rgb.rows, rgb.cols))
+      std::fprintf(stderr, "SolveEA::setNowFrame: %s\n", ea_last_error());
   }
-#endif
 
-  // OpenCV-free forms of the same two calls (src/SolveEA.cpp:29-82, :86-119), pre-processing on the GPU.
-  // bgr: rows x cols x 3 bytes (bgr8, src/ea.cpp:34), depth: rows x cols float32 metres (NaN already set to 0, :56-58).
-  // Return false (and leave the members untouched) when the library reports an error, e.g. a frame without edges.
+  // the same two calls on raw buffers.  bgr: rows x cols x 3 bytes (bgr8, src/ea.cpp:34), depth: rows x cols float32
+  // metres; rows x cols is the resolution of the buffers (full resolution when halvings() > 0).
+  // Return false when the library reports an error (ea_last_error()), e.g. a frame without edges.
   bool setRefFrame(const unsigned char *bgr, const float *depth, int rows, int cols) {
-    ea_problem *p = nullptr;
-    const ea_camera cam = {fx, fy, cx, cy};
-    if (ea_problem_create(&p, &cam, EA_F64, 0) != EA_OK) return false;
-    bool ok = ea_problem_set_ref_frame_ros(p, bgr, depth, rows, cols, 150, 100) == EA_OK;
-    if (ok) {
-      const long long n = ea_problem_num_points(p);
-      std::vector<double> pts((size_t)3 * (size_t)n);
-      ok = ea_problem_get_points(p, pts.data(), n) == EA_OK;
-      if (ok) setRefPoints(pts.data(), (int)n);
-    }
-    ea_problem_destroy(p);
-    return ok;
+    if (!device_problem()) return false;
+    host_points_ = false;
+    have_ref_ = ea_problem_set_ref_frame_ros_scaled(dev_, bgr, depth, rows, cols, halvings_, 150, 100) == EA_OK;
+    return have_ref_;
   }
   bool setNowFrame(const unsigned char *bgr, const float * /*depth*/, int rows, int cols) {
-    ea_problem *p = nullptr;
-    const ea_camera cam = {fx, fy, cx, cy};
-    if (ea_problem_create(&p, &cam, EA_F64, 0) != EA_OK) return false;
-    bool ok = ea_problem_set_now_frame_ros(p, bgr, rows, cols, 150, 100) == EA_OK;
-    if (ok) {
-      std::vector<double> img((size_t)rows * cols), colmajor((size_t)rows * cols);
-      int h = 0, w = 0;
-      ok = ea_problem_get_dt(p, img.data(), &h, &w) == EA_OK && h == rows && w == cols;
-      if (ok) {
-        for (int c = 0; c < cols; ++c)
-          for (int r = 0; r < rows; ++r) colmajor[(size_t)c * rows + r] = img[(size_t)r * cols + c];
-        setNowDistanceTransform(colmajor.data(), rows, cols);
-      }
-    }
-    ea_problem_destroy(p);
-    return ok;
+    if (!device_problem()) return false;
+    host_dt_ = false;
+    have_now_ = ea_problem_set_now_frame_ros_scaled(dev_, bgr, rows, cols, halvings_, 150, 100) == EA_OK;
+    return have_now_;
   }
+  // frames arrive at 2^n times the working resolution: reduce them on the device first (src/ea.cpp:38, :62: n = 1)
+  void setHalvings(int n) { halvings_ = n < 0 ? 0 : n; }
+  int halvings() const { return halvings_; }
 
-  // list_edge_ref: 3 x N, column-major (src/SolveEA.cpp:55,73-75)
-  void setRefPoints(const double *xyz_3xN, int N) { list_edge_ref.assign(xyz_3xN, xyz_3xN + 3 * (size_t)N); }
+  // host-data path — list_edge_ref: 3 x N, column-major (src/SolveEA.cpp:55,73-75)
+  void setRefPoints(const double *xyz_3xN, int N) {
+    list_edge_ref.assign(xyz_3xN, xyz_3xN + 3 * (size_t)N);
+    host_points_ = true;
+  }
   // now_dist_transform_eig: rows x cols, column-major like Eigen::MatrixXd (src/SolveEA.cpp:110)
   void setNowDistanceTransform(const double *colmajor, int rows, int cols) {
     dt_rows = rows; dt_cols = cols;
     now_dist_transform_eig.assign(colmajor, colmajor + (size_t)rows * cols);
+    host_dt_ = true;
   }
 
   // src/SolveEA.cpp:124-216
   void setAsCERESProblem() {
+    if (!host_points_ && !host_dt_ && have_ref_ && have_now_) { solve_on_device(); return; }
+    if (!host_points_ || !host_dt_) {
+      // one input lives on the device, the other came from the host: bring the device one over (rare, explicit)
+      if (!host_points_ && have_ref_) fetch_points();
+      if (!host_dt_ && have_now_) fetch_dt();
+    }
     double q_cap[4] = {1, 0, 0, 0};
     double t_cap[3] = {0, 0, 0};
     ceres::Problem problem;
@@ -122,12 +105,11 @@ class SolveEA {
     ceres::Grid2D<double, 1> grid(now_dist_transform_eig.data(), 0, dt_cols, 0, dt_rows);
     ceres::BiCubicInterpolator<ceres::Grid2D<double, 1>> interpolated_cost_function(grid);
     const int N = (int)(list_edge_ref.size() / 3);
-    for (int ir = 0; ir < N; ir++) {
-      const double curX = list_edge_ref[3 * ir], curY = list_edge_ref[3 * ir + 1], curZ = list_edge_ref[3 * ir + 2];
-      problem.AddResidualBlock(new ceres::AutoDiffCostFunction<EAResidue, 1, 4, 3>(
-                                   new EAResidue(curX, curY, curZ, interpolated_cost_function, K)),
+    for (int ir = 0; ir < N; ir++)
+      problem.AddResidualBlock(new ceres::AutoDiffCostFunction<EAResidue, 1, 4, 3>(new EAResidue(
+                                   list_edge_ref[3 * ir], list_edge_ref[3 * ir + 1], list_edge_ref[3 * ir + 2],
+                                   interpolated_cost_function, K)),
                                NULL, q_cap, t_cap);
-    }
     problem.SetParameterization(q_cap, new ceres::QuaternionParameterization);
     ceres::Solver::Options options;
     options.max_num_iterations = 25;
@@ -155,12 +137,69 @@ class SolveEA {
     for (int i = 0; i < 3; i++) t[i] = t_[i];
   }
   const ceres::Solver::Summary &summary() const { return summary_; }
-  int numRefPoints() const { return (int)(list_edge_ref.size() / 3); }
+  int numRefPoints() const {
+    return (!host_points_ && dev_ && have_ref_) ? (int)ea_problem_num_points(dev_) : (int)(list_edge_ref.size() / 3);
+  }
   bool verbose = false;
 
  private:
+  bool device_problem() {
+    if (dev_) return true;
+    const ea_camera cam = {fx, fy, cx, cy};
+    if (ea_problem_create(&dev_, &cam, EA_F64, 0) != EA_OK) { dev_ = nullptr; return false; }
+    // this flavour's functor: R applied transposed, divisor z + 0.001, no guard (include/EAResidue.h:90-105 upstream);
+    // loss NULL (src/SolveEA.cpp:171)
+    return ea_problem_set_flavour(dev_, 0.0, 0.001, 1) == EA_OK && ea_problem_set_loss(dev_, EA_LOSS_TRIVIAL, 1.0) == EA_OK;
+  }
+  // setAsCERESProblem's set-up block as options of one device solve (src/SolveEA.cpp:130-131, :184-198)
+  void solve_on_device() {
+    double q_cap[4] = {1, 0, 0, 0};
+    double t_cap[3] = {0, 0, 0};
+    ea_options o;
+    ea_default_options(&o);
+    o.max_num_iterations = 25;
+    o.strategy = EA_STRATEGY_DOGLEG;
+    o.minimizer_progress_to_stdout = verbose ? 1 : 0;
+    ceres::Solver::Summary s;
+    s.num_residual_blocks = s.num_residuals = (int)ea_problem_num_points(dev_);
+    if (ea_solve(dev_, &o, q_cap, t_cap, &s.detail) != EA_OK) {
+      s.termination_type = ceres::FAILURE;
+      s.message = std::string("libea_hip: ") + ea_last_error();
+    } else {
+      s.termination_type = s.detail.termination == EA_CONVERGENCE ? ceres::CONVERGENCE
+                           : (s.detail.termination == EA_NO_CONVERGENCE ? ceres::NO_CONVERGENCE : ceres::FAILURE);
+      s.message = ceres::internal::WhyMessage(s.detail.why);
+      s.initial_cost = s.detail.initial_cost;
+      s.final_cost = s.detail.final_cost;
+      s.num_successful_steps = s.detail.num_successful_steps;
+      s.num_unsuccessful_steps = s.detail.num_unsuccessful_steps;
+      s.total_time_in_seconds = s.detail.total_time_ms * 1e-3;
+    }
+    summary_ = s;
+    if (verbose) std::printf("%s\n", summary_.FullReport().c_str());
+    for (int i = 0; i < 4; i++) q_[i] = q_cap[i];
+    for (int i = 0; i < 3; i++) t_[i] = t_cap[i];
+  }
+  void fetch_points() {
+    const long long n = ea_problem_num_points(dev_);
+    std::vector<double> pts((size_t)3 * (size_t)n);
+    if (ea_problem_get_points(dev_, pts.data(), n) == EA_OK) setRefPoints(pts.data(), (int)n);
+  }
+  void fetch_dt() {
+    int h = 0, w = 0;
+    if (ea_problem_get_dt(dev_, nullptr, &h, &w) != EA_OK) return;
+    std::vector<double> img((size_t)h * w), colmajor((size_t)h * w);
+    if (ea_problem_get_dt(dev_, img.data(), nullptr, nullptr) != EA_OK) return;
+    for (int c = 0; c < w; ++c)
+      for (int r = 0; r < h; ++r) colmajor[(size_t)c * h + r] = img[(size_t)r * w + c];
+    setNowDistanceTransform(colmajor.data(), h, w);
+  }
+
   Intrinsics K;
   double fx, fy, cx, cy;
+  ea_problem *dev_ = nullptr;
+  bool have_ref_ = false, have_now_ = false, host_points_ = false, host_dt_ = false;
+  int halvings_ = 0;
   std::vector<double> list_edge_ref;
   std::vector<double> now_dist_transform_eig;
   int dt_rows = 0, dt_cols = 0;

@@ -2,8 +2,10 @@
 // setAsCERESProblem) on raw frames: bgr8 + float32 depth buffers, what the ROS callbacks hold after
 // cv_bridge / resize (src/ea.cpp:30-64).  Pre-processing and solve both run on the GPU.
 // input file: int32 rows, cols | ref bgr (rows*cols*3 bytes) | ref depth (rows*cols float32) | now bgr
+// usage: ros_frames_demo frames.bin [halvings]   (halvings > 0: the file holds full-resolution frames)
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "ros/SolveEA.h"
@@ -21,9 +23,18 @@ int main(int argc, char **argv) {
   if (std::fread(ref_depth.data(), 4, np, f) != np) return 2;
   if (std::fread(now_im.data(), 1, np * 3, f) != np * 3) return 2;
   std::fclose(f);
+  // a stand-in with cv::Mat's shape (data, rows, cols, isContinuous()): the calls below are src/ea.cpp:184-191 verbatim
+  struct Mat {
+    unsigned char *data; int rows, cols;
+    bool isContinuous() const { return true; }
+  };
+  Mat ref_im_m = {ref_im.data(), rows, cols}, now_im_m = {now_im.data(), rows, cols};
+  Mat ref_depth_m = {reinterpret_cast<unsigned char *>(ref_depth.data()), rows, cols};
   SolveEA *ea = new SolveEA();
-  if (!ea->setRefFrame(ref_im.data(), ref_depth.data(), rows, cols)) { std::fprintf(stderr, "setRefFrame: %s\n", ea_last_error()); return 1; }
-  if (!ea->setNowFrame(now_im.data(), ref_depth.data(), rows, cols)) { std::fprintf(stderr, "setNowFrame: %s\n", ea_last_error()); return 1; }
+  if (argc > 2) ea->setHalvings(std::atoi(argv[2]));   // frames at 2^n x the working resolution: resized on the device
+  ea->setRefFrame(ref_im_m, ref_depth_m);
+  ea->setNowFrame(now_im_m, ref_depth_m);
+  if (ea->numRefPoints() == 0) { std::fprintf(stderr, "no reference points: %s\n", ea_last_error()); return 1; }
   ea->_verify3dPts();
   ea->setAsCERESProblem();
   double q[4], t[3];

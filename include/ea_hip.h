@@ -320,6 +320,19 @@ int ea_problem_set_now_frame_ros(ea_problem *p, const uint8_t *bgr, int height, 
                                  double threshold2);
 int ea_problem_debug_now_frame_ros(ea_problem *p, const uint8_t *bgr, int height, int width, double threshold1,
                                    double threshold2, uint8_t *edges_out, float *dt_out);
+/* The same two producers fed with the frames as the ROS callbacks RECEIVE them (full resolution), the node's reduction to
+ * its working resolution done on the device first: `halvings` times cv::resize(src, dst, cv::Size(), 0.5, 0.5) -- the
+ * 2 x 2 area mean OpenCV's linear resize is at an exact factor of two -- on the bgr8 frame and on the float32 depth frame
+ * after NaN -> 0 (src/ea.cpp:38, :56-62).  full_height / full_width must be divisible by 2^halvings; the problem's
+ * intrinsics are those of the working resolution (SolveEA's constructor: TUM x 0.5, src/SolveEA.cpp:15-18).  With
+ * halvings = 0..L these calls build the levels of ea_solve_pyramid from one pair of full-resolution frames. */
+int ea_problem_set_ref_frame_ros_scaled(ea_problem *p, const uint8_t *bgr, const float *depth, int full_height,
+                                        int full_width, int halvings, double threshold1, double threshold2);
+int ea_problem_set_now_frame_ros_scaled(ea_problem *p, const uint8_t *bgr, int full_height, int full_width, int halvings,
+                                        double threshold1, double threshold2);
+/* the half-resolution step by itself, host in / host out: kind 0 = bgr8 (height x width x 3 bytes), 1 = float32 with
+ * NaN -> 0 first, 2 = float32 as is; dst = (height / 2) x (width / 2); height and width even */
+int ea_resize_half(int device, int kind, const void *src, int height, int width, void *dst);
 /* read back what the problem holds in HBM: points (n x 3 doubles), DT image (H x W doubles, [v][u]) */
 int ea_problem_get_points(ea_problem *p, double *xyz, int64_t capacity);
 int ea_problem_get_dt(ea_problem *p, double *image, int *height, int *width);

@@ -311,6 +311,30 @@ def get_aX_canny(img_bgr, depth_u16, fx, fy, cx, cy, z_scaling=5000.0):
     return a_X, (vv, uu)
 
 
+def resize_half_bgr8(img_u8):
+    """cv::resize(im, im_resized, cv::Size(), 0.5, 0.5) on a bgr8 frame (ref: src/ea.cpp:38).  At an exact factor of two
+    OpenCV's INTER_LINEAR resize is its fast 2 x 2 area mean (cv::resize switches to INTER_AREA there; the fixed-point
+    bilinear path gives the same numbers: weights 1024/2048 twice): (a + b + c + d + 2) >> 2 per channel."""
+    a = img_u8.astype(np.int32)
+    H, W = a.shape[0] // 2 * 2, a.shape[1] // 2 * 2
+    a = a[:H, :W]
+    s = a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2]
+    return ((s + 2) >> 2).astype(np.uint8)
+
+
+def resize_half_f32(img_f32, nan_to_zero=True):
+    """the depth callback (ref: src/ea.cpp:56-62): depth.setTo(0, depth != depth), then cv::resize x0.5 on CV_32F = the
+    area mean in float32, summed in the order of OpenCV's generic loop: 0.25f * (((a + b) + c) + d)."""
+    a = np.array(img_f32, dtype=np.float32, copy=True)
+    if nan_to_zero:
+        a[np.isnan(a)] = np.float32(0)
+    H, W = a.shape[0] // 2 * 2, a.shape[1] // 2 * 2
+    a = a[:H, :W]
+    s = ((a[0::2, 0::2] + a[0::2, 1::2]).astype(np.float32) + a[1::2, 0::2]).astype(np.float32)
+    s = (s + a[1::2, 1::2]).astype(np.float32)
+    return (s * np.float32(0.25)).astype(np.float32)
+
+
 def grid_view_of_image(dt_hw):
     """What `ceres::Grid2D<double,1> grid(e.data(), 0, e.cols(), 0, e.rows())` sees after
     cv::cv2eigen into a column-major Eigen::MatrixXd (standalone_edge_align.cpp:205-206,258):

@@ -99,6 +99,37 @@ def test_ros_frames_through_solve_ea(binaries, oracle, tmp_path):
     assert int(v[7]) == so["termination"]
 
 
+def test_ros_frames_full_resolution_resized_on_device(binaries, oracle, tmp_path):
+    """The same call sequence fed with the frames as the callbacks receive them (640 x 480): SolveEA::setHalvings(1)
+    moves the node's cv::resize(..., 0.5, 0.5) (src/ea.cpp:38, :56-62) onto the device; frames, edge points and distance
+    transform never come back to the host between setRefFrame and the pose.  Checked against the oracle's DOGLEG solve on
+    the restated pre-processing (numpy resize, Canny, exact EDT)."""
+    from oracle import preprocess_np as pp
+    G = os.path.join(ROOT, "tests", "golden", "rgbd")
+    ref = pp.load_rgb_as_bgr(os.path.join(G, "rgb_1.png"))
+    now = pp.load_rgb_as_bgr(os.path.join(G, "rgb_2.png"))
+    depth = (pp.load_depth_u16(os.path.join(G, "depth_1.png")).astype(np.float32) / np.float32(5000.0)).copy()
+    rows, cols = depth.shape
+    path = str(tmp_path / "frames_full.bin")
+    with open(path, "wb") as f:
+        f.write(struct.pack("<ii", rows, cols))
+        f.write(ref.tobytes()); f.write(depth.tobytes()); f.write(now.tobytes())
+    out = subprocess.run([os.path.join(binaries, "ros_frames_demo"), path, "1"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    v = [float(x) for x in out.stdout.strip().split("\n")[-1].split()]
+    q, t = np.array(v[:4]), np.array(v[4:7])
+    Kh = (262.5, 262.5, 159.75, 119.75)
+    ref_h, now_h, depth_h = pp.resize_half_bgr8(ref), pp.resize_half_bgr8(now), pp.resize_half_f32(depth)
+    pts, _ = pp.ros_ref_points(ref_h, depth_h, *Kh)
+    assert int(v[8]) == pts.shape[1] > 5000
+    dt = pp.ros_now_distance_transform(now_h)
+    O = oracle.OracleProblem(pp.grid_view_of_image(dt), *Kh, loss=oracle.LOSS_TRIVIAL, z_guard=0.0, z_eps=0.001,
+                             rot_transposed=True)
+    qo, to, so = O.solve(pts.T.copy(), [1, 0, 0, 0], [0, 0, 0], strategy=oracle.STRATEGY_DOGLEG, max_num_iterations=25)
+    assert synth.rotation_angle_between(q, qo) < 1e-7 and np.linalg.norm(t - to) < 1e-7
+    assert int(v[7]) == so["termination"]
+
+
 @pytest.mark.parametrize("ex", [False, True])
 def test_stereo_call_sequence(binaries, oracle, tmp_path, ex):
     """standalone_edge_align.cpp:778-815 (EAResidue + EAResidueSecondCam, CauchyLoss) and :3195-3233

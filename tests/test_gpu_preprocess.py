@@ -366,3 +366,55 @@ def test_random_frame_sizes_all_flavours(hip, frames):
         with pytest.raises(Exception):
             P.set_now_frame(np.zeros((H, W, 3), np.uint8))
     P.close()
+
+
+# ---- the node's half-resolution step on the device (src/ea.cpp:38, :56-62) ------------------------------------------
+
+def test_resize_half_bit_exact(hip):
+    from oracle import preprocess_np as pp
+    rng = np.random.default_rng(21)
+    G = os.path.join(ROOT, "tests", "golden", "rgbd")
+    frames = [pp.load_rgb_as_bgr(os.path.join(G, "rgb_1.png")), rng.integers(0, 256, (62, 94, 3), dtype=np.uint8),
+              np.full((4, 6, 3), 255, np.uint8)]
+    for im in frames:
+        assert np.array_equal(hip.resize_half(im), pp.resize_half_bgr8(im))
+    d = pp.load_depth_u16(os.path.join(G, "depth_1.png")).astype(np.float32) / np.float32(5000.0)
+    d2 = d.copy(); d2[rng.random(d.shape) < 0.05] = np.nan           # the callback's invalid depths
+    for dep, nz in ((d, True), (d2, True), (rng.normal(size=(30, 44)).astype(np.float32), False)):
+        got, want = hip.resize_half(dep, nan_to_zero=nz), pp.resize_half_f32(dep, nan_to_zero=nz)
+        assert not np.isnan(got).any() and np.array_equal(got, want)
+    with pytest.raises(hip.EAError):
+        hip.resize_half(np.zeros((5, 6, 3), np.uint8))               # odd extent
+
+
+def test_ros_producers_from_full_resolution_frames(hip, oracle):
+    """Full-resolution frames -> x0.5 on the device -> ROS producers -> DOGLEG solve, against the same chain with the
+    x0.5 done by the numpy restatement on the host: identical points, identical DT, identical pose.  Two halvings build
+    the next pyramid level the same way."""
+    from oracle import preprocess_np as pp
+    G = os.path.join(ROOT, "tests", "golden", "rgbd")
+    ref = pp.load_rgb_as_bgr(os.path.join(G, "rgb_1.png"))
+    now = pp.load_rgb_as_bgr(os.path.join(G, "rgb_2.png"))
+    depth = pp.load_depth_u16(os.path.join(G, "depth_1.png")).astype(np.float32) / np.float32(5000.0)
+    depth[::7, ::5] = np.nan
+    for halvings in (1, 2):
+        r, n, d = ref, now, depth
+        for k in range(halvings):
+            r, n = pp.resize_half_bgr8(r), pp.resize_half_bgr8(n)
+            d = pp.resize_half_f32(d, nan_to_zero=(k == 0))
+        s = 0.5 ** halvings
+        Kl = (525.0 * s, 525.0 * s, 319.5 * s, 239.5 * s)          # src/SolveEA.cpp:15-18 scales all four
+        A, B = hip.Problem(*Kl), hip.Problem(*Kl)
+        for P in (A, B):
+            P.set_flavour(z_guard=0.0, z_eps=0.001, rot_transposed=True); P.set_loss(hip.LOSS_TRIVIAL, 1.0)
+        A.set_ref_frame_ros(ref, depth, halvings=halvings); A.set_now_frame_ros(now, halvings=halvings)
+        B.set_ref_frame_ros(r, d); B.set_now_frame_ros(n)
+        assert A.num_points == B.num_points > 1000
+        assert np.array_equal(A.get_points(), B.get_points()) and np.array_equal(A.get_dt(), B.get_dt())
+        qa, ta, sa = A.solve([1, 0, 0, 0], [0, 0, 0], strategy=hip.STRATEGY_DOGLEG, max_num_iterations=25)
+        qb, tb, sb = B.solve([1, 0, 0, 0], [0, 0, 0], strategy=hip.STRATEGY_DOGLEG, max_num_iterations=25)
+        assert np.array_equal(qa, qb) and np.array_equal(ta, tb) and sa["num_iterations"] == sb["num_iterations"]
+        A.close(); B.close()
+    with pytest.raises(hip.EAError):
+        P = hip.Problem(*Kl)
+        P.set_now_frame_ros(now[:478], halvings=2)                   # 478 is not divisible by 4
