@@ -48,6 +48,29 @@ def build_workload(name, seed_offset):
     return cfg, dtype, tag, loss, desc
 
 
+SIMDS = 256 * 4                # MI355X: 256 CUs x 4 SIMDs
+VALU_PEAK_IPS = SIMDS * 2.4e9 / 2.0  # one wave64 vector instruction per 2 cycles and SIMD at 2.4 GHz (guide: v_fma_f32 2 cyc)
+
+
+def valu_issue(workload_key, kernel_ms):
+    """Second bound of the same kernel: vector-instruction issue.  SQ_INSTS_VALU per launch comes from
+    the committed PMC pass (profiles/pmc_valu.json), the duration is the live one.  `frac` is against the 2-cycle issue
+    peak of the guide; `frac_of_measured_ceiling` is against what this machine sustains on the kernel's mix of instruction
+    classes (profiles/r01_issue_rates_2.txt: 1.05 ns for two-VGPR-operand forms, 1.75 ns for three-operand FMAs, DPP,
+    conversions and every fp64 instruction, per wave64 instruction and SIMD at eight waves per SIMD)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_valu.json")))[workload_key]
+    except Exception:
+        return None
+    n = d["sq_insts_valu_per_launch"]
+    achieved = n / (kernel_ms * 1e-3)
+    c = d.get("cheap_class_fraction_static", 0.5)
+    ceiling = SIMDS / ((c * 1.05 + (1.0 - c) * 1.75) * 1e-9)
+    return {"bound": "valu_issue", "achieved": achieved, "peak": VALU_PEAK_IPS, "unit": "wave64 instr/s",
+            "frac": achieved / VALU_PEAK_IPS, "measured_ceiling": ceiling, "frac_of_measured_ceiling": achieved / ceiling,
+            "sq_insts_valu_per_launch": n, "source": "profiles/pmc_valu.json (rocprofv3 --pmc SQ_INSTS_VALU) / live kernel time"}
+
+
 def algorithmic_bytes(n_points, H, W, esize):
     """Fused mode: 3*s per point + the DT image once per launch."""
     return 3 * esize * n_points + H * W * esize
@@ -212,7 +235,8 @@ def main():
                 "kernel_ms": ms_kernel, "kernel_ms_back_to_back": ms_kernel_b2b,
                 "frac_back_to_back": bytes_launch / (ms_kernel_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "fold_kernel_ms": ms_fold, "step_ms_events": ms_steps / nk, "kernel_ms_isolated": ms_kernel_isolated,
-                "algorithmic_bytes_per_launch": bytes_launch}
+                "algorithmic_bytes_per_launch": bytes_launch,
+                "secondary": valu_issue(args.workload, ms_kernel_b2b)}
 
     extras = {}
     if not args.no_extras:
@@ -345,10 +369,12 @@ def main():
     others = {}
     if not args.no_extras and rank == 0 and world == 1:
         from edge_alignment_amd import synth
-        def measure(problems, dtype, esz, loss):
+        def measure(problems, dtype, esz, loss, tile=None, valu_key=None):
             Ps = []
             for cfgx in problems:
                 Px = capi.Problem(*cfgx["K"], dtype=dtype, device=local_rank)
+                if tile is not None:
+                    Px.set_point_order(tile)
                 Px.set_points(cfgx["xyz"]); Px.set_dt_grid(cfgx["grid"]); Px.set_loss(*loss)
                 Ps.append(Px)
             Bx = capi.Batch(Ps)
@@ -362,7 +388,9 @@ def main():
             res = {"evals_per_s": npts / (ms / 100 * 1e-3), "us_per_step": ms / 100 * 1e3, "kernel_us": msk * 1e3,
                    "roofline_frac": by / (msk * 1e-3) / 1e9 / HBM_PEAK_GBS, "points": int(npts),
                    "point_order_tile_px": Ps[0].point_order}
-            if m > 1:  # the production shape of BASELINE config C4: all frame pairs of a GPU solved by one launch sequence
+            if valu_key:
+                res["valu_issue"] = valu_issue(valu_key, msk)
+            if m > 1 and tile is None:  # the production shape of BASELINE config C4: all frame pairs of a GPU solved by one launch sequence
                 Bx.solve(Q, T)
                 tsv = time.perf_counter()
                 for _ in range(5):
@@ -375,7 +403,7 @@ def main():
                 Px.close()
             return res
         if args.workload != "c5":
-            others["c5_fp32_1e6pts_2048x1536"] = measure([synth.config_c5()], capi.EA_F32, 4, (capi.LOSS_TRIVIAL, 1.0))
+            others["c5_fp32_1e6pts_2048x1536"] = measure([synth.config_c5()], capi.EA_F32, 4, (capi.LOSS_TRIVIAL, 1.0), valu_key="c5")
         # C3: 3-level pyramid (1280x960 / 640x480 / 320x240, 2.0e5 points in total), fp32, coarse-to-fine solve
         lv = synth.config_c3_levels()
         Pl = []
@@ -397,8 +425,12 @@ def main():
         for Px in Pl:
             Px.close()
         batch = [synth.config_c2_twin(seed=100 + i) for i in range(32)]
-        others["batch32_c2_fp64"] = measure(batch, capi.EA_F64, 8, (capi.LOSS_CAUCHY, 1.0))
-        others["batch32_c2_fp32"] = measure(batch, capi.EA_F32, 4, (capi.LOSS_CAUCHY, 1.0))
+        others["batch32_c2_fp64"] = measure(batch, capi.EA_F64, 8, (capi.LOSS_CAUCHY, 1.0), valu_key="batch32_c2_fp64")
+        others["batch32_c2_fp32"] = measure(batch, capi.EA_F32, 4, (capi.LOSS_CAUCHY, 1.0), valu_key="batch32_c2_fp32")
+        # the same batch with the points stored tile by tile (ea_problem_set_point_order(16): what the storage order of
+        # large clouds buys, applied to frame-sized clouds the caller intends to evaluate many times)
+        others["batch32_c2_fp64_tile16"] = measure(batch, capi.EA_F64, 8, (capi.LOSS_CAUCHY, 1.0), tile=16)
+        others["batch32_c2_fp32_tile16"] = measure(batch, capi.EA_F32, 4, (capi.LOSS_CAUCHY, 1.0), tile=16)
 
     out = None
     if rank == 0:

@@ -15,7 +15,7 @@ def run(cfg, dtype, loss, steps, solve=True, tune=None):
         print('solve', s['why'], s['num_iterations'], s['total_time_ms'])
     B.close(); P.close()
 if which in ('all', 'c2'):
-    run(synth.config_c2_twin(), capi.EA_F64, (capi.LOSS_CAUCHY, 1.0), 50)
+    run(synth.config_c2_twin(seed=2, n_points=50000), capi.EA_F64, (capi.LOSS_CAUCHY, 1.0), 50)
 if which in ('all', 'lm'):
     run(synth.config_c2_twin(seed=7, n_points=100000), capi.EA_F64, (capi.LOSS_CAUCHY, 1.0), 50)
 if which in ('all', 'c5'):
