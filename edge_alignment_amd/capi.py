@@ -27,7 +27,7 @@ EXPORTED = [
     "ea_problem_create", "ea_problem_destroy", "ea_problem_set_points", "ea_problem_set_point_order", "ea_problem_get_point_order",
     "ea_problem_set_points_device", "ea_problem_set_dt", "ea_problem_set_dt_image_device",
     "ea_problem_set_loss", "ea_problem_set_flavour", "ea_problem_num_points",
-    "ea_eval", "ea_eval_points", "ea_cost", "ea_solve",
+    "ea_eval", "ea_eval_points", "ea_cost", "ea_problem_pixel_cost", "ea_solve",
     "ea_batch_create", "ea_batch_destroy", "ea_batch_count", "ea_batch_eval", "ea_batch_solve",
     "ea_solve_pyramid", "ea_solve_sharded", "ea_solve_sharded_device", "ea_tracker_create", "ea_tracker_destroy", "ea_tracker_problem", "ea_tracker_push_frame",
     "ea_batch_bench_eval", "ea_batch_bench_steps", "ea_batch_bench_kernel", "ea_batch_bench_fold", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
@@ -66,6 +66,11 @@ class Options(C.Structure):
                 ("jacobi_scaling", C.c_int), ("strategy", C.c_int),
                 ("minimizer_progress_to_stdout", C.c_int), ("iterations_per_sync", C.c_int),
                 ("solve_timeout_ms", C.c_double)]
+
+
+class PixelCost(C.Structure):
+    _fields_ = [("total_cost", C.c_double), ("mean_cost", C.c_double), ("max_cost", C.c_double),
+                ("max_pixel", C.c_double * 2), ("count", C.c_int64), ("outside", C.c_int64)]
 
 
 class Summary(C.Structure):
@@ -126,6 +131,7 @@ def load():
     L.ea_batch_bench_steps.argtypes = [vp, C.c_int, dp]
     L.ea_batch_bench_kernel.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp]
     L.ea_batch_bench_fold.argtypes = [vp, C.c_int, C.c_int, dp]
+    L.ea_problem_pixel_cost.argtypes = [vp, dp, dp, C.POINTER(PixelCost)]
     L.ea_solve_sharded.argtypes = [vp, C.POINTER(Options), ALLREDUCE_FN, vp, dp, dp, C.POINTER(Summary)]
     L.ea_solve_sharded_device.argtypes = [vp, C.POINTER(Options), DEVICE_ALLREDUCE_FN, vp, vp, dp, dp, C.POINTER(Summary)]
     L.ea_solve_pyramid.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Options), dp, dp, C.POINTER(Summary)]
@@ -394,6 +400,14 @@ class Problem:
         _check(load().ea_solve_sharded_device(self._h, C.byref(o), cb, None, C.c_void_p(int(device_sums_ptr)), _dp(q), _dp(t),
                                               C.byref(s)))
         return q, t, summary_to_dict(s)
+
+    def pixel_cost(self, q, t):
+        """the reference's integer-pixel cost report (standalone_edge_align.cpp:2494-2567) at pose (q, t)"""
+        q, t = _f64(q).reshape(4), _f64(t).reshape(3)
+        pc = PixelCost()
+        _check(load().ea_problem_pixel_cost(self._h, _dp(q), _dp(t), C.byref(pc)))
+        return dict(total_cost=pc.total_cost, mean_cost=pc.mean_cost, max_cost=pc.max_cost,
+                    max_pixel=(pc.max_pixel[0], pc.max_pixel[1]), count=pc.count, outside=pc.outside)
 
     def get_points(self):
         n = self.num_points

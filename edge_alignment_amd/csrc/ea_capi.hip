@@ -22,6 +22,8 @@ namespace ea {
 hipError_t launch_eval_fused(int dtype, int ppt, int nt, int variant, const ProblemDesc *probs, int nterms, int chunk,
                              int max_chunks, int xcd_remap, const PoseState *poses, double *partials,
                              int lds_bytes, int terms_are_groups, int buffer_loads, hipStream_t stream);
+hipError_t launch_pixel_cost(int dtype, const ProblemDesc *probs, int problem, int n, const PoseState *poses, void *partials,
+                             hipStream_t stream);
 hipError_t launch_eval_points(int dtype, const ProblemDesc *probs, int problem, int n, const PoseState *poses,
                               double *r_out, double *J_out, int corrected, hipStream_t stream);
 hipError_t launch_reduce(const GroupDesc *groups, int count, const double *partials, EvalOut *out,
@@ -1249,6 +1251,40 @@ extern "C" int ea_eval(ea_problem *p, const double q[4], const double t[3], doub
 
 extern "C" int ea_cost(ea_problem *p, const double q[4], const double t[3], double *cost, int64_t *n_invalid) {
   return ea_eval(p, q, t, cost, nullptr, nullptr, n_invalid);
+}
+
+// the reference's integer-pixel cost report (standalone_edge_align.cpp:2494-2567, :2704-2776)
+extern "C" int ea_problem_pixel_cost(ea_problem *p, const double q[4], const double t[3], ea_pixel_cost *out) {
+  if (!q || !t || !out) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  ea_batch *b;
+  int rc = self_batch(p, &b);
+  if (rc != EA_OK) return rc;
+  rc = batch_build(b);
+  if (rc != EA_OK) return rc;
+  std::memset(out, 0, sizeof(*out));
+  out->max_cost = -1.0;
+  if (p->n == 0) return EA_OK;
+  rc = batch_upload_poses(b, q, t);
+  if (rc != EA_OK) return rc;
+  struct Partial { double sum, max, max_u, max_v; long long max_index, inside, outside, pad_; };
+  const int nwg = (int)((p->n + kBlockThreads - 1) / kBlockThreads);
+  DevBuf buf;
+  HIPCHK(hipMalloc(&buf.p, (size_t)nwg * sizeof(Partial)));
+  HIPCHK(launch_pixel_cost(p->dtype, b->d_probs, 0, (int)p->n, b->d_poses, buf.p, b->stream));
+  std::vector<Partial> parts((size_t)nwg);
+  HIPCHK(hipMemcpyAsync(parts.data(), buf.p, (size_t)nwg * sizeof(Partial), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  long long best = 0x7fffffffffffffffLL;
+  for (const Partial &w : parts) {  // fixed order: workgroup 0, 1, ...
+    out->total_cost += w.sum;
+    out->count += w.inside;
+    out->outside += w.outside;
+    if (w.max > out->max_cost || (w.max == out->max_cost && w.max_index < best)) {
+      out->max_cost = w.max; out->max_pixel[0] = w.max_u; out->max_pixel[1] = w.max_v; best = w.max_index;
+    }
+  }
+  out->mean_cost = out->count > 0 ? out->total_cost / (double)out->count : 0.0;
+  return EA_OK;
 }
 
 extern "C" int ea_eval_points(ea_problem *p, const double q[4], const double t[3], double *r, double *J, int corrected) {

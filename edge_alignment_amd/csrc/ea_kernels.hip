@@ -992,6 +992,81 @@ __global__ __launch_bounds__(kBlockThreads) void ea_eval_points_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// The reference's own quantitative self-check (standalone_edge_align.cpp:2494-2567 before the solve, :2704-2776 after):
+// every point warped by the pose, divided by its depth, pushed through K, truncated `(int)` to a pixel, the distance
+// transform read at that pixel; total, maximum and where the maximum sits.  One partial per workgroup
+// {sum, max, u of max, v of max, smallest point index holding the max, points inside, points outside}; the host folds
+// them in workgroup order.  Arithmetic is fp64 with the reference's operation order (x / z first, then fx * x + cx, no
+// contraction) so that borderline pixels truncate the same way.  Upstream reads outside the image without a check
+// (undefined behaviour); such points are skipped here and counted.
+struct PixelCostPartial {
+  double sum, max, max_u, max_v;
+  long long max_index, inside, outside;
+  long long pad_;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlockThreads) void ea_pixel_cost_kernel(const ProblemDesc *__restrict__ probs, int problem,
+                                                                      const PoseState *__restrict__ poses,
+                                                                      PixelCostPartial *__restrict__ out) {
+  __shared__ double s_sum[kBlockThreads / 64], s_max[kBlockThreads / 64], s_u[kBlockThreads / 64], s_v[kBlockThreads / 64];
+  __shared__ long long s_idx[kBlockThreads / 64], s_in[kBlockThreads / 64], s_out[kBlockThreads / 64];
+  const ProblemDesc &pd = probs[problem];
+  const PoseState &ps = poses[pd.group];
+  const int i = blockIdx.x * kBlockThreads + threadIdx.x;
+  double cost = 0.0, mx = -1.0, mu = 0.0, mv = 0.0;  // upstream starts MaxCost at -1
+  long long midx = 0x7fffffffffffffffLL, nin = 0, nout = 0;
+  if (i < pd.n) {
+    const double x = (double)static_cast<const T *>(pd.x)[i], y = (double)static_cast<const T *>(pd.y)[i],
+                 z = (double)static_cast<const T *>(pd.z)[i];
+    const double *R = ps.R, *t = ps.t;
+    // Eigen's 4x4 * 4x1 product, row by row, left to right; then x / z, fx * x + cx.  No contraction: upstream's build
+    // has no FMA, and fma(fy, y / z, cy) lands on 34.999999999999986 where the two roundings give 35.0 -- another pixel.
+    // (hipcc contracts __dmul_rn + __dadd_rn pairs like plain operators, hence the pragma.)
+    double bx, by, bz, u, v;
+    {
+#pragma clang fp contract(off)
+      bx = ((R[0] * x + R[1] * y) + R[2] * z) + t[0];
+      by = ((R[3] * x + R[4] * y) + R[5] * z) + t[1];
+      bz = ((R[6] * x + R[7] * y) + R[8] * z) + t[2];
+      const double xn = bx / bz, yn = by / bz;
+      u = pd.fx * xn + pd.cx;
+      v = pd.fy * yn + pd.cy;
+    }
+    const bool finite = (u == u) && (v == v) && fabs(u) < 1e9 && fabs(v) < 1e9;
+    const int iu = finite ? (int)u : -1, iv = finite ? (int)v : -1;  // `(int)`: truncation toward zero
+    if (finite && iu >= 0 && iu < pd.W && iv >= 0 && iv < pd.H && !(u <= -1.0) && !(v <= -1.0)) {
+      cost = (double)static_cast<const T *>(pd.dt)[(size_t)(iv + kImagePad) * (size_t)pd.pitch + (size_t)(iu + kImagePad)];
+      mx = cost; mu = u; mv = v; midx = i; nin = 1;
+    } else {
+      nout = 1;
+    }
+  }
+  // wavefront reduction: sum, count, and (max, smallest index) with the pixel carried along
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    cost += __shfl_xor(cost, m, 64);
+    nin += __shfl_xor(nin, m, 64);
+    nout += __shfl_xor(nout, m, 64);
+    const double omx = __shfl_xor(mx, m, 64), ou = __shfl_xor(mu, m, 64), ov = __shfl_xor(mv, m, 64);
+    const long long oi = __shfl_xor(midx, m, 64);
+    if (omx > mx || (omx == mx && oi < midx)) { mx = omx; mu = ou; mv = ov; midx = oi; }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { s_sum[wave] = cost; s_max[wave] = mx; s_u[wave] = mu; s_v[wave] = mv; s_idx[wave] = midx; s_in[wave] = nin; s_out[wave] = nout; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    PixelCostPartial o;
+    o.sum = 0.0; o.max = -1.0; o.max_u = 0.0; o.max_v = 0.0; o.max_index = 0x7fffffffffffffffLL; o.inside = 0; o.outside = 0; o.pad_ = 0;
+    for (int w = 0; w < kBlockThreads / 64; ++w) {
+      o.sum += s_sum[w]; o.inside += s_in[w]; o.outside += s_out[w];
+      if (s_max[w] > o.max || (s_max[w] == o.max && s_idx[w] < o.max_index)) { o.max = s_max[w]; o.max_u = s_u[w]; o.max_v = s_v[w]; o.max_index = s_idx[w]; }
+    }
+    out[blockIdx.x] = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // fixed-order reduction of a problem's tile partials -> 32 accumulators
 
 constexpr int kFoldThreads = 1024;  // plain fold: 32 slots x 32 strided groups
@@ -1240,6 +1315,19 @@ hipError_t launch_eval_points(int dtype, const ProblemDesc *probs, int problem, 
   else
     hipLaunchKernelGGL((ea_eval_points_kernel<double>), dim3(grid), dim3(kBlockThreads), 0, stream, probs, problem,
                        poses, r_out, J_out, corrected);
+  return hipGetLastError();
+}
+
+hipError_t launch_pixel_cost(int dtype, const ProblemDesc *probs, int problem, int n, const PoseState *poses, void *partials,
+                             hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  const int grid = (n + kBlockThreads - 1) / kBlockThreads;
+  if (dtype == 1)
+    hipLaunchKernelGGL((ea_pixel_cost_kernel<float>), dim3(grid), dim3(kBlockThreads), 0, stream, probs, problem, poses,
+                       static_cast<PixelCostPartial *>(partials));
+  else
+    hipLaunchKernelGGL((ea_pixel_cost_kernel<double>), dim3(grid), dim3(kBlockThreads), 0, stream, probs, problem, poses,
+                       static_cast<PixelCostPartial *>(partials));
   return hipGetLastError();
 }
 

@@ -194,6 +194,19 @@ int ea_eval_points(ea_problem *p, const double q[4], const double t[3], double *
 int ea_cost(ea_problem *p, const double q[4], const double t[3], double *cost,
             int64_t *n_invalid);
 
+/* The reference's own quantitative self-check, printed before and after its solves (standalone_edge_align.cpp:2494-2567
+ * "initialCost / InitialMaxCost / Initialmaxpixel", :2704-2776 the same after): every point warped by the pose, x / z and
+ * y / z pushed through K, truncated `(int)` to a pixel, the distance transform read there; total, mean over the points,
+ * maximum and the (untruncated) pixel of the first point that attains it.  Computed on the device from the points and the
+ * DT image the problem already holds.  Upstream reads outside the image unchecked (undefined behaviour): such points are
+ * skipped and counted in `outside`; upstream accumulates in float in point order, this sums in double. */
+typedef struct {
+  double total_cost, mean_cost, max_cost;
+  double max_pixel[2];      /* (u, v) before truncation */
+  int64_t count, outside;   /* points read / points projecting outside the image */
+} ea_pixel_cost;
+int ea_problem_pixel_cost(ea_problem *p, const double q[4], const double t[3], ea_pixel_cost *out);
+
 /* ceres::Solve(options, &problem, &summary) (standalone_edge_align.cpp:286; SolveEA.cpp:198).
  * q,t in/out.  The whole trust-region loop runs on the device. */
 int ea_solve(ea_problem *p, const ea_options *opt, double q[4], double t[3], ea_summary *summary);

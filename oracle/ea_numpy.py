@@ -91,3 +91,32 @@ def evaluate(grid, K, xyz, q, t, loss_kind=LOSS_CAUCHY, loss_a=1.0, z_guard=0.01
     return dict(raw_r=f, raw_J=J, r=rc, J=Jc, valid=valid,
                 cost=0.5 * float(np.sum(rho[m])),
                 JtJ=Jc[m].T @ Jc[m], Jtr=Jc[m].T @ rc[m], n_invalid=int((~m).sum()))
+
+
+def pixel_cost(xyz, q, t, fx, fy, cx, cy, dt_image):
+    """The reference's integer-pixel cost report (ref: standalone_edge_align.cpp:2494-2567, :2704-2776): location3D =
+    b_T_a * a_X; unvn = (x / z, y / z, 1); imagePixel = K * unvn; cost = disTrans.at<float>((int)v, (int)u); total, mean,
+    max and the pixel of the first maximum.  Points outside the image (which upstream reads unchecked) are skipped and
+    counted.  dt_image: H x W, [v][u].  Returns dict(total_cost, mean_cost, max_cost, max_pixel, count, outside)."""
+    xyz = np.asarray(xyz, dtype=np.float64)
+    R = quat_to_R(np.asarray(q, dtype=np.float64))
+    t = np.asarray(t, dtype=np.float64)
+    b = np.empty_like(xyz[:, :3])
+    for k in range(3):  # row by row, left to right, as Eigen's product evaluates it
+        b[:, k] = ((R[k, 0] * xyz[:, 0] + R[k, 1] * xyz[:, 1]) + R[k, 2] * xyz[:, 2]) + t[k]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        u = fx * (b[:, 0] / b[:, 2]) + cx
+        v = fy * (b[:, 1] / b[:, 2]) + cy
+    H, W = dt_image.shape
+    fin = np.isfinite(u) & np.isfinite(v) & (np.abs(u) < 1e9) & (np.abs(v) < 1e9)
+    iu = np.where(fin, np.trunc(np.where(fin, u, 0)), -1).astype(np.int64)
+    iv = np.where(fin, np.trunc(np.where(fin, v, 0)), -1).astype(np.int64)
+    ok = fin & (iu >= 0) & (iu < W) & (iv >= 0) & (iv < H) & (u > -1.0) & (v > -1.0)
+    cost = np.asarray(dt_image, dtype=np.float64)[iv[ok], iu[ok]]
+    out = dict(total_cost=float(cost.sum()), count=int(ok.sum()), outside=int((~ok).sum()), max_cost=-1.0, max_pixel=(0.0, 0.0))
+    out["mean_cost"] = out["total_cost"] / out["count"] if out["count"] else 0.0
+    if out["count"]:
+        k = int(np.argmax(cost))  # first maximum
+        idx = np.flatnonzero(ok)[k]
+        out["max_cost"] = float(cost[k]); out["max_pixel"] = (float(u[idx]), float(v[idx]))
+    return out

@@ -423,3 +423,32 @@ def test_wave_reduce_primitives(hip):
     lanes = np.arange(64)
     a = np.array([np.where(lanes & 8, V[i + 16] + V[i + 16][lanes ^ 15], V[i] + V[i][lanes ^ 15]) for i in range(16)])
     assert np.array_equal(stages[:16], a)
+
+
+def test_integer_pixel_cost_report(hip, bundled_pair):
+    """The reference's own printed self-check (standalone_edge_align.cpp:2494-2567 before the solve, :2704-2776 after):
+    mean / max distance-transform value at the truncated pixel of every projected point.  Device report against the numpy
+    restatement, before and after the solve, in fp64 and fp32 storage, with points that leave the image."""
+    from oracle import ea_numpy as en
+    K = bundled_pair["K"]
+    X = bundled_pair["aX"][:3].T.copy()
+    grid = bundled_pair["grids"][3]
+    dt_img = np.ascontiguousarray(grid.T)          # [v][u]
+    for dtype in (hip.EA_F64, hip.EA_F32):
+        P = hip.Problem(*K, dtype=dtype)
+        P.set_points(X); P.set_dt_grid(grid)
+        Xs = P.get_points()                        # what the device holds (fp32 problems round the points)
+        q1, t1, s = P.solve(Q0, T0)
+        far_q = synth.quat_from_axis_angle([0, 1, 0], np.deg2rad(25.0))   # swings part of the cloud out of the frame
+        for q, t in ((Q0, T0), (q1, t1), (far_q, np.array([0.3, 0.0, 0.0]))):
+            got = P.pixel_cost(q, t)
+            want = en.pixel_cost(Xs, q, t, *K, dt_img)
+            assert got["count"] == want["count"] and got["outside"] == want["outside"]
+            assert got["count"] + got["outside"] == X.shape[0]
+            assert got["total_cost"] == pytest.approx(want["total_cost"], rel=1e-12)
+            assert got["mean_cost"] == pytest.approx(want["mean_cost"], rel=1e-12)
+            assert got["max_cost"] == want["max_cost"] and got["max_pixel"] == want["max_pixel"]
+        before, after = P.pixel_cost(Q0, T0), P.pixel_cost(q1, t1)
+        assert after["mean_cost"] < before["mean_cost"]     # what the reference prints the two numbers for
+        assert P.pixel_cost(far_q, [0.3, 0, 0])["outside"] > 0
+        P.close()
