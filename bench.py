@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=["c2", "c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue the timed steps launch by launch instead of replaying a hipGraph")
     # rehearsal knobs (the driver never passes them): run the N>1 control flow on a one-GPU box
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--force-device", type=int, default=None, help="use this HIP device on every rank")
@@ -194,6 +195,13 @@ def main():
     # creates its events).  Timed: EXACTLY K steps between barrier+sync brackets -- ea_batch_bench_steps only enqueues
     # K x (fused eval + fold) at the resident poses and synchronises the stream, no setup inside the bracket.
     B.bench_eval(q0, t0, 0, max(args.warmup, 1), kernel_pass=False)
+    graph = None
+    if not args.no_graph:
+        try:  # untimed: the K steps as one hipGraph (launch-bound inner loop: two ~3 us kernels per step)
+            B.bench_capture(args.steps)
+            graph = "hipGraph of %d steps (2 kernel nodes per step), one replay" % args.steps
+        except capi.EAError as e:
+            graph = "eager launches (graph capture failed: %s)" % e
     barrier_sync()
     t_start = time.perf_counter()
     B.bench_steps(args.steps)
@@ -256,9 +264,10 @@ def main():
         el = time.perf_counter() - ts
         lm_local = its / el
         # the one collective: all-gather of the solved poses (7 doubles + status per problem)
+        pg1 = ead.PoseGather(1, world, device=coll_dev if world > 1 else "cpu")  # tensors allocated once, outside the clock
+        pg1.gather([q], [t], [s["termination"]])
         tg = time.perf_counter()
-        qa, ta, st = ead.gather_poses([q], [t], [s["termination"]], world, rank, world,
-                                      device=coll_dev if world > 1 else "cpu")
+        qa, ta, st = pg1.gather([q], [t], [s["termination"]])
         gather_ms = (time.perf_counter() - tg) * 1e3
         if dist is not None:
             tt = torch.tensor([lm_local], dtype=torch.float64, device=coll_dev)
@@ -441,7 +450,8 @@ def main():
                "config": {"workload": desc, "points_per_gpu": int(n_pts), "dt_image": "%dx%d" % (W, H),
                           "parallelism": "independent frame pairs, one per GPU; single RCCL pose all-gather",
                           "tiles": B.info("num_tiles"), "points_per_thread": B.info("points_per_thread"),
-                          "lds_bytes": B.info("lds_bytes"), "point_order_tile_px": P.point_order},
+                          "lds_bytes": B.info("lds_bytes"), "point_order_tile_px": P.point_order,
+                          "timed_region": graph or "eager launches"},
                "roofline": roofline}
         out.update(extras)
         if others:

@@ -30,7 +30,7 @@ EXPORTED = [
     "ea_eval", "ea_eval_points", "ea_cost", "ea_problem_pixel_cost", "ea_solve",
     "ea_batch_create", "ea_batch_destroy", "ea_batch_count", "ea_batch_eval", "ea_batch_solve",
     "ea_solve_pyramid", "ea_solve_sharded", "ea_solve_sharded_device", "ea_tracker_create", "ea_tracker_destroy", "ea_tracker_problem", "ea_tracker_push_frame",
-    "ea_batch_bench_eval", "ea_batch_bench_steps", "ea_batch_bench_kernel", "ea_batch_bench_fold", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
+    "ea_batch_bench_eval", "ea_batch_bench_steps", "ea_batch_bench_capture", "ea_batch_bench_kernel", "ea_batch_bench_fold", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
     "ea_problem_set_ref_frame", "ea_problem_set_ref_frame_masked", "ea_problem_set_now_frame", "ea_problem_debug_now_frame",
     "ea_problem_set_ref_frame_canny", "ea_problem_set_now_frame_canny", "ea_problem_debug_now_frame_canny",
     "ea_problem_set_ref_frame_ros", "ea_problem_set_now_frame_ros", "ea_problem_debug_now_frame_ros",
@@ -129,6 +129,7 @@ def load():
     L.ea_batch_solve.argtypes = [vp, C.POINTER(Options), dp, dp, C.POINTER(Summary)]
     L.ea_batch_bench_eval.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp, dp]
     L.ea_batch_bench_steps.argtypes = [vp, C.c_int, dp]
+    L.ea_batch_bench_capture.argtypes = [vp, C.c_int]
     L.ea_batch_bench_kernel.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp]
     L.ea_batch_bench_fold.argtypes = [vp, C.c_int, C.c_int, dp]
     L.ea_problem_pixel_cost.argtypes = [vp, dp, dp, C.POINTER(PixelCost)]
@@ -560,6 +561,10 @@ class Batch:
         _check(load().ea_batch_bench_eval(self._h, _dp(q), _dp(t), warmup, steps, C.byref(ms_total),
                                           C.byref(ms_kernel) if kernel_pass else None))
         return ms_total.value, (ms_kernel.value if kernel_pass else None)
+
+    def bench_capture(self, steps):
+        """untimed: capture `steps` steps into a hipGraph that bench_steps(steps) replays"""
+        _check(load().ea_batch_bench_capture(self._h, int(steps)))
 
     def bench_steps(self, steps, host_times=False):
         """`steps` x (fused evaluation + fold) at the poses already on the device, then a stream sync: the timed region"""

@@ -182,6 +182,8 @@ struct ea_batch {
   int t_buf = -1, buffer_loads = 0;  // raw-buffer addressing of the DT image and the points (needs a < 2 GiB image)
   std::vector<ea_batch *> parts;  // sub-batches of the concurrent solve (ea_batch_solve)
   bool built = false;
+  hipGraphExec_t bench_graph = nullptr;  // K x (evaluation + fold) captured once (ea_batch_bench_capture), replayed by
+  int bench_graph_steps = 0;             // ea_batch_bench_steps(K): the timed region then holds no per-launch host work
   bool needs_drain = false;     // a solve gave up on its deadline with launches still queued: synchronise before reuse
   hipEvent_t round_done = nullptr;  // behind the last step kernel of a round of ea_solve_sharded_device
   GroupDesc *d_one_row = nullptr;  // {0, 1, 0, 1}: "one partial row" for the step kernel of ea_solve_sharded_device
@@ -507,6 +509,7 @@ extern "C" int ea_problem_set_flavour(ea_problem *p, double z_guard, double z_ep
 // ---- batch --------------------------------------------------------------------------------------
 
 static void batch_free_device(ea_batch *b) {
+  if (b->bench_graph) { (void)hipGraphExecDestroy(b->bench_graph); b->bench_graph = nullptr; b->bench_graph_steps = 0; }
   (void)hipFree(b->d_one_row); b->d_one_row = nullptr;
   if (b->round_done) { (void)hipEventDestroy(b->round_done); b->round_done = nullptr; }
   (void)hipFree(b->d_probs); (void)hipFree(b->d_groups); (void)hipFree(b->d_lm_block); (void)hipFree(b->d_cold);
@@ -640,6 +643,7 @@ static int batch_build(ea_batch *b) {
   (void)sig;
   if (!dirty) return EA_OK;
   b->built = false;  // until the last allocation and upload below has succeeded
+  if (b->bench_graph) { (void)hipGraphExecDestroy(b->bench_graph); b->bench_graph = nullptr; b->bench_graph_steps = 0; }
   HIPCHK(hipSetDevice(b->device));
   // terms of a problem follow it; all share its pose
   std::vector<const ea_problem *> terms;
@@ -1124,6 +1128,38 @@ extern "C" int ea_batch_bench_eval(ea_batch *b, const double *q, const double *t
   return EA_OK;
 }
 
+// Capture `steps` x (evaluation + fold) into a hipGraph (untimed set-up).  A step is two dependent launches of ~3 us
+// each; enqueued one by one the host needs ~3.1 us per launch and the stream never runs ahead of it
+// (profiles/r02_bench_bracket.txt) -- replayed from a graph the same launches execute back to back from the queue.
+extern "C" int ea_batch_bench_capture(ea_batch *b, int steps) {
+  if (!b || steps < 1) return fail(EA_ERR_INVALID_ARG, "bad argument");
+  int rc = batch_build(b);
+  if (rc != EA_OK) return rc;
+  if (!b->poses_uploaded) return fail(EA_ERR_STATE, "no poses uploaded yet (ea_batch_bench_eval or ea_batch_eval first)");
+  if (b->bench_graph) { (void)hipGraphExecDestroy(b->bench_graph); b->bench_graph = nullptr; b->bench_graph_steps = 0; }
+  const int count = (int)b->probs.size();
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < steps && e == hipSuccess; ++i) {
+    if (batch_launch_eval(b) != EA_OK) { e = hipErrorUnknown; break; }
+    e = launch_reduce(b->d_groups, count, b->d_partials, b->d_out, b->stream);
+  }
+  hipGraph_t graph = nullptr;
+  const hipError_t ee = hipStreamEndCapture(b->stream, &graph);
+  if (e != hipSuccess || ee != hipSuccess || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return fail(EA_ERR_HIP, std::string("graph capture: ") + hipGetErrorString(e != hipSuccess ? e : ee));
+  }
+  e = hipGraphInstantiate(&b->bench_graph, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) { b->bench_graph = nullptr; return fail(EA_ERR_HIP, std::string("graph instantiate: ") + hipGetErrorString(e)); }
+  b->bench_graph_steps = steps;
+  HIPCHK(hipGraphLaunch(b->bench_graph, b->stream));  // one untimed replay: uploads the executable graph
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return EA_OK;
+}
+
 extern "C" int ea_batch_bench_steps(ea_batch *b, int steps, double *host_us) {
   if (!b || steps < 1) return fail(EA_ERR_INVALID_ARG, "bad argument");
   int rc = batch_build(b);
@@ -1131,9 +1167,13 @@ extern "C" int ea_batch_bench_steps(ea_batch *b, int steps, double *host_us) {
   if (!b->poses_uploaded) return fail(EA_ERR_STATE, "no poses uploaded yet (ea_batch_bench_eval or ea_batch_eval first)");
   const int count = (int)b->probs.size();
   const auto t0 = std::chrono::steady_clock::now();
-  for (int i = 0; i < steps; ++i) {
-    if ((rc = batch_launch_eval(b)) != EA_OK) return rc;
-    HIPCHK(launch_reduce(b->d_groups, count, b->d_partials, b->d_out, b->stream));
+  if (b->bench_graph && b->bench_graph_steps == steps) {
+    HIPCHK(hipGraphLaunch(b->bench_graph, b->stream));
+  } else {
+    for (int i = 0; i < steps; ++i) {
+      if ((rc = batch_launch_eval(b)) != EA_OK) return rc;
+      HIPCHK(launch_reduce(b->d_groups, count, b->d_partials, b->d_out, b->stream));
+    }
   }
   const auto t1 = std::chrono::steady_clock::now();
   HIPCHK(hipStreamSynchronize(b->stream));

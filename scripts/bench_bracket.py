@@ -10,7 +10,10 @@ P = capi.Problem(*cfg["K"], dtype=capi.EA_F64); P.set_points(cfg["xyz"]); P.set_
 B = capi.Batch([P])
 q0, t0 = np.array([1., 0, 0, 0]), np.zeros(3)
 B.bench_eval(q0, t0, 0, 50, kernel_pass=False)
+use_graph = len(sys.argv) > 1 and sys.argv[1] == "graph"
 for K in (1, 2, 5, 10, 20, 50, 100, 500, 2000):
+    if use_graph:
+        B.bench_capture(K)
     best = None
     for rep in range(7):
         torch.cuda.synchronize()
