@@ -440,6 +440,12 @@ def main():
         # large clouds buys, applied to frame-sized clouds the caller intends to evaluate many times)
         others["batch32_c2_fp64_tile16"] = measure(batch, capi.EA_F64, 8, (capi.LOSS_CAUCHY, 1.0), tile=16)
         others["batch32_c2_fp32_tile16"] = measure(batch, capi.EA_F32, 4, (capi.LOSS_CAUCHY, 1.0), tile=16)
+        # 64 pairs per launch: where the launch has grown out of its ramp and tail (profiles/r02_batch_size_sweep.txt);
+        # 256 pairs (fp32: 468 MB): beyond the 256 MB Infinity Cache that serves repeated launches over a smaller
+        # batch, i.e. the rate with every byte coming from HBM
+        others["batch64_c2_fp32_tile16"] = measure(batch * 2, capi.EA_F32, 4, (capi.LOSS_CAUCHY, 1.0), tile=16)
+        others["batch64_c2_fp64_tile16"] = measure(batch * 2, capi.EA_F64, 8, (capi.LOSS_CAUCHY, 1.0), tile=16)
+        others["batch256_c2_fp32_tile16_beyond_infinity_cache"] = measure(batch * 8, capi.EA_F32, 4, (capi.LOSS_CAUCHY, 1.0), tile=16)
 
     out = None
     if rank == 0:

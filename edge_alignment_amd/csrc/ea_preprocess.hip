@@ -602,7 +602,10 @@ __global__ void ea_edge_scatter_ros_kernel(const uint8_t *__restrict__ edges, co
 // ---- half-resolution level: cv::resize(src, dst, cv::Size(), 0.5, 0.5) as the ROS callbacks apply it to the bgr8 colour
 // frame and to the float depth frame after NaN -> 0 (ref: src/ea.cpp:38, :56-62).  At an exact factor of two OpenCV's
 // INTER_LINEAR resize is the 2 x 2 area mean (cv::resize switches to its fast area path; the bilinear weights are 1/2, 1/2
-// anyway): 8-bit channels (a + b + c + d + 2) >> 2, float 0.25f * (((a + b) + c) + d) in the order of the generic loop.
+// anyway): 8-bit channels (a + b + c + d + 2) >> 2; float 0.25f * ((a + b) + (c + d)), the order of OpenCV 3's vector
+// path for CV_32F (ResizeAreaFastVec_SIMD_32f: the two pixels of each source row are added first, then the rows) -- what
+// an x86 or NEON build executes for every pixel of a width that is a multiple of four; the scalar generic loop would
+// sum ((a + b) + c) + d, which differs in the last bit on some pixels.
 __global__ void ea_resize_half_bgr8_kernel(const uint8_t *__restrict__ src, int H2, int W2, uint8_t *__restrict__ dst) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;  // destination column x channel
   const int y = blockIdx.y;
@@ -626,7 +629,7 @@ __global__ void ea_resize_half_f32_kernel(const float *__restrict__ src, int H2,
   if (nan_to_zero) {  // depth.setTo(0, depth != depth) before the resize (src/ea.cpp:56-58)
     a = (a != a) ? 0.0f : a; b = (b != b) ? 0.0f : b; c = (c != c) ? 0.0f : c; d = (d != d) ? 0.0f : d;
   }
-  dst[(size_t)y * W2 + x] = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(a, b), c), d), 0.25f);
+  dst[(size_t)y * W2 + x] = __fmul_rn(__fadd_rn(__fadd_rn(a, b), __fadd_rn(c, d)), 0.25f);
 }
 
 __global__ void ea_nan_to_zero_kernel(float *__restrict__ img, size_t n) {

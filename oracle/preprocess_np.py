@@ -324,15 +324,17 @@ def resize_half_bgr8(img_u8):
 
 def resize_half_f32(img_f32, nan_to_zero=True):
     """the depth callback (ref: src/ea.cpp:56-62): depth.setTo(0, depth != depth), then cv::resize x0.5 on CV_32F = the
-    area mean in float32, summed in the order of OpenCV's generic loop: 0.25f * (((a + b) + c) + d)."""
+    area mean in float32.  Summation order of OpenCV 3's vector path (ResizeAreaFastVec_SIMD_32f, what x86 / NEON builds
+    run): the two pixels of each source row first, then the two rows, times 0.25f.  (The scalar generic loop would add
+    ((a + b) + c) + d; without OpenCV in the image neither can be checked against the library itself.)"""
     a = np.array(img_f32, dtype=np.float32, copy=True)
     if nan_to_zero:
         a[np.isnan(a)] = np.float32(0)
     H, W = a.shape[0] // 2 * 2, a.shape[1] // 2 * 2
     a = a[:H, :W]
-    s = ((a[0::2, 0::2] + a[0::2, 1::2]).astype(np.float32) + a[1::2, 0::2]).astype(np.float32)
-    s = (s + a[1::2, 1::2]).astype(np.float32)
-    return (s * np.float32(0.25)).astype(np.float32)
+    top = (a[0::2, 0::2] + a[0::2, 1::2]).astype(np.float32)
+    bot = (a[1::2, 0::2] + a[1::2, 1::2]).astype(np.float32)
+    return ((top + bot).astype(np.float32) * np.float32(0.25)).astype(np.float32)
 
 
 def grid_view_of_image(dt_hw):
