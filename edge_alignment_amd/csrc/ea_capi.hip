@@ -178,6 +178,7 @@ struct ea_batch {
   // tuning (-1 = heuristic)
   int t_lds_bytes = -1, t_ppt = -1, t_use_lds = -1, t_xcd = -1, t_nt = -1, t_streams = -1, t_variant = 0;
   int ppt = 1, nt = 256, lds_bytes = 0, xcd_remap = 1;
+  int t_test_fail_build = 0;  // test hook: the next descriptor build fails half-way, as a failed allocation would
   int t_test_stall_ms = 0;  // test hook: hold the stream on a host function for this long at the start of a solve
   int t_buf = -1, buffer_loads = 0;  // raw-buffer addressing of the DT image and the points (needs a < 2 GiB image)
   std::vector<ea_batch *> parts;  // sub-batches of the concurrent solve (ea_batch_solve)
@@ -723,6 +724,10 @@ static int batch_build(ea_batch *b) {
     b->terms_cap = b->nterms + 8;
     HIPCHK(hipMalloc(&b->d_probs, (size_t)b->terms_cap * sizeof(ProblemDesc)));
   }
+  if (b->t_test_fail_build) {  // (tests/test_gpu_robustness.py: a build that fails here must leave the batch dirty)
+    b->t_test_fail_build = 0;
+    return fail(EA_ERR_ALLOC, "batch build: injected allocation failure (test hook)");
+  }
   if (b->ntiles > b->tiles_cap) {
     (void)hipFree(b->d_partials);
     b->d_partials = nullptr;
@@ -1246,6 +1251,7 @@ extern "C" int ea_batch_set_tuning(ea_batch *b, const char *key, int value) {
   else if (k == "threads") b->t_nt = value;
   else if (k == "buffer_loads") b->t_buf = value;
   else if (k == "test_stall_ms") { b->t_test_stall_ms = value; return EA_OK; }
+  else if (k == "test_fail_build") { b->t_test_fail_build = value; return EA_OK; }
   else if (k == "solve_streams") { b->t_streams = value; return EA_OK; }
   else return fail(EA_ERR_INVALID_ARG, "unknown tuning key: " + k);
   b->built = false;

@@ -71,3 +71,22 @@ def test_tracker_push_is_all_or_nothing(hip):
     rb = TB.push_frame(fr[3][0], fr[3][1])
     assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1])
     TA.close(); TB.close()
+
+
+def test_failed_descriptor_build_leaves_the_batch_dirty(hip):
+    """A build that fails after the problems changed (a failed allocation in the field, a hook here) must not leave
+    the batch believing it is up to date: round 1 committed the version stamps first, and the next call would have
+    launched on stale descriptors.  The next call rebuilds and evaluates the NEW points."""
+    P, pr = _problem(hip)
+    B = hip.Batch([P])
+    g0 = B.eval(Q0, T0)
+    P.set_points(pr["xyz"][::2])                    # the batch is dirty now
+    B.set_tuning("test_fail_build", 1)
+    with pytest.raises(hip.EAError) as ei:
+        B.eval(Q0, T0)
+    assert ei.value.code == hip.EA_ERR_ALLOC
+    g1 = B.eval(Q0, T0)                             # rebuilds: half the points, not the stale descriptors
+    Pref = hip.Problem(*pr["K"]); Pref.set_points(pr["xyz"][::2]); Pref.set_dt_grid(pr["grid"])
+    want = Pref.eval(Q0, T0)
+    assert g1["cost"][0] == want["cost"] and np.array_equal(g1["JtJ"][0], want["JtJ"]) and g1["cost"][0] != g0["cost"][0]
+    B.close(); P.close(); Pref.close()
