@@ -23,12 +23,18 @@ if which in ('all', 'c5'):
 if which in ('batch32f32', 'batch32f64'):
     dtype = capi.EA_F32 if which.endswith('f32') else capi.EA_F64
     Ps = []
+    tile = [int(kv.split('=')[1]) for kv in sys.argv[2:] if kv.startswith('tile=')]
     for i in range(32):
         cfg = synth.config_c2_twin(seed=100 + i)
-        P = capi.Problem(*cfg['K'], dtype=dtype); P.set_points(cfg['xyz']); P.set_dt_grid(cfg['grid']); P.set_loss(capi.LOSS_CAUCHY, 1.0)
+        P = capi.Problem(*cfg['K'], dtype=dtype)
+        if tile:
+            P.set_point_order(tile[0])   # storage order of the points: tiles of this many pixels
+        P.set_points(cfg['xyz']); P.set_dt_grid(cfg['grid']); P.set_loss(capi.LOSS_CAUCHY, 1.0)
         Ps.append(P)
     B = capi.Batch(Ps)
     for kv in sys.argv[2:]:
+        if kv.startswith('tile='):
+            continue
         k, v = kv.split('='); B.set_tuning(k, int(v))
     ms, _ = B.bench_eval(np.tile(q0, (32, 1)), np.tile(t0, (32, 1)), 5, 30, kernel_pass=False)
     print('ms/step', ms / 30, 'tiles', B.info('num_tiles'), 'ppt', B.info('points_per_thread'), 'threads', B.info('threads'))
