@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=["c2", "c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--device-allreduce", action="store_true",
+                    help="with --gpus > 1: also time ea_solve_sharded_device with its all-reduce enqueued on the stream (RCCL)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the timed steps launch by launch instead of replaying a hipGraph")
     # rehearsal knobs (the driver never passes them): run the N>1 control flow on a one-GPU box
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
@@ -321,6 +323,23 @@ def main():
                                                   "points_per_gpu": int(sl.stop - sl.start),
                                                   "pose_err_vs_planted": {"rad": synth.rotation_angle_between(q3, cfg2["q_true"]),
                                                                           "m": float(np.linalg.norm(t3 - cfg2["t_true"]))}}
+            # the same solve with the exchange kept on the stream (ea_solve_sharded_device): on one rank always (nothing to
+            # enqueue: measures the path without the host hop); over RCCL only on request -- it has been rehearsed with gloo
+            # only, and a collective that misbehaves on its first contact with a real node must not cost the scaling record
+            if world == 1 or args.device_allreduce:
+                sums, enqueue = ead.make_device_allreduce(world, torch.device("cuda", local_rank))
+                P3.solve_sharded_device(q0, t0, enqueue, sums.data_ptr())
+                barrier_sync()
+                ts = time.perf_counter()
+                its4 = 0
+                for _ in range(reps3):
+                    q4, t4, s4 = P3.solve_sharded_device(q0, t0, enqueue, sums.data_ptr())
+                    its4 += s4["num_iterations"]
+                barrier_sync()
+                el4 = time.perf_counter() - ts
+                extras["lm_point_sharded_device_1e5_pts"] = {"iters_per_s": its4 / el4, "solve_ms": el4 / reps3 * 1e3,
+                                                             "pose_err_vs_planted": {"rad": synth.rotation_angle_between(q4, cfg2["q_true"]),
+                                                                                     "m": float(np.linalg.norm(t4 - cfg2["t_true"]))}}
             P3.close()
         except Exception as e:  # never let the secondary measurement take the headline line down
             extras["lm_point_sharded_1e5_pts"] = {"error": repr(e)}
