@@ -30,7 +30,7 @@ hipError_t launch_reduce(const GroupDesc *groups, int count, const double *parti
                          hipStream_t stream);
 hipError_t launch_lm_step(const GroupDesc *groups, int count, const double *partials, PoseState *poses,
                           LMState *states, LMCold *cold, LMTrace *traces, const LMOptions &opt, int *running_flags,
-                          LMState *host_states, LMTrace *host_traces, hipStream_t stream);
+                          LMState *host_states, LMTrace *host_traces, const GroupDesc &first, hipStream_t stream);
 hipError_t launch_pad_image(int dtype, const void *src, int H, int W, void *dst, int pitch, hipStream_t stream);
 hipError_t launch_selftest_reduce(const float *in, float *a, float *b, float *c, float *d, double *o32, double *o64,
                                   hipStream_t stream);
@@ -186,6 +186,7 @@ struct ea_batch {
   hipGraphExec_t bench_graph = nullptr;  // K x (evaluation + fold) captured once (ea_batch_bench_capture), replayed by
   int bench_graph_steps = 0;             // ea_batch_bench_steps(K): the timed region then holds no per-launch host work
   bool needs_drain = false;     // a solve gave up on its deadline with launches still queued: synchronise before reuse
+  GroupDesc group0 = {0, 0, 0, 0};  // host copy of d_groups[0]: handed to the step kernel by value
   hipEvent_t round_done = nullptr;  // behind the last step kernel of a round of ea_solve_sharded_device
   GroupDesc *d_one_row = nullptr;  // {0, 1, 0, 1}: "one partial row" for the step kernel of ea_solve_sharded_device
   bool poses_uploaded = false;  // d_poses holds caller-supplied poses (ea_batch_bench_steps re-evaluates at them)
@@ -716,6 +717,7 @@ static int batch_build(ea_batch *b) {
     g.term_end = (int)k + 1;
   }
   b->nterms = (int)terms.size();
+  b->group0 = groups.empty() ? GroupDesc{0, 0, 0, 0} : groups[0];
   b->ntiles = rows;
   b->max_chunks = max_chunks;
   if (b->nterms > b->terms_cap) {
@@ -902,7 +904,7 @@ static int solve_pump(SolveRun &r, const LMOptions &lo) {
     int rc = batch_launch_eval(b);
     if (rc != EA_OK) return rc;
     HIPCHK(launch_lm_step(b->d_groups, count, b->d_partials, b->d_poses, b->d_states, b->d_cold, b->d_traces, lo,
-                          b->d_progress, b->dv_states, b->dv_traces, b->stream));
+                          b->d_progress, b->dv_states, b->dv_traces, b->group0, b->stream));
     ++r.enq;
     r.spins = 0;
     r.moved = true;
@@ -1506,7 +1508,7 @@ extern "C" int ea_solve_sharded_device(ea_problem *p, const ea_options *opt_in, 
         return fail(EA_ERR_STATE, "the all-reduce callback reported a failure");
       }
       HIPCHK(launch_lm_step(b->d_one_row, 1, device_sums, b->d_poses, b->d_states, b->d_cold, b->d_traces, lo, b->d_progress,
-                            b->dv_states, b->dv_traces, b->stream));
+                            b->dv_states, b->dv_traces, GroupDesc{0, 1, 0, 1}, b->stream));
       ++r.enq;
     }
     // Wait for the whole round (an event behind its last step kernel), THEN look at the flag: the decision to go on must

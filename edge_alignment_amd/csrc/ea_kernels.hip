@@ -1144,9 +1144,10 @@ template <int STRAT>
 __global__ __launch_bounds__(kLmThreads) void ea_lm_step_kernel(
     const GroupDesc *__restrict__ groups, const double *__restrict__ partials,
     PoseState *__restrict__ poses, LMState *__restrict__ states, LMCold *__restrict__ cold,
-    LMTrace *__restrict__ traces, LMOptions opt,
+    LMTrace *__restrict__ traces, LMOptions opt_arg,
     int *__restrict__ progress /* pinned host: [running x n | evals x n] */,
-    LMState *__restrict__ host_states, LMTrace *__restrict__ host_traces /* pinned host, nullable: final delivery */) {
+    LMState *__restrict__ host_states, LMTrace *__restrict__ host_traces /* pinned host, nullable: final delivery */,
+    GroupDesc first /* = groups[0], by value: problem 0's row range needs no dependent load */) {
   __shared__ double s_part[(kLmThreads / 32) * kAccSlots];
   __shared__ double s_acc[kAccSlots];
   __shared__ LMState s_st;
@@ -1165,7 +1166,17 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_step_kernel(
 #ifdef EA_STAMPS
   if (threadIdx.x == 0 && blockIdx.x == 0) g_lm_probe_row = ev_ & 63;
 #endif
-  const GroupDesc gd = groups[p];
+  // Everything the kernel argument segment holds is fetched HERE, in one batch of scalar loads behind one wait: left to
+  // the compiler, the options were loaded where lane 0 first uses them -- two more cold misses of the argument segment
+  // on the state machine's critical path, after the fold.
+  LMOptions opt = opt_arg;
+  asm volatile("" : "+s"(opt.max_num_iterations), "+s"(opt.function_tolerance), "+s"(opt.gradient_tolerance),
+                    "+s"(opt.parameter_tolerance), "+s"(opt.initial_trust_region_radius), "+s"(opt.max_trust_region_radius),
+                    "+s"(opt.min_trust_region_radius), "+s"(opt.min_relative_decrease), "+s"(opt.min_lm_diagonal),
+                    "+s"(opt.max_lm_diagonal), "+s"(opt.max_num_consecutive_invalid_steps), "+s"(opt.jacobi_scaling),
+                    "+s"(opt.strategy));
+  GroupDesc gd = first;
+  if (p != 0) gd = groups[p];  // (uniform)
   const int running = states[p].running;
   const int evals_before = states[p].num_evals;  // (a register copy: the LDS copy is rewritten by lane 0 below)
   const double state_word = tid < kStateWords ? reinterpret_cast<const double *>(states + p)[tid] : 0.0;
@@ -1340,14 +1351,14 @@ hipError_t launch_reduce(const GroupDesc *groups, int count, const double *parti
 
 hipError_t launch_lm_step(const GroupDesc *groups, int count, const double *partials, PoseState *poses,
                           LMState *states, LMCold *cold, LMTrace *traces, const LMOptions &opt, int *progress,
-                          LMState *host_states, LMTrace *host_traces, hipStream_t stream) {
+                          LMState *host_states, LMTrace *host_traces, const GroupDesc &first, hipStream_t stream) {
   if (count <= 0) return hipSuccess;
   if (opt.strategy == 0)
     hipLaunchKernelGGL(ea_lm_step_kernel<0>, dim3(count), dim3(kLmThreads), 0, stream, groups, partials, poses,
-                       states, cold, traces, opt, progress, host_states, host_traces);
+                       states, cold, traces, opt, progress, host_states, host_traces, first);
   else
     hipLaunchKernelGGL(ea_lm_step_kernel<1>, dim3(count), dim3(kLmThreads), 0, stream, groups, partials, poses,
-                       states, cold, traces, opt, progress, host_states, host_traces);
+                       states, cold, traces, opt, progress, host_states, host_traces, first);
   return hipGetLastError();
 }
 
