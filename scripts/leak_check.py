@@ -20,7 +20,16 @@ def cycle():
     P = capi.Problem(*big['K'], dtype=capi.EA_F32); P.set_points(big['xyz']); P.set_dt_grid(big['grid'])
     P.eval([1., 0, 0, 0], [0, 0, 0]); P.eval_points([1., 0, 0, 0], [0, 0, 0]); P.get_points(); P.close()
     P = capi.Problem(525.0, 525.0, 319.5, 239.5, dtype=capi.EA_F64)
-    P.set_ref_frame(bgr, depth); P.set_now_frame(bgr); P.set_ref_frame_canny(bgr, depth); P.set_now_frame_canny(bgr); P.solve([1., 0, 0, 0], [0, 0, 0], max_num_iterations=3); P.close()
+    P.set_ref_frame(bgr, depth); P.set_now_frame(bgr); P.set_ref_frame_canny(bgr, depth); P.set_now_frame_canny(bgr); P.solve([1., 0, 0, 0], [0, 0, 0], max_num_iterations=3)
+    P.pixel_cost([1., 0, 0, 0], [0, 0, 0]); P.close()
+    # round 2: scaled ROS producers (staging buffer), bench graph, sharded device solve (event + one-row descriptor)
+    P = capi.Problem(262.5, 262.5, 159.75, 119.75, dtype=capi.EA_F64)
+    P.set_flavour(z_guard=0.0, z_eps=0.001, rot_transposed=True)
+    big_bgr = np.repeat(np.repeat(bgr, 2, axis=0), 2, axis=1); big_depth = np.repeat(np.repeat(depth, 2, axis=0), 2, axis=1).astype(np.float32) / 5000.0
+    P.set_ref_frame_ros(big_bgr, big_depth, halvings=1); P.set_now_frame_ros(big_bgr, halvings=1)
+    sums = torch.zeros(32, dtype=torch.float64, device='cuda')
+    P.solve_sharded_device([1., 0, 0, 0], [0, 0, 0], lambda stream: None, sums.data_ptr(), max_num_iterations=3)
+    B = capi.Batch([P]); B.eval([1., 0, 0, 0], [0, 0, 0]); B.bench_capture(4); B.bench_steps(4); B.close(); P.close()
 for _ in range(3): cycle()
 torch.cuda.synchronize(); free0 = torch.cuda.mem_get_info()[0]
 for i in range(40): cycle()
