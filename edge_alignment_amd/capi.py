@@ -569,7 +569,7 @@ class Batch:
     def bench_steps(self, steps, host_times=False):
         """`steps` x (fused evaluation + fold) at the poses already on the device, then a stream sync: the timed region"""
         if host_times:
-            us = np.zeros(2)
+            us = np.zeros(3)
             _check(load().ea_batch_bench_steps(self._h, int(steps), _dp(us)))
             return us
         _check(load().ea_batch_bench_steps(self._h, int(steps), None))

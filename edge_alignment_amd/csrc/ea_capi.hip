@@ -183,6 +183,7 @@ struct ea_batch {
   int t_buf = -1, buffer_loads = 0;  // raw-buffer addressing of the DT image and the points (needs a < 2 GiB image)
   std::vector<ea_batch *> parts;  // sub-batches of the concurrent solve (ea_batch_solve)
   bool built = false;
+  hipEvent_t bench_e0 = nullptr, bench_e1 = nullptr;
   hipGraphExec_t bench_graph = nullptr;  // K x (evaluation + fold) captured once (ea_batch_bench_capture), replayed by
   int bench_graph_steps = 0;             // ea_batch_bench_steps(K): the timed region then holds no per-launch host work
   bool needs_drain = false;     // a solve gave up on its deadline with launches still queued: synchronise before reuse
@@ -512,6 +513,8 @@ extern "C" int ea_problem_set_flavour(ea_problem *p, double z_guard, double z_ep
 
 static void batch_free_device(ea_batch *b) {
   if (b->bench_graph) { (void)hipGraphExecDestroy(b->bench_graph); b->bench_graph = nullptr; b->bench_graph_steps = 0; }
+  if (b->bench_e0) { (void)hipEventDestroy(b->bench_e0); b->bench_e0 = nullptr; }
+  if (b->bench_e1) { (void)hipEventDestroy(b->bench_e1); b->bench_e1 = nullptr; }
   (void)hipFree(b->d_one_row); b->d_one_row = nullptr;
   if (b->round_done) { (void)hipEventDestroy(b->round_done); b->round_done = nullptr; }
   (void)hipFree(b->d_probs); (void)hipFree(b->d_groups); (void)hipFree(b->d_lm_block); (void)hipFree(b->d_cold);
@@ -1173,7 +1176,14 @@ extern "C" int ea_batch_bench_steps(ea_batch *b, int steps, double *host_us) {
   if (rc != EA_OK) return rc;
   if (!b->poses_uploaded) return fail(EA_ERR_STATE, "no poses uploaded yet (ea_batch_bench_eval or ea_batch_eval first)");
   const int count = (int)b->probs.size();
+  // host_us != NULL: also an event pair around the region on the stream ([2] = milliseconds between them): the device's
+  // own view of the K steps, from which bench.py takes the evaluation kernel's share of a step
+  if (host_us && (!b->bench_e0 || !b->bench_e1)) {
+    HIPCHK(hipEventCreate(&b->bench_e0));
+    HIPCHK(hipEventCreate(&b->bench_e1));
+  }
   const auto t0 = std::chrono::steady_clock::now();
+  if (host_us) HIPCHK(hipEventRecord(b->bench_e0, b->stream));
   if (b->bench_graph && b->bench_graph_steps == steps) {
     HIPCHK(hipGraphLaunch(b->bench_graph, b->stream));
   } else {
@@ -1182,11 +1192,15 @@ extern "C" int ea_batch_bench_steps(ea_batch *b, int steps, double *host_us) {
       HIPCHK(launch_reduce(b->d_groups, count, b->d_partials, b->d_out, b->stream));
     }
   }
+  if (host_us) HIPCHK(hipEventRecord(b->bench_e1, b->stream));
   const auto t1 = std::chrono::steady_clock::now();
   HIPCHK(hipStreamSynchronize(b->stream));
   if (host_us) {
     host_us[0] = std::chrono::duration<double, std::micro>(t1 - t0).count();
     host_us[1] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, b->bench_e0, b->bench_e1));
+    host_us[2] = ms;
   }
   return EA_OK;
 }

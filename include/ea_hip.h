@@ -271,7 +271,8 @@ int ea_batch_bench_eval(ea_batch *b, const double *q, const double *t, int warmu
  * poses the last ea_batch_bench_eval / ea_batch_eval uploaded, then a stream synchronisation.  No pose upload, no event
  * creation, no allocation inside: whoever brackets this call with a wall clock times exactly K steps (round 1's bracket
  * contained ~70 us of setup, a third of a 20-step run).  EA_ERR_STATE when no poses have been uploaded yet. */
-int ea_batch_bench_steps(ea_batch *b, int steps, double *host_us /* nullable: [0] enqueue, [1] wait, microseconds */);
+int ea_batch_bench_steps(ea_batch *b, int steps, double *host_us /* nullable, 3 doubles: [0] enqueue and [1] wait in
+                         microseconds of host time, [2] milliseconds between a HIP event pair around the region on the stream */);
 /* Untimed set-up for it: capture `steps` x (evaluation + fold) into a hipGraph once; ea_batch_bench_steps with the same
  * `steps` then replays the graph (one host call, the launches execute back to back from the queue) instead of enqueueing
  * 2 x steps launches at ~3 us of host time each.  Dropped when the batch's problems or tuning change. */
