@@ -21,7 +21,8 @@
 namespace ea {
 hipError_t launch_eval_fused(int dtype, int ppt, int nt, int variant, const ProblemDesc *probs, int nterms, int chunk,
                              int max_chunks, int xcd_remap, const PoseState *poses, double *partials,
-                             int lds_bytes, int terms_are_groups, int buffer_loads, hipStream_t stream);
+                             int lds_bytes, int terms_are_groups, int buffer_loads, const void *x0, const void *y0,
+                             const void *z0, int n0, hipStream_t stream);
 hipError_t launch_pixel_cost(int dtype, const ProblemDesc *probs, int problem, int n, const PoseState *poses, void *partials,
                              hipStream_t stream);
 hipError_t launch_eval_points(int dtype, const ProblemDesc *probs, int problem, int n, const PoseState *poses,
@@ -187,6 +188,8 @@ struct ea_batch {
   hipGraphExec_t bench_graph = nullptr;  // K x (evaluation + fold) captured once (ea_batch_bench_capture), replayed by
   int bench_graph_steps = 0;             // ea_batch_bench_steps(K): the timed region then holds no per-launch host work
   bool needs_drain = false;     // a solve gave up on its deadline with launches still queued: synchronise before reuse
+  const void *x0 = nullptr, *y0 = nullptr, *z0 = nullptr;  // problem 0's point arrays and count, handed to the evaluation
+  int n0 = 0;                                              // kernel in its preloaded arguments
   GroupDesc group0 = {0, 0, 0, 0};  // host copy of d_groups[0]: handed to the step kernel by value
   hipEvent_t round_done = nullptr;  // behind the last step kernel of a round of ea_solve_sharded_device
   GroupDesc *d_one_row = nullptr;  // {0, 1, 0, 1}: "one partial row" for the step kernel of ea_solve_sharded_device
@@ -721,6 +724,8 @@ static int batch_build(ea_batch *b) {
   }
   b->nterms = (int)terms.size();
   b->group0 = groups.empty() ? GroupDesc{0, 0, 0, 0} : groups[0];
+  if (!descs.empty()) { b->x0 = descs[0].x; b->y0 = descs[0].y; b->z0 = descs[0].z; b->n0 = descs[0].n; }
+  else { b->x0 = b->y0 = b->z0 = nullptr; b->n0 = 0; }
   b->ntiles = rows;
   b->max_chunks = max_chunks;
   if (b->nterms > b->terms_cap) {
@@ -784,7 +789,7 @@ static void host_pose_state(const ea_problem *p, const double *q, const double *
 static int batch_launch_eval(ea_batch *b) {
   HIPCHK(launch_eval_fused(b->dtype, b->ppt, b->nt, b->any_variant, b->d_probs, b->nterms, b->chunk, b->max_chunks,
                            b->xcd_remap, b->d_poses, b->d_partials, b->lds_bytes, b->terms_are_groups, b->buffer_loads,
-                           b->stream));
+                           b->x0, b->y0, b->z0, b->n0, b->stream));
   return EA_OK;
 }
 

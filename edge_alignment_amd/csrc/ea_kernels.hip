@@ -179,6 +179,25 @@ template <> struct Uni<float> {
   static __device__ __forceinline__ const float *di(const ProblemDesc &pd) { return pd.dif; }
 };
 
+// The pose as the fused kernel carries it: rotation and translation in the kernel's arithmetic type, held in SGPRs
+// (fetched speculatively in the same batch as the descriptor), the rarely needed rest through a pointer.
+template <typename T>
+struct PoseLite {
+  T R[9], t[3];
+  int unit_q;
+  const PoseState *full;
+};
+template <typename T> struct PoseAcc {
+  static __device__ __forceinline__ const T *R(const PoseState &ps) { return Uni<T>::R(ps); }
+  static __device__ __forceinline__ const T *t(const PoseState &ps) { return Uni<T>::t(ps); }
+  static __device__ __forceinline__ const T *G(const PoseState &ps) { return Uni<T>::G(ps); }
+  static __device__ __forceinline__ int unit_q(const PoseState &ps) { return ps.unit_q; }
+  static __device__ __forceinline__ const T *R(const PoseLite<T> &ps) { return ps.R; }
+  static __device__ __forceinline__ const T *t(const PoseLite<T> &ps) { return ps.t; }
+  static __device__ __forceinline__ const T *G(const PoseLite<T> &ps) { return Uni<T>::G(*ps.full); }
+  static __device__ __forceinline__ int unit_q(const PoseLite<T> &ps) { return ps.unit_q; }
+};
+
 // per-point state carried from the projection phase to the sampling phase
 template <typename T>
 struct Proj {
@@ -190,11 +209,11 @@ struct Proj {
   int state;       // 0 = lane has no point, 1 = valid, 2 = functor returned false
 };
 
-template <typename T>
-__device__ __forceinline__ void project_point(const ProblemDesc &pd, const PoseState &ps, T x, T y, T z,
+template <typename T, typename PS>
+__device__ __forceinline__ void project_point(const ProblemDesc &pd, const PS &ps, T x, T y, T z,
                                               Proj<T> &o) {
-  const T *R = Uni<T>::R(ps);
-  const T *t = Uni<T>::t(ps);
+  const T *R = PoseAcc<T>::R(ps);
+  const T *t = PoseAcc<T>::t(ps);
   const T cxr = t_fma<T>(R[2], z, t_fma<T>(R[1], y, R[0] * x));
   const T cyr = t_fma<T>(R[5], z, t_fma<T>(R[4], y, R[3] * x));
   const T czr = t_fma<T>(R[8], z, t_fma<T>(R[7], y, R[6] * x));
@@ -236,11 +255,11 @@ struct ProjV {
   int state;
 };
 
-template <typename T>
-__device__ __forceinline__ void project_point_var(const ProblemDesc &pd, const PoseState &ps, T px, T py, T pz,
+template <typename T, typename PS>
+__device__ __forceinline__ void project_point_var(const ProblemDesc &pd, const PS &ps, T px, T py, T pz,
                                                   ProjV<T> &o) {
-  const T *R = Uni<T>::R(ps);
-  const T *t = Uni<T>::t(ps);
+  const T *R = PoseAcc<T>::R(ps);
+  const T *t = PoseAcc<T>::t(ps);
   T ax = px, ay = py, az = pz;
   if (pd.variant & 2) {
     const T *Ai = Uni<T>::Ai(pd), *di = Uni<T>::di(pd);
@@ -290,8 +309,8 @@ __device__ __forceinline__ void project_point_var(const ProblemDesc &pd, const P
   o.state = bad ? 2 : 1;
 }
 
-template <typename T>
-__device__ __forceinline__ void jacobian_row_var(const ProblemDesc &pd, const PoseState &ps, const ProjV<T> &pr,
+template <typename T, typename PS>
+__device__ __forceinline__ void jacobian_row_var(const ProblemDesc &pd, const PS &ps, const ProjV<T> &pr,
                                                  T Fu, T Fv, T J[6]) {
   const T fu_ = Fu * Uni<T>::fx(pd), fv_ = Fv * Uni<T>::fy(pd);
   const T rx = t_fma<T>(fv_, pr.ydx, fu_ * pr.xdx);  // d r / d x
@@ -304,7 +323,7 @@ __device__ __forceinline__ void jacobian_row_var(const ProblemDesc &pd, const Po
     const T g2 = t_fma<T>(A[8], gz, t_fma<T>(A[5], gy, A[2] * gx));
     gx = g0; gy = g1; gz = g2;
   }
-  if (ps.unit_q) {
+  if (PoseAcc<T>::unit_q(ps)) {
     J[0] = T(2) * t_fma<T>(pr.cy_, gz, -(pr.cz_ * gy));
     J[1] = T(2) * t_fma<T>(pr.cz_, gx, -(pr.cx_ * gz));
     J[2] = T(2) * t_fma<T>(pr.cx_, gy, -(pr.cy_ * gx));
@@ -314,7 +333,7 @@ __device__ __forceinline__ void jacobian_row_var(const ProblemDesc &pd, const Po
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const T *G = Uni<T>::G(ps) + 9 * j;
+      const T *G = PoseAcc<T>::G(ps) + 9 * j;
       const T d0 = t_fma<T>(G[2], pr.az, t_fma<T>(G[1], pr.ay, G[0] * pr.ax));
       const T d1 = t_fma<T>(G[5], pr.az, t_fma<T>(G[4], pr.ay, G[3] * pr.ax));
       const T d2 = t_fma<T>(G[8], pr.az, t_fma<T>(G[7], pr.ay, G[6] * pr.ax));
@@ -372,13 +391,13 @@ __device__ __forceinline__ void loss_eval(int kind, T a, T inv_b, T s, T &rho, T
 }
 
 // raw 1x6 row of one point from its sample gradient
-template <typename T>
-__device__ __forceinline__ void jacobian_row(const ProblemDesc &pd, const PoseState &ps,
+template <typename T, typename PS>
+__device__ __forceinline__ void jacobian_row(const ProblemDesc &pd, const PS &ps,
                                              const Proj<T> &pr, T x, T y, T z, T Fu, T Fv, T J[6]) {
   const T gx = Fu * pr.fxz;
   const T gy = Fv * pr.fyz;
   const T gz = -t_fma<T>(gx, pr.bx, gy * pr.by) * pr.iz;
-  if (ps.unit_q) {
+  if (PoseAcc<T>::unit_q(ps)) {
     // d b / d delta = -2 [R a]x  =>  J_delta = 2 (R a) x g
     J[0] = T(2) * t_fma<T>(pr.cy_, gz, -(pr.cz_ * gy));
     J[1] = T(2) * t_fma<T>(pr.cz_, gx, -(pr.cx_ * gz));
@@ -389,7 +408,7 @@ __device__ __forceinline__ void jacobian_row(const ProblemDesc &pd, const PoseSt
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const T *G = Uni<T>::G(ps) + 9 * j;
+      const T *G = PoseAcc<T>::G(ps) + 9 * j;
       const T d0 = t_fma<T>(G[2], z, t_fma<T>(G[1], y, G[0] * x));
       const T d1 = t_fma<T>(G[5], z, t_fma<T>(G[4], y, G[3] * x));
       const T d2 = t_fma<T>(G[8], z, t_fma<T>(G[7], y, G[6] * x));
@@ -700,8 +719,8 @@ constexpr int kHdrBytes = kRedBytes + kMaxWaves * 16;  // + bbox words, keeps th
 // One workgroup's share of an evaluation: NT lanes x PPT points -> the workgroup's partial row.
 // X/Y/Z hold the lane's points (lanes past `count` carry a copy of the chunk's last point); the return value is
 // slot `my_slot` of the row (0 when my_slot < 0).  `ps` may live in global memory (scalar loads) or LDS.
-template <typename T, int PPT, int MODE, int NT, bool VAR, bool BUF>
-__device__ __forceinline__ double fused_chunk(const ProblemDesc &pd, const PoseState &ps, const T (&X)[PPT],
+template <typename T, int PPT, int MODE, int NT, bool VAR, bool BUF, typename PS>
+__device__ __forceinline__ double fused_chunk(const ProblemDesc &pd, const PS &ps, const T (&X)[PPT],
                                               const T (&Y)[PPT], const T (&Z)[PPT], int count, double *s_red,
                                               int *s_box, T *s_tile, int lds_texels, int my_slot) {
   // MODE 0: stencil rows from L2.  1: DT footprint staged in LDS.
@@ -863,9 +882,15 @@ __device__ __forceinline__ double fused_chunk(const ProblemDesc &pd, const PoseS
 // to fold afterwards at the same points-per-lane latency.
 template <typename T, int PPT, int MODE, int NT, bool VAR, bool BUF>
 __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
+    // the first 16 dwords of the argument segment arrive in SGPRs with the wave (kernarg preload): what problem 0's point
+    // loads need sits there, so that they can be issued at once, beside the descriptor fetch instead of behind it
+    // (14 dwords fit beside the argument pointer: three pointers, the count, the launch shape packed into one word --
+    // chunk | xcd_remap << 16 | terms_are_groups << 17 --, chunks per XCD, and the descriptor and pose tables)
+    const void *__restrict__ x0, const void *__restrict__ y0, const void *__restrict__ z0, int n0,
+    int shape, int chunks_per_xcd,
     const ProblemDesc *__restrict__ probs, const PoseState *__restrict__ poses,
-    double *__restrict__ partials, int chunk, int chunks_per_xcd, int xcd_remap, int lds_texels,
-    int terms_are_groups) {
+    double *__restrict__ partials, int lds_texels) {
+  const int chunk = shape & 0xffff, xcd_remap = (shape >> 16) & 1, terms_are_groups = (shape >> 17) & 1;
   extern __shared__ __align__(16) unsigned char smem[];
   double *s_red = reinterpret_cast<double *>(smem);
   int *s_box = reinterpret_cast<int *>(smem + kRedBytes);
@@ -876,33 +901,86 @@ __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
   EA_STAMP(0);
   const int bx = blockIdx.x;
   const int c = xcd_remap ? (bx & 7) * chunks_per_xcd + (bx >> 3) : bx;
+  const long long start = (long long)c * chunk;
+  const int tid = threadIdx.x;
+  T X[PPT], Y[PPT], Z[PPT];
+  // Problem 0 (every single-problem launch: C2, an LM iteration): its point arrays and count came with the wave, so the
+  // coalesced point loads go out now and travel while the descriptor and the pose are fetched -- one dependent memory
+  // round trip less in the chain descriptor -> points -> stencil rows that bounds a small launch.
+  const bool early = BUF && blockIdx.y == 0 && n0 > 0;  // (uniform)
+  if constexpr (BUF) {
+    if (early) {
+      if (start >= n0) return;
+      const int count0 = min(chunk, (int)(n0 - start));
+      const __amdgpu_buffer_rsrc_t rx = make_raw_buffer(static_cast<const T *>(x0) + start, (unsigned)count0 * (unsigned)sizeof(T));
+      const __amdgpu_buffer_rsrc_t ry = make_raw_buffer(static_cast<const T *>(y0) + start, (unsigned)count0 * (unsigned)sizeof(T));
+      const __amdgpu_buffer_rsrc_t rz = make_raw_buffer(static_cast<const T *>(z0) + start, (unsigned)count0 * (unsigned)sizeof(T));
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const int poff = min(tid + k * NT, count0 - 1) * (int)sizeof(T);
+        X[k] = buf_load_elem<T>(rx, poff); Y[k] = buf_load_elem<T>(ry, poff); Z[k] = buf_load_elem<T>(rz, poff);
+      }
+    }
+  }
   // descriptor and pose by value: every scalar load is issued here, behind one wait, instead of a
   // chain of dependent loads at the points of use
   const ProblemDesc pd = probs[blockIdx.y];
   // one pose per group of terms; when every problem is a single residual family the group index is
   // the term index and the pose load does not have to wait for the descriptor
-  const PoseState &ps = poses[terms_are_groups ? (int)blockIdx.y : pd.group];
-  const int active = ps.active;
-  const long long start = (long long)c * chunk;
+  // The pose is fetched SPECULATIVELY from the slot of this term's own index -- the right one whenever every problem is a
+  // single residual family (terms_are_groups), and then independent of the descriptor -- into scalars, beside the
+  // descriptor.  Every uniform the common path reads is named in front of the early exit: descriptor and pose go out as
+  // ONE batch of scalar loads behind one wait.  Left alone the compiler fetches what the exit test needs, then the
+  // pose's flag, then the rest: three dependent round trips at the head of every workgroup.
+  PoseLite<T> ps;
+  int active;
+  {
+    const PoseState *psp = poses + blockIdx.y;
+    const T *R_ = Uni<T>::R(*psp), *t_ = Uni<T>::t(*psp);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) ps.R[i] = R_[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ps.t[i] = t_[i];
+    ps.unit_q = psp->unit_q;
+    ps.full = psp;
+    active = psp->active;
+    asm volatile("" ::"s"(pd.x), "s"(pd.y), "s"(pd.z), "s"(pd.dt), "s"(pd.n), "s"(pd.W), "s"(pd.H), "s"(pd.pitch),
+                 "s"(Uni<T>::fx(pd)), "s"(Uni<T>::fy(pd)), "s"(Uni<T>::cx(pd)), "s"(Uni<T>::cy(pd)),
+                 "s"(Uni<T>::loss_a(pd)), "s"(Uni<T>::loss_inv_b(pd)), "s"(Uni<T>::z_guard(pd)), "s"(Uni<T>::z_eps(pd)),
+                 "s"(pd.loss_kind), "s"(pd.tile_begin), "s"(pd.variant), "s"(pd.group));
+    asm volatile("" : "+s"(active), "+s"(ps.unit_q), "+s"(ps.R[0]), "+s"(ps.R[1]), "+s"(ps.R[2]), "+s"(ps.R[3]), "+s"(ps.R[4]),
+                      "+s"(ps.R[5]), "+s"(ps.R[6]), "+s"(ps.R[7]), "+s"(ps.R[8]), "+s"(ps.t[0]), "+s"(ps.t[1]), "+s"(ps.t[2]));
+    if (!terms_are_groups && pd.group != (int)blockIdx.y) {  // (uniform, rare: a term that shares another term's pose)
+      psp = poses + pd.group;
+      R_ = Uni<T>::R(*psp); t_ = Uni<T>::t(*psp);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) ps.R[i] = R_[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) ps.t[i] = t_[i];
+      ps.unit_q = psp->unit_q;
+      ps.full = psp;
+      active = psp->active;
+    }
+  }
   if (start >= pd.n || !active) return;
   const int count = min(chunk, (int)(pd.n - start));
   EA_STAMP(1);  // descriptor + pose.active arrived
 
-  const int tid = threadIdx.x;
   const GPtr<T> px = (GPtr<T>)(static_cast<const T *>(pd.x) + start);
   const GPtr<T> py = (GPtr<T>)(static_cast<const T *>(pd.y) + start);
   const GPtr<T> pz = (GPtr<T>)(static_cast<const T *>(pd.z) + start);
   // coalesced point loads; lanes past the end of the chunk re-read its last point
-  T X[PPT], Y[PPT], Z[PPT];
   if constexpr (BUF) {
-    // the chunk's points as three raw buffers: one 32-bit offset per lane serves all three loads
-    const __amdgpu_buffer_rsrc_t rx = make_raw_buffer((const T *)px, (unsigned)count * (unsigned)sizeof(T));
-    const __amdgpu_buffer_rsrc_t ry = make_raw_buffer((const T *)py, (unsigned)count * (unsigned)sizeof(T));
-    const __amdgpu_buffer_rsrc_t rz = make_raw_buffer((const T *)pz, (unsigned)count * (unsigned)sizeof(T));
+    if (!early) {
+      // the chunk's points as three raw buffers: one 32-bit offset per lane serves all three loads
+      const __amdgpu_buffer_rsrc_t rx = make_raw_buffer((const T *)px, (unsigned)count * (unsigned)sizeof(T));
+      const __amdgpu_buffer_rsrc_t ry = make_raw_buffer((const T *)py, (unsigned)count * (unsigned)sizeof(T));
+      const __amdgpu_buffer_rsrc_t rz = make_raw_buffer((const T *)pz, (unsigned)count * (unsigned)sizeof(T));
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-      const int poff = min(tid + k * NT, count - 1) * (int)sizeof(T);
-      X[k] = buf_load_elem<T>(rx, poff); Y[k] = buf_load_elem<T>(ry, poff); Z[k] = buf_load_elem<T>(rz, poff);
+      for (int k = 0; k < PPT; ++k) {
+        const int poff = min(tid + k * NT, count - 1) * (int)sizeof(T);
+        X[k] = buf_load_elem<T>(rx, poff); Y[k] = buf_load_elem<T>(ry, poff); Z[k] = buf_load_elem<T>(rz, poff);
+      }
     }
   } else {
 #pragma unroll
@@ -916,7 +994,7 @@ __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
   asm volatile("" ::"v"(X[0]), "v"(Y[0]), "v"(Z[0]));
 #endif
   EA_STAMP(2);  // points arrived
-  const double sum = fused_chunk<T, PPT, MODE, NT, VAR, BUF>(pd, ps, X, Y, Z, count, s_red, s_box, s_tile, lds_texels,
+  const double sum = fused_chunk<T, PPT, MODE, NT, VAR, BUF, PoseLite<T>>(pd, ps, X, Y, Z, count, s_red, s_box, s_tile, lds_texels,
                                                            tid < kAccSlots ? tid : -1);
   if (tid < kAccSlots) partials[(size_t)(pd.tile_begin + c) * kAccSlots + tid] = sum;
 #ifdef EA_STAMPS
@@ -1279,16 +1357,19 @@ __global__ void ea_pad_image_kernel(const T *__restrict__ src, int H, int W, T *
 
 hipError_t launch_eval_fused(int dtype, int ppt, int nt, int variant, const ProblemDesc *probs, int nterms, int chunk,
                              int max_chunks, int xcd_remap, const PoseState *poses, double *partials,
-                             int lds_bytes, int terms_are_groups, int buffer_loads, hipStream_t stream) {
+                             int lds_bytes, int terms_are_groups, int buffer_loads, const void *x0, const void *y0,
+                             const void *z0, int n0, hipStream_t stream) {
   if (nterms <= 0 || max_chunks <= 0) return hipSuccess;
   const int chunks_per_xcd = (max_chunks + 7) / 8;
   const dim3 grid(xcd_remap ? chunks_per_xcd * 8 : max_chunks, nterms);
+  if (chunk <= 0 || chunk > 0xffff) return hipErrorInvalidValue;  // (NT * PPT <= 4096)
+  const int shape = chunk | ((xcd_remap ? 1 : 0) << 16) | ((terms_are_groups ? 1 : 0) << 17);
   const int esz = dtype == 1 ? 4 : 8;
   const int lds_texels = lds_bytes > 0 ? lds_bytes / esz : 0;
   const size_t shmem = (size_t)kHdrBytes + (size_t)lds_texels * esz;
 #define EA_LAUNCH_B(T, P, L, N, V, B)                                                              \
-  hipLaunchKernelGGL((ea_eval_fused_kernel<T, P, L, N, V, B>), grid, dim3(N), shmem, stream, probs, \
-                     poses, partials, chunk, chunks_per_xcd, xcd_remap, lds_texels, terms_are_groups)
+  hipLaunchKernelGGL((ea_eval_fused_kernel<T, P, L, N, V, B>), grid, dim3(N), shmem, stream, x0, y0, z0, n0, shape, \
+                     chunks_per_xcd, probs, poses, partials, lds_texels)
 #define EA_LAUNCH(T, P, L, N, V)                                                                   \
   do {                                                                                             \
     if (buffer_loads && (L) == 0) EA_LAUNCH_B(T, P, 0, N, V, true); else EA_LAUNCH_B(T, P, L, N, V, false); \
