@@ -369,13 +369,26 @@ __device__ __forceinline__ void bicubic(T fu, T fv, RowFn row, T &f, T &Fu, T &F
 }
 
 // rho(s), rho'(s) — ceres loss_function.cc
+// log(1 + x), x >= 0, as the Cauchy loss needs it.  fp64: log of the rounded sum, what Ceres computes.  fp32: 1 + x rounds
+// x away below 6e-8 and v_log_f32 has only absolute accuracy near 1 -- residuals under ~1e-3 would contribute nothing
+// (or noise) to the cost, and the solve would stop on "cost = 0" short of the fp64 pose (scripts/soak.py found a
+// zero-residual problem ending 1.1e-4 rad away).  Below 2^-7 the series x (1 - x/2 + x^2/3) is used instead: relative
+// error < 2e-7 there, and the hardware log2 is relatively accurate above.
+template <typename T> __device__ __forceinline__ T t_log1p_of(T x, T sum);
+template <> __device__ __forceinline__ double t_log1p_of<double>(double, double sum) { return t_log<double>(sum); }
+template <> __device__ __forceinline__ float t_log1p_of<float>(float x, float sum) {
+  const float series = x * __builtin_fmaf(x, __builtin_fmaf(x, 0.33333334f, -0.5f), 1.0f);
+  return x < 0.0078125f ? series : t_log<float>(sum);
+}
+
 template <typename T>
 __device__ __forceinline__ void loss_eval(int kind, T a, T inv_b, T s, T &rho, T &w) {
   if (kind == 1) {  // Cauchy
     const T b = a * a;
-    const T sum = t_fma<T>(s, inv_b, T(1));
+    const T x = s * inv_b;
+    const T sum = x + T(1);
     w = t_rcp<T>(sum);
-    rho = b * t_log<T>(sum);
+    rho = b * t_log1p_of<T>(x, sum);
   } else if (kind == 2) {  // Huber
     const T b = a * a;
     if (s > b) {
