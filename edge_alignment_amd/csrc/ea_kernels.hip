@@ -303,7 +303,14 @@ __device__ __forceinline__ void project_point_var(const ProblemDesc &pd, const P
   o.x = x; o.y = y; o.iz = iz;
   o.ax = ax; o.ay = ay; o.az = az;
   o.cx_ = cxr; o.cy_ = cyr; o.cz_ = czr;
-  o.fu = u - uf; o.fv = v - vf;
+  // Where the four taps along an axis are the one replicated border texel (floor <= -2 or >= extent), Ceres' Horner
+  // spline returns that texel and a derivative of exactly 0.  The tap-weight form used here returns texel * (sum of the
+  // derivative weights) = texel * O(eps) instead, which the distortion chain rule then multiplies by d(u,v)/d(x,y):
+  // unbounded for points far outside the field of view (r^6 terms; 1e6 .. 1e12 seen in scripts/soak_variants.py, i.e.
+  // rows of O(1..10) where the reference has zeros).  A zero fraction makes the weights (0,1,0,0) / (-.5,0,.5,0) and
+  // both results exact.  (The plain functor's chain factor is fx / b_z <= fx / z_guard, so it keeps the true fraction.)
+  o.fu = (uf <= T(-2) || uf >= (T)pd.W) ? T(0) : u - uf;
+  o.fv = (vf <= T(-2) || vf >= (T)pd.H) ? T(0) : v - vf;
   o.iu = (int)fmin(fmax(uf, T(-2)), (T)pd.W);
   o.iv = (int)fmin(fmax(vf, T(-2)), (T)pd.H);
   o.state = bad ? 2 : 1;

@@ -154,3 +154,34 @@ def test_random_mixed_batches(hip, oracle):
             B.close()
             for P in keep:
                 P.close()
+
+
+@pytest.mark.parametrize("dtype_name", ["EA_F64", "EA_F32"])
+def test_points_far_outside_the_view_have_zero_rows(hip, oracle, dtype_name):
+    """A point whose distorted projection lands far outside the image (r^6 terms: pixel coordinates of 1e6 .. 1e12) reads
+    the replicated border texel: Ceres' Horner spline gives that texel and derivatives of exactly 0, so the 1x6 row is
+    exactly 0 whatever d(u,v)/d(x,y) is.  A tap-weight spline leaves texel * O(eps) there, times that factor (found by
+    scripts/soak_variants.py: rows of O(10) in fp32, 0.1 in fp64, where the oracle has zeros)."""
+    dist = (-0.05, 0.17, 0.002, -0.005, -0.55)
+    fam = synth.make_stereo_problem(120, 160, 2000, 500, 7, K1, K2, T12, Q, T, distortion=dist)[0]
+    rng = np.random.default_rng(3)
+    z = rng.uniform(0.5, 5.0, size=200)
+    wide = np.stack([z * rng.uniform(3, 40, size=200) * rng.choice([-1, 1], size=200),
+                     z * rng.uniform(3, 40, size=200) * rng.choice([-1, 1], size=200), z], axis=1)
+    xyz = np.concatenate([fam["xyz"], wide])
+    P = hip.Problem(*K1, dtype=getattr(hip, dtype_name))
+    P.set_points(xyz); P.set_dt_grid(fam["grid"]); P.set_loss(0, 1.0); P.set_distortion(*dist)
+    X = P.get_points()                     # the cloud as the device holds it (fp32 mode rounds the coordinates)
+    e = oracle.OracleProblem(fam["grid"], *K1, loss=0, distortion=dist).eval(X, Q, T, oracle.JAC_JET, materialize=True)
+    r, J = P.eval_points(Q, T, corrected=False)
+    wide_rows = np.abs(X[:, 0] / X[:, 2]) > 2.9
+    dead = wide_rows & (np.abs(e["raw_J"]).max(axis=1) == 0.0)
+    assert wide_rows.sum() == 200 and dead.sum() >= 150    # (a few wide points fold back into the view)
+    assert np.abs(J[dead]).max() == 0.0
+    tol = 1e-11 if dtype_name == "EA_F64" else 2e-4
+    assert _rel(J, e["raw_J"]) < tol
+    # fp32 reads the fp32 image: the border texel itself is rounded
+    assert np.abs(r[dead] - e["raw_r"][dead]).max() <= (0.0 if dtype_name == "EA_F64" else 1e-6)
+    g = P.eval(Q, T)
+    assert _rel(g["JtJ"], e["JtJ"]) < tol
+    P.close()
