@@ -18,6 +18,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -142,12 +143,17 @@ def main():
     ap.add_argument("--workload", default="c2", choices=["c2", "c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--device-allreduce", action="store_true",
-                    help="with --gpus > 1: also time ea_solve_sharded_device with its all-reduce enqueued on the stream (RCCL)")
+    ap.add_argument("--no-device-allreduce", action="store_true",
+                    help="with --gpus > 1: skip the last leg (ea_solve_sharded_device with its all-reduce enqueued on the stream over RCCL)")
+    ap.add_argument("--device-allreduce", action="store_true", help=argparse.SUPPRESS)  # (round-2 spelling; now the default)
+    ap.add_argument("--extras-timeout", type=float, default=240.0,
+                    help="seconds the secondary measurements may take before the line is printed without the unfinished ones")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the timed steps launch by launch instead of replaying a hipGraph")
     # rehearsal knobs (the driver never passes them): run the N>1 control flow on a one-GPU box
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--force-device", type=int, default=None, help="use this HIP device on every rank")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="world size 1: create the process group anyway and take the N>1 branches (RCCL on a one-rank group)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -161,9 +167,12 @@ def main():
     if args.force_device is not None:
         local_rank = args.force_device
     coll_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
-    if world > 1:
+    multi = world > 1 or args.force_dist   # the N>1 control flow (collectives on coll_dev)
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29511"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -257,8 +266,45 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_launch,
                 "secondary": valu_issue(args.workload, ms_kernel_b2b)}
 
-    extras = {}
+    # The line's mandatory part is complete here.  Everything below is secondary; a watchdog prints the line without the
+    # unfinished measurements if they take longer than --extras-timeout (a collective meeting a real node for the first
+    # time must not cost the scaling record) and ends the process; every rank runs one.
+    base = None
+    if rank == 0:
+        base = {"metric": "edge-point residual+Jacobian evals/sec", "value": value, "unit": "evals/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": tag, "data": "synthetic",
+                "config": {"workload": desc, "points_per_gpu": int(n_pts), "dt_image": "%dx%d" % (W, H),
+                           "parallelism": "independent frame pairs, one per GPU; single RCCL pose all-gather",
+                           "tiles": B.info("num_tiles"), "points_per_thread": B.info("points_per_thread"),
+                           "lds_bytes": B.info("lds_bytes"), "point_order_tile_px": P.point_order,
+                           "timed_region": graph or "eager launches"},
+                "roofline": roofline}
+    extras, others, leg = {}, {}, ["start"]
+
+    def compose(note=None):
+        out = dict(base)
+        out.update(extras)
+        if others:
+            out["other_workloads"] = dict(others)
+        out.setdefault("cpu_baseline", None)
+        if note:
+            out["extras_incomplete"] = note
+        return out
+
+    def on_timeout():
+        if rank == 0:
+            sys.stdout.write(json.dumps(compose("timed out after %.0f s in: %s" % (args.extras_timeout, leg[0]))) + "\n")
+            sys.stdout.flush()
+        os._exit(0)
+    watchdog = threading.Timer(args.extras_timeout, on_timeout)
+    watchdog.daemon = True
     if not args.no_extras:
+        watchdog.start()
+
+    if not args.no_extras:
+        leg[0] = "LM iterations/s at 1e5 points"
         # LM iterations/s at 1e5 points (second headline of BASELINE.json), device-resident loop
         cfg2, dt2, _, loss2, _ = build_workload("lm1e5", rank)
         P2 = capi.Problem(*cfg2["K"], dtype=dt2, device=local_rank)
@@ -275,7 +321,7 @@ def main():
         el = time.perf_counter() - ts
         lm_local = its / el
         # the one collective: all-gather of the solved poses (7 doubles + status per problem)
-        pg1 = ead.PoseGather(1, world, device=coll_dev if world > 1 else "cpu")  # tensors allocated once, outside the clock
+        pg1 = ead.PoseGather(1, world, device=coll_dev if multi else "cpu", force_collective=multi)  # tensors allocated once, outside the clock
         pg1.gather([q], [t], [s["termination"]])
         tg = time.perf_counter()
         qa, ta, st = pg1.gather([q], [t], [s["termination"]])
@@ -289,10 +335,10 @@ def main():
         from edge_alignment_amd import synth
         err_rot = synth.rotation_angle_between(q, cfg2["q_true"])
         err_t = float(np.linalg.norm(t - cfg2["t_true"]))
-        extras = {"lm_iters_per_s_at_1e5_pts": lm_total, "lm_iters_per_s_at_1e5_pts_library_clock": its / (lib_ms * 1e-3),
+        extras.update({"lm_iters_per_s_at_1e5_pts": lm_total, "lm_iters_per_s_at_1e5_pts_library_clock": its / (lib_ms * 1e-3),
                   "lm_iterations_per_solve": its / reps,
                   "lm_solve_ms": el / reps * 1e3, "pose_gather_ms": gather_ms,
-                  "lm_pose_err_vs_planted": {"rad": err_rot, "m": err_t}}
+                  "lm_pose_err_vs_planted": {"rad": err_rot, "m": err_t}})
         if rank == 0 and world == 1:
             # the same problem in fp32 (the arithmetic of BASELINE configs C3 / C5; pose tolerance 1e-4 rad / 1e-3 m)
             try:
@@ -314,11 +360,12 @@ def main():
                 extras["lm_fp32_at_1e5_pts"] = {"error": repr(e)}
         # the other way to use N GPUs on this path: ONE 1e5-point problem sharded by points, an
         # all-reduce of the 32 accumulator slots per iteration (RCCL when world > 1), the step replicated on every rank
+        leg[0] = "point-sharded LM, all-reduce through the host"
         try:
             sl = ead.shard_slice(cfg2["xyz"].shape[0], rank, world)
             P3 = capi.Problem(*cfg2["K"], dtype=dt2, device=local_rank)
             P3.set_points(cfg2["xyz"][sl]); P3.set_dt_grid(cfg2["grid"]); P3.set_loss(*loss2)
-            ar = ead.make_allreduce(world, device=coll_dev if world > 1 else "cpu")
+            ar = ead.make_allreduce(world, device=coll_dev if multi else "cpu", force_collective=multi)
             P3.solve_sharded(q0, t0, ar)
             barrier_sync()
             ts = time.perf_counter()
@@ -332,23 +379,6 @@ def main():
                                                   "points_per_gpu": int(sl.stop - sl.start),
                                                   "pose_err_vs_planted": {"rad": synth.rotation_angle_between(q3, cfg2["q_true"]),
                                                                           "m": float(np.linalg.norm(t3 - cfg2["t_true"]))}}
-            # the same solve with the exchange kept on the stream (ea_solve_sharded_device): on one rank always (nothing to
-            # enqueue: measures the path without the host hop); over RCCL only on request -- it has been rehearsed with gloo
-            # only, and a collective that misbehaves on its first contact with a real node must not cost the scaling record
-            if world == 1 or args.device_allreduce:
-                sums, enqueue = ead.make_device_allreduce(world, torch.device("cuda", local_rank))
-                P3.solve_sharded_device(q0, t0, enqueue, sums.data_ptr())
-                barrier_sync()
-                ts = time.perf_counter()
-                its4 = 0
-                for _ in range(reps3):
-                    q4, t4, s4 = P3.solve_sharded_device(q0, t0, enqueue, sums.data_ptr())
-                    its4 += s4["num_iterations"]
-                barrier_sync()
-                el4 = time.perf_counter() - ts
-                extras["lm_point_sharded_device_1e5_pts"] = {"iters_per_s": its4 / el4, "solve_ms": el4 / reps3 * 1e3,
-                                                             "pose_err_vs_planted": {"rad": synth.rotation_angle_between(q4, cfg2["q_true"]),
-                                                                                     "m": float(np.linalg.norm(t4 - cfg2["t_true"]))}}
             P3.close()
         except Exception as e:  # never let the secondary measurement take the headline line down
             extras["lm_point_sharded_1e5_pts"] = {"error": repr(e)}
@@ -358,6 +388,7 @@ def main():
     # bundled grabs (edge points of frame A, distance transform of frame B), ONE ea_batch_solve, ONE all-gather of the
     # 32 x 8 doubles from preallocated device tensors.
     if not args.no_extras:
+        leg[0] = "C4 run shape (32 pairs per GPU, one pose all-gather)"
         c4 = None
         solve_fn = None
         try:
@@ -387,7 +418,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MIN)
             ok = int(tt.item())
         if ok:
-            c4, _ = ead.run_c4(rank, world, build_and_solve, per_gpu=32, device=coll_dev if world > 1 else "cpu", repeats=3)
+            c4, _ = ead.run_c4(rank, world, build_and_solve, per_gpu=32, device=coll_dev if multi else "cpu", repeats=3, force_collective=multi)
             if dist is not None:
                 tt = torch.tensor([c4["lm_iters_per_s_per_gpu"], c4["evals_per_s_per_gpu"]], dtype=torch.float64, device=coll_dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.SUM)
@@ -403,8 +434,8 @@ def main():
 
     # Throughput-regime context for the same kernel (not the headline value): the C5 roofline-stress
     # cloud and a C4-style batch of 32 C2-shaped frame pairs evaluated by one launch.
-    others = {}
     if not args.no_extras and rank == 0 and world == 1:
+        leg[0] = "other workloads"
         from edge_alignment_amd import synth
         def measure(problems, dtype, esz, loss, tile=None, valu_key=None):
             Ps = []
@@ -475,34 +506,52 @@ def main():
         others["batch64_c2_fp64_tile16"] = measure(batch * 2, capi.EA_F64, 8, (capi.LOSS_CAUCHY, 1.0), tile=16)
         others["batch256_c2_fp32_tile16_beyond_infinity_cache"] = measure(batch * 8, capi.EA_F32, 4, (capi.LOSS_CAUCHY, 1.0), tile=16)
 
+    # Last, because it is the one measurement whose collective pattern (RCCL calls enqueued on the library's stream from a
+    # callback, four per round) has only met a one-rank group so far: the point-sharded solve with the exchange kept on
+    # the stream (ea_solve_sharded_device).  On one rank there is nothing to enqueue: the path without the host hop.
+    if not args.no_extras and not (world > 1 and args.no_device_allreduce):
+        leg[0] = "point-sharded LM, all-reduce enqueued on the stream"
+        try:
+            from edge_alignment_amd import synth
+            cfg2, dt2, _, loss2, _ = build_workload("lm1e5", rank)
+            sl = ead.shard_slice(cfg2["xyz"].shape[0], rank, world)
+            P3 = capi.Problem(*cfg2["K"], dtype=dt2, device=local_rank)
+            P3.set_points(cfg2["xyz"][sl]); P3.set_dt_grid(cfg2["grid"]); P3.set_loss(*loss2)
+            sums, enqueue = ead.make_device_allreduce(world, torch.device("cuda", local_rank), force_collective=multi)
+            P3.solve_sharded_device(q0, t0, enqueue, sums.data_ptr())
+            barrier_sync()
+            ts = time.perf_counter()
+            reps4, its4 = 10, 0
+            for _ in range(reps4):
+                q4, t4, s4 = P3.solve_sharded_device(q0, t0, enqueue, sums.data_ptr())
+                its4 += s4["num_iterations"]
+            barrier_sync()
+            el4 = time.perf_counter() - ts
+            extras["lm_point_sharded_device_1e5_pts"] = {"iters_per_s": its4 / el4, "solve_ms": el4 / reps4 * 1e3,
+                                                         "points_per_gpu": int(sl.stop - sl.start),
+                                                         "pose_err_vs_planted": {"rad": synth.rotation_angle_between(q4, cfg2["q_true"]),
+                                                                                 "m": float(np.linalg.norm(t4 - cfg2["t_true"]))}}
+            P3.close()
+        except Exception as e:
+            extras["lm_point_sharded_device_1e5_pts"] = {"error": repr(e)}
+
     out = None
     if rank == 0:
-        out = {"metric": "edge-point residual+Jacobian evals/sec", "value": value, "unit": "evals/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": tag, "data": "synthetic",
-               "config": {"workload": desc, "points_per_gpu": int(n_pts), "dt_image": "%dx%d" % (W, H),
-                          "parallelism": "independent frame pairs, one per GPU; single RCCL pose all-gather",
-                          "tiles": B.info("num_tiles"), "points_per_thread": B.info("points_per_thread"),
-                          "lds_bytes": B.info("lds_bytes"), "point_order_tile_px": P.point_order,
-                          "timed_region": graph or "eager launches"},
-               "roofline": roofline}
-        out.update(extras)
-        if others:
-            out["other_workloads"] = others
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, loss)
+            leg[0] = "cpu baseline"
+            extras["cpu_baseline"] = cpu_baseline(cfg, loss)
             try:
-                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cfg, loss)
+                extras["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cfg, loss)
             except Exception as e:  # a reported extra, never a reason to lose the line
-                out["cpu_baseline_all_cores"] = {"error": repr(e)}
-        else:
-            out["cpu_baseline"] = None
+                extras["cpu_baseline_all_cores"] = {"error": repr(e)}
+        out = compose()
+    leg[0] = "teardown"
     B.close()
     P.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    watchdog.cancel()
     if rank == 0:
         print(json.dumps(out))
 

@@ -15,11 +15,11 @@ def shard_slice(n_points, rank, world_size):
     return slice((rank * n_points) // world_size, ((rank + 1) * n_points) // world_size)
 
 
-def make_allreduce(world_size, device="cpu"):
+def make_allreduce(world_size, device="cpu", force_collective=False):
     """In-place sum of a small float64 numpy array over all ranks: the per-iteration exchange of a point-sharded solve
     (32 accumulator slots = 256 bytes).  RCCL when the process group's backend is "nccl" (device = this rank's GPU),
     gloo on the CPU.  world_size 1: identity, no process group needed."""
-    if world_size == 1:
+    if world_size == 1 and not force_collective:
         return lambda a: None
     import torch
     import torch.distributed as dist
@@ -33,7 +33,7 @@ def make_allreduce(world_size, device="cpu"):
     return allreduce
 
 
-def make_device_allreduce(world_size, device):
+def make_device_allreduce(world_size, device, force_collective=False):
     """The on-stream exchange of Problem.solve_sharded_device: returns (sums, enqueue) where `sums` is a torch tensor of
     32 doubles on `device` (the buffer the library folds into and the step kernel reads) and `enqueue(stream_ptr)`
     enqueues the in-place all-reduce of it on the library's HIP stream -- torch.distributed under an ExternalStream:
@@ -44,7 +44,7 @@ def make_device_allreduce(world_size, device):
     import torch
     import torch.distributed as dist
     sums = torch.zeros(32, dtype=torch.float64, device=device)
-    if world_size == 1:
+    if world_size == 1 and not force_collective:   # (force_collective: rehearse the RCCL call on a one-rank group)
         return sums, (lambda stream_ptr: None)
     backend = dist.get_backend()
     streams = {}
@@ -107,9 +107,10 @@ class PoseGather:
     allocated ONCE; gather() is one host-to-device copy of m x 8 doubles, ONE all_gather_into_tensor (RCCL over xGMI
     when the backend is "nccl") and one copy back.  Blocks of `m` problems per rank, global order = rank-major."""
 
-    def __init__(self, m, world_size, device="cpu"):
+    def __init__(self, m, world_size, device="cpu", force_collective=False):
         import torch
         self.m, self.world, self.device = int(m), int(world_size), device
+        self.collective = self.world > 1 or force_collective
         self.host = torch.zeros((self.m, 8), dtype=torch.float64)
         if str(device) != "cpu":
             self.host = self.host.pin_memory()
@@ -125,7 +126,7 @@ class PoseGather:
         h[:, 4:7] = np.asarray(t_local, dtype=np.float64).reshape(self.m, 3)
         h[:, 7] = np.asarray(status_local, dtype=np.float64).reshape(self.m)
         self.send.copy_(self.host, non_blocking=True)
-        if self.world > 1:
+        if self.collective:
             dist.all_gather_into_tensor(self.recv, self.send)
         else:
             self.recv.copy_(self.send)
@@ -133,7 +134,7 @@ class PoseGather:
         return out[:, 0:4].copy(), out[:, 4:7].copy(), out[:, 7].copy()
 
 
-def run_c4(rank, world_size, build_and_solve, per_gpu=32, device="cpu", total=None, repeats=1):
+def run_c4(rank, world_size, build_and_solve, per_gpu=32, device="cpu", total=None, repeats=1, force_collective=False):
     """BASELINE config C4 as a run shape: every rank takes its block of `per_gpu` frame-pair problems
     (synth.config_c4_specs), solves them with ONE batched solve (`build_and_solve(specs) -> (solve_fn, info)`,
     solve_fn() -> (q, t, summaries) -- ea_batch_solve on the GPU, a CPU stand-in in the gloo test), then ONE
@@ -145,7 +146,7 @@ def run_c4(rank, world_size, build_and_solve, per_gpu=32, device="cpu", total=No
     mine = shard_block(total, rank, world_size)
     assert len(mine) == per_gpu, "C4 shards evenly: %d problems over %d ranks" % (total, world_size)
     solve_fn, info = build_and_solve([specs_all[i] for i in mine])
-    pg = PoseGather(per_gpu, world_size, device=device)
+    pg = PoseGather(per_gpu, world_size, device=device, force_collective=force_collective)
     q, t, ss = solve_fn()  # warm-up (descriptor upload, first-touch)
     pg.gather(q, t, [s["termination"] for s in ss])
     t0 = time.perf_counter()

@@ -147,3 +147,44 @@ def test_sharded_device_two_ranks(hip, tmp_path):
     assert r0["it"] == s["num_iterations"]
     assert np.abs(r0["q"] - q).max() < 1e-10 and np.abs(r0["t"] - t).max() < 1e-10
     assert r0["cost"] == pytest.approx(s["final_cost"], rel=1e-10)
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    torch.cuda.init()
+    torch.cuda.set_device(0)
+    from edge_alignment_amd import capi, dist as ead
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world,
+                            device_id=torch.device("cuda", 0))
+    cfg = _problem()
+    P = capi.Problem(*cfg["K"], dtype=capi.EA_F64, device=0)
+    P.set_points(cfg["xyz"]); P.set_dt_grid(cfg["grid"]); P.set_loss(capi.LOSS_CAUCHY, 1.0)
+    q, t, s = P.solve(Q0, T0)
+    sums, enqueue = ead.make_device_allreduce(world, torch.device("cuda", 0), force_collective=True)
+    n = [0]
+    def enq(stream):
+        n[0] += 1; enqueue(stream)
+    q2, t2, s2 = P.solve_sharded_device(Q0, T0, enq, sums.data_ptr(), solve_timeout_ms=20000.0)
+    g = ead.PoseGather(3, world, device=torch.device("cuda", 0), force_collective=True)
+    qs = np.stack([q2, q, q2]); ts = np.stack([t2, t, t2])
+    gq, gt, gs = g.gather(qs, ts, [0, 1, 2])
+    dist.barrier()
+    np.savez(os.path.join(out_dir, "rccl.npz"), q=q, t=t, q2=q2, t2=t2, it=s["num_iterations"], it2=s2["num_iterations"], calls=n[0],
+             gq=gq, gt=gt, gs=gs, qs=qs, ts=ts, backend=dist.get_backend())
+    P.close()
+    dist.destroy_process_group()
+
+
+def test_rccl_calls_on_a_one_rank_group(hip, tmp_path):
+    """The collectives of both multi-GPU modes through RCCL itself (backend "nccl"), as far as a one-GPU box allows: a
+    one-rank group, the all-reduce enqueued on the library's stream under torch's ExternalStream inside
+    ea_solve_sharded_device, and the pose all_gather_into_tensor from the preallocated device tensors.  (Two ranks cannot
+    share one device under RCCL; the two-rank protocol is the gloo test above.)"""
+    import torch.multiprocessing as mp
+    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = np.load(tmp_path / "rccl.npz")
+    assert str(r["backend"]) == "nccl"
+    assert r["it2"] == r["it"] and r["calls"] >= r["it"] + 1
+    assert np.abs(r["q2"] - r["q"]).max() < 1e-10 and np.abs(r["t2"] - r["t"]).max() < 1e-10
+    assert np.array_equal(r["gq"], r["qs"]) and np.array_equal(r["gt"], r["ts"]) and list(r["gs"]) == [0, 1, 2]
