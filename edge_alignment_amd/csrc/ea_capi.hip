@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cfloat>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -246,11 +248,35 @@ extern "C" void ea_default_options(ea_options *o) {
   o->solve_timeout_ms = 0.0;
 }
 
+// ceres::Solver::Options::IsValid for the fields carried here (solver.cc: OPTION_GE / OPTION_GT / OPTION_LE_OPTION);
+// written so that a NaN fails every test.  Ceres ends such a Solve with FAILURE before touching the problem; the C-ABI
+// returns EA_ERR_INVALID_ARG and leaves q, t and the summary alone.
+static int check_options(const ea_options &o) {
+  if (!(o.max_num_iterations >= 0)) return fail(EA_ERR_INVALID_ARG, "max_num_iterations < 0");
+  if (o.strategy != EA_STRATEGY_LM && o.strategy != EA_STRATEGY_DOGLEG)
+    return fail(EA_ERR_INVALID_ARG, "unknown trust-region strategy");
+  if (!(o.function_tolerance >= 0.0) || !(o.gradient_tolerance >= 0.0) || !(o.parameter_tolerance >= 0.0))
+    return fail(EA_ERR_INVALID_ARG, "tolerances must be >= 0");
+  if (!(o.min_trust_region_radius > 0.0) || !(o.initial_trust_region_radius > 0.0) || !(o.max_trust_region_radius > 0.0) ||
+      !(o.min_trust_region_radius <= o.initial_trust_region_radius) || !(o.initial_trust_region_radius <= o.max_trust_region_radius))
+    return fail(EA_ERR_INVALID_ARG, "need 0 < min_trust_region_radius <= initial_trust_region_radius <= max_trust_region_radius");
+  if (!(o.min_relative_decrease >= 0.0)) return fail(EA_ERR_INVALID_ARG, "min_relative_decrease < 0");
+  if (!(o.min_lm_diagonal >= 0.0) || !(o.min_lm_diagonal <= o.max_lm_diagonal))
+    return fail(EA_ERR_INVALID_ARG, "need 0 <= min_lm_diagonal <= max_lm_diagonal");
+  if (!(o.max_num_consecutive_invalid_steps >= 0)) return fail(EA_ERR_INVALID_ARG, "max_num_consecutive_invalid_steps < 0");
+  if (o.iterations_per_sync < 0) return fail(EA_ERR_INVALID_ARG, "iterations_per_sync < 0");
+  if (o.solve_timeout_ms != o.solve_timeout_ms) return fail(EA_ERR_INVALID_ARG, "solve_timeout_ms is NaN");
+  return EA_OK;
+}
+
 // ---- problem ------------------------------------------------------------------------------------
 
 extern "C" int ea_problem_create(ea_problem **out, const ea_camera *cam, int dtype, int device) {
   if (!out || !cam) return fail(EA_ERR_INVALID_ARG, "NULL argument");
   if (dtype != EA_F64 && dtype != EA_F32) return fail(EA_ERR_INVALID_ARG, "dtype must be EA_F64 or EA_F32");
+  if (!(std::fabs(cam->fx) <= DBL_MAX) || !(std::fabs(cam->fy) <= DBL_MAX) || !(std::fabs(cam->cx) <= DBL_MAX) ||
+      !(std::fabs(cam->cy) <= DBL_MAX) || cam->fx == 0.0 || cam->fy == 0.0)
+    return fail(EA_ERR_INVALID_ARG, "camera intrinsics must be finite, focal lengths non-zero");
   int rc = check_device(device);
   if (rc != EA_OK) return rc;
   ea_problem *p = new (std::nothrow) ea_problem();
@@ -341,6 +367,9 @@ extern "C" int64_t ea_problem_num_points(const ea_problem *p) { return p ? p->n 
 
 extern "C" int ea_problem_set_distortion(ea_problem *p, double k1, double k2, double p1, double p2, double k3) {
   if (!p) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  if (!(std::fabs(k1) <= DBL_MAX) || !(std::fabs(k2) <= DBL_MAX) || !(std::fabs(p1) <= DBL_MAX) || !(std::fabs(p2) <= DBL_MAX) ||
+      !(std::fabs(k3) <= DBL_MAX))
+    return fail(EA_ERR_INVALID_ARG, "distortion coefficients must be finite");
   p->dist[0] = k1; p->dist[1] = k2; p->dist[2] = p1; p->dist[3] = p2; p->dist[4] = k3;
   const bool on = k1 != 0.0 || k2 != 0.0 || p1 != 0.0 || p2 != 0.0 || k3 != 0.0;
   p->variant = on ? (p->variant | 1) : (p->variant & ~1);
@@ -360,6 +389,8 @@ extern "C" int ea_problem_set_second_camera(ea_problem *p, const double trans_1t
     const double *m = k ? trans_1to2_inv : trans_1to2;
     if (m[12] != 0.0 || m[13] != 0.0 || m[14] != 0.0 || m[15] != 1.0)
       return fail(EA_ERR_INVALID_ARG, "rig transforms must be affine (last row 0 0 0 1)");
+    for (int i = 0; i < 12; ++i)
+      if (!(std::fabs(m[i]) <= DBL_MAX)) return fail(EA_ERR_INVALID_ARG, "rig transforms must be finite");
   }
   for (int i = 0; i < 16; ++i) { p->T12[i] = trans_1to2[i]; p->T12inv[i] = trans_1to2_inv[i]; }
   p->variant |= 2;
@@ -371,6 +402,7 @@ extern "C" int ea_problem_add_term(ea_problem *p, ea_problem *term) {
   if (!p || !term || p == term) return fail(EA_ERR_INVALID_ARG, "bad argument");
   if (!term->terms.empty()) return fail(EA_ERR_INVALID_ARG, "a term cannot have terms of its own");
   if (p->device != term->device || p->dtype != term->dtype) return fail(EA_ERR_INVALID_ARG, "terms must share device and dtype");
+  if (std::find(p->terms.begin(), p->terms.end(), term) != p->terms.end()) return fail(EA_ERR_INVALID_ARG, "term already added");
   p->terms.push_back(term);
   p->version++;
   return EA_OK;
@@ -506,7 +538,8 @@ extern "C" int ea_problem_set_loss(ea_problem *p, int kind, double a) {
 
 extern "C" int ea_problem_set_flavour(ea_problem *p, double z_guard, double z_eps, int rot_transposed) {
   if (!p) return fail(EA_ERR_INVALID_ARG, "NULL argument");
-  if (z_guard < 0.0) return fail(EA_ERR_INVALID_ARG, "z_guard must be >= 0");
+  if (!(z_guard >= 0.0) || !(z_guard <= DBL_MAX) || !(std::fabs(z_eps) <= DBL_MAX))
+    return fail(EA_ERR_INVALID_ARG, "z_guard must be >= 0, z_guard and z_eps finite");
   p->z_guard = z_guard; p->z_eps = z_eps; p->rot_transposed = rot_transposed ? 1 : 0;
   p->version++;
   return EA_OK;
@@ -1004,9 +1037,7 @@ extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, 
   const auto t0 = std::chrono::steady_clock::now();
   ea_options o;
   if (opt_in) o = *opt_in; else ea_default_options(&o);
-  if (o.max_num_iterations < 0) return fail(EA_ERR_INVALID_ARG, "max_num_iterations < 0");
-  if (o.strategy != EA_STRATEGY_LM && o.strategy != EA_STRATEGY_DOGLEG)
-    return fail(EA_ERR_INVALID_ARG, "unknown trust-region strategy");
+  if (int vrc = check_options(o)) return vrc;
   LMOptions lo;
   lo.max_num_iterations = o.max_num_iterations;
   lo.function_tolerance = o.function_tolerance;
@@ -1411,9 +1442,7 @@ extern "C" int ea_solve_sharded(ea_problem *p, const ea_options *opt_in, ea_allr
   const auto t0 = std::chrono::steady_clock::now();
   ea_options o;
   if (opt_in) o = *opt_in; else ea_default_options(&o);
-  if (o.max_num_iterations < 0) return fail(EA_ERR_INVALID_ARG, "max_num_iterations < 0");
-  if (o.strategy != EA_STRATEGY_LM && o.strategy != EA_STRATEGY_DOGLEG)
-    return fail(EA_ERR_INVALID_ARG, "unknown trust-region strategy");
+  if (int vrc = check_options(o)) return vrc;
   ea_batch *b = nullptr;
   int rc = self_batch(p, &b);
   if (rc != EA_OK) return rc;
@@ -1484,9 +1513,7 @@ extern "C" int ea_solve_sharded_device(ea_problem *p, const ea_options *opt_in, 
   const auto t0 = std::chrono::steady_clock::now();
   ea_options o;
   if (opt_in) o = *opt_in; else ea_default_options(&o);
-  if (o.max_num_iterations < 0) return fail(EA_ERR_INVALID_ARG, "max_num_iterations < 0");
-  if (o.strategy != EA_STRATEGY_LM && o.strategy != EA_STRATEGY_DOGLEG)
-    return fail(EA_ERR_INVALID_ARG, "unknown trust-region strategy");
+  if (int vrc = check_options(o)) return vrc;
   ea_batch *b = nullptr;
   int rc = self_batch(p, &b);
   if (rc != EA_OK) return rc;
@@ -1860,6 +1887,16 @@ static int run_dt(ea_problem *p, WsCarver &ws, const uint8_t *d_bgr, int height,
   return dt_from_mask(p, ws, d_mask, height, width, normalize, 0.0, 1.0, dist_out, plain_out);
 }
 
+// cv::Canny's integer thresholds (L1 magnitude): floor of the ordered pair.  NaN is refused; values beyond any magnitude an
+// 8-bit image can produce (|dx| + |dy| <= 2040) are clamped before the conversion, which is undefined for them otherwise.
+static int canny_thresholds(double t1, double t2, int *low, int *high) {
+  if (t1 != t1 || t2 != t2) return fail(EA_ERR_INVALID_ARG, "Canny threshold is NaN");
+  const double lo = std::min(t1, t2), hi = std::max(t1, t2);
+  *low = (int)std::floor(std::min(std::max(lo, -1e9), 1e9));
+  *high = (int)std::floor(std::min(std::max(hi, -1e9), 1e9));
+  return EA_OK;
+}
+
 // blur 3x3 -> gray -> Canny(low, high) [-> AND (keep > 1)]: edge map and its inverse in the workspace
 static int run_canny(WsCarver &ws, const uint8_t *d_bgr, const uint8_t *d_keep, int height, int width, int low, int high,
                      uint8_t **edges_out, uint8_t **inv_out, int *rounds_out, int l2_bgr = 0) {
@@ -1889,7 +1926,10 @@ extern "C" int ea_problem_set_ref_frame_canny(ea_problem *p, const uint8_t *bgr,
   int rc = check_frame_args(p, bgr, height, width);
   if (rc != EA_OK) return rc;
   if (!depth) return fail(EA_ERR_INVALID_ARG, "NULL argument");
-  if (!(z_scaling > 0.0)) return fail(EA_ERR_INVALID_ARG, "z_scaling must be > 0");
+  if (!(z_scaling > 0.0) || !(z_scaling <= DBL_MAX)) return fail(EA_ERR_INVALID_ARG, "z_scaling must be > 0 and finite");
+  int lo, hi;
+  rc = canny_thresholds(low_threshold, high_threshold, &lo, &hi);
+  if (rc != EA_OK) return rc;
   HIPCHK(hipSetDevice(p->device));
   rc = ensure_ws(p, frame_ws_bytes(height, width));
   if (rc != EA_OK) return rc;
@@ -1902,7 +1942,6 @@ extern "C" int ea_problem_set_ref_frame_canny(ea_problem *p, const uint8_t *bgr,
   int *d_total = d_counts + nblocks;
   HIPCHK(hipMemcpyAsync(d_bgr, bgr, np * 3, hipMemcpyHostToDevice, nullptr));
   HIPCHK(hipMemcpyAsync(d_depth, depth, np * 2, hipMemcpyHostToDevice, nullptr));
-  const int lo = (int)std::floor(std::min(low_threshold, high_threshold)), hi = (int)std::floor(std::max(low_threshold, high_threshold));
   uint8_t *d_edges, *d_inv;
   rc = run_canny(ws, d_bgr, nullptr, height, width, lo, hi, &d_edges, &d_inv, nullptr);
   if (rc != EA_OK) return rc;
@@ -1930,6 +1969,11 @@ static int now_frame_canny(ea_problem *p, const uint8_t *bgr, const uint8_t *mas
                            int32_t *chamfer_fix_out, float *dt_out, int *rounds_out) {
   int rc = check_frame_args(p, bgr, height, width);
   if (rc != EA_OK) return rc;
+  int lo, hi;
+  rc = canny_thresholds(low_threshold, high_threshold, &lo, &hi);
+  if (rc != EA_OK) return rc;
+  if (normalize && (!(std::fabs(norm_lo) <= DBL_MAX) || !(std::fabs(norm_hi) <= DBL_MAX)))
+    return fail(EA_ERR_INVALID_ARG, "normalisation range must be finite");
   HIPCHK(hipSetDevice(p->device));
   rc = ensure_ws(p, frame_ws_bytes(height, width));
   if (rc != EA_OK) return rc;
@@ -1939,7 +1983,6 @@ static int now_frame_canny(ea_problem *p, const uint8_t *bgr, const uint8_t *mas
   uint8_t *d_keep = mask ? ws.take<uint8_t>(np) : nullptr;
   HIPCHK(hipMemcpyAsync(d_bgr, bgr, np * 3, hipMemcpyHostToDevice, nullptr));
   if (mask) HIPCHK(hipMemcpyAsync(d_keep, mask, np, hipMemcpyHostToDevice, nullptr));
-  const int lo = (int)std::floor(std::min(low_threshold, high_threshold)), hi = (int)std::floor(std::max(low_threshold, high_threshold));
   uint8_t *d_edges, *d_inv;
   rc = run_canny(ws, d_bgr, d_keep, height, width, lo, hi, &d_edges, &d_inv, rounds_out);
   if (rc != EA_OK) return rc;
@@ -1955,14 +1998,16 @@ static int now_frame_canny(ea_problem *p, const uint8_t *bgr, const uint8_t *mas
 }
 
 // ---- ROS flavour of the producers (ref: src/SolveEA.cpp:29-119): Canny(rgb, 150, 100, 3, true) on the 3-channel image
-static void ros_thresholds(double t1, double t2, int *low, int *high) {
+static int ros_thresholds(double t1, double t2, int *low, int *high) {
   // cv::Canny with L2gradient: min(t, 32767)^2, ordered
-  double lo = std::min(t1, t2), hi = std::max(t1, t2);
+  if (t1 != t1 || t2 != t2) return fail(EA_ERR_INVALID_ARG, "Canny threshold is NaN");
+  double lo = std::max(std::min(t1, t2), -1e4), hi = std::max(std::max(t1, t2), -1e4);
   lo = std::min(32767.0, lo); hi = std::min(32767.0, hi);
   if (lo > 0) lo *= lo;
   if (hi > 0) hi *= hi;
   *low = (int)std::floor(lo);
   *high = (int)std::floor(hi);
+  return EA_OK;
 }
 
 // Frames as the ROS callbacks receive them -> the resolution the node works at, on the device: `halvings` times
@@ -2018,6 +2063,9 @@ extern "C" int ea_problem_set_ref_frame_ros_scaled(ea_problem *p, const uint8_t 
   if (!depth) return fail(EA_ERR_INVALID_ARG, "NULL argument");
   rc = check_scaled_args(full_height, full_width, halvings);
   if (rc != EA_OK) return rc;
+  int lo, hi;
+  rc = ros_thresholds(threshold1, threshold2, &lo, &hi);
+  if (rc != EA_OK) return rc;
   const int height = full_height >> halvings, width = full_width >> halvings;
   if (height < 3 || width < 3) return fail(EA_ERR_INVALID_ARG, "image extent out of range");
   HIPCHK(hipSetDevice(p->device));
@@ -2032,8 +2080,6 @@ extern "C" int ea_problem_set_ref_frame_ros_scaled(ea_problem *p, const uint8_t 
   int *d_total = d_counts + nblocks;
   rc = stage_scaled(p, bgr, depth, full_height, full_width, halvings, d_bgr, d_depth);
   if (rc != EA_OK) return rc;
-  int lo, hi;
-  ros_thresholds(threshold1, threshold2, &lo, &hi);
   uint8_t *d_edges, *d_inv;
   rc = run_canny(ws, d_bgr, nullptr, height, width, lo, hi, &d_edges, &d_inv, nullptr, /*l2_bgr=*/1);
   if (rc != EA_OK) return rc;
@@ -2065,6 +2111,9 @@ static int now_frame_ros_impl(ea_problem *p, const uint8_t *bgr, int full_height
   if (rc != EA_OK) return rc;
   rc = check_scaled_args(full_height, full_width, halvings);
   if (rc != EA_OK) return rc;
+  int lo, hi;
+  rc = ros_thresholds(threshold1, threshold2, &lo, &hi);
+  if (rc != EA_OK) return rc;
   const int height = full_height >> halvings, width = full_width >> halvings;
   if (height < 3 || width < 3) return fail(EA_ERR_INVALID_ARG, "image extent out of range");
   HIPCHK(hipSetDevice(p->device));
@@ -2077,8 +2126,6 @@ static int now_frame_ros_impl(ea_problem *p, const uint8_t *bgr, int full_height
   int *d_counts = ws.take<int>(nblocks + 1);
   rc = stage_scaled(p, bgr, nullptr, full_height, full_width, halvings, d_bgr, nullptr);
   if (rc != EA_OK) return rc;
-  int lo, hi;
-  ros_thresholds(threshold1, threshold2, &lo, &hi);
   uint8_t *d_edges, *d_inv;
   rc = run_canny(ws, d_bgr, nullptr, height, width, lo, hi, &d_edges, &d_inv, nullptr, /*l2_bgr=*/1);
   if (rc != EA_OK) return rc;

@@ -484,7 +484,9 @@ EA_HD inline void lm_begin(LMState *s, LMCold *c, LMTrace *tr, const LMOptions *
   pend->store_system = 0;
   pend->trace_it = -1;
   s->num_evals += 1;
-  if (EA_UNLIKELY(acc[kAccInvalid] > 0.0)) { lm_finish(s, 2, 6); return; }
+  // a functor returning false, or a non-finite residual (ceres: ResidualBlock::Evaluate's IsArrayValid check), fails the
+  // evaluation: at the start point the solve ends with FAILURE and the parameters untouched
+  if (EA_UNLIKELY(acc[kAccInvalid] > 0.0 || !(fabs(acc[kAccCost]) <= DBL_MAX))) { lm_finish(s, 2, 6); return; }
   lm_take_system(s, pend, acc);
   if (o->jacobi_scaling)
     for (int i = 0; i < 6; ++i) s->S[i] = 1.0 / (1.0 + sqrt(acc[kAccJtJ + sym6(i, i)]));
@@ -499,7 +501,7 @@ EA_HD inline void lm_advance(LMState *s, LMCold *c, LMTrace *tr, const LMOptions
   pend->store_system = 0;
   pend->trace_it = -1;
   s->num_evals += 1;
-  const bool eval_ok = !(acc[kAccInvalid] > 0.0);
+  const bool eval_ok = !(acc[kAccInvalid] > 0.0) && (fabs(acc[kAccCost]) <= DBL_MAX);  // (non-finite: see lm_begin)
   const double cand_cost = eval_ok ? acc[kAccCost] : DBL_MAX;
   double dx[7];
 #pragma unroll

@@ -827,7 +827,7 @@ int ea_oracle_solve_terms(const ea_oracle_term *terms, int nterms, const ea_orac
                                   Jtr, rc, Jc);                                                 \
     sum->num_residual_evals += n;                                                               \
     sum->num_jacobian_evals += n;                                                               \
-    eval_ok = (bad == 0);                                                                       \
+    eval_ok = (bad == 0) && (fabs(x_cost) <= DBL_MAX); /* IsArrayValid: non-finite residuals fail */ \
   } while (0)
 
   int eval_ok;
@@ -918,7 +918,8 @@ int ea_oracle_solve_terms(const ea_oracle_term *terms, int nterms, const ea_orac
     {
       int64_t bad = cost_terms(terms, nterms, cand, cand + 4, &cand_cost);
       sum->num_residual_evals += n;
-      if (bad) cand_cost = DBL_MAX; /* "Step failed to evaluate. Treating it as a step with infinite cost" */
+      /* "Step failed to evaluate. Treating it as a step with infinite cost" (functor false, or non-finite residuals) */
+      if (bad || !(fabs(cand_cost) <= DBL_MAX)) cand_cost = DBL_MAX;
     }
     /* ParameterToleranceReached */
     double dx[7];
