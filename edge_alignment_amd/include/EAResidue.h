@@ -66,6 +66,48 @@ class EAResidue {
 
 // ---- variants of standalone/utils.h:102-421: carriers with the reference's constructors and Create() -----
 
+namespace ea_shim {
+// Host-side evaluation shared by the three variant functors' templated call operators (T = double or ceres::Jet):
+//   a' = T12inv a;  b' = R(q) a' + t;  b = T12 b'   (i.e. b = (T12 * b_T_a * T12inv) a, utils.h:244-259; rig == NULL: b = b')
+//   |b_z| < 0.01 -> false (:262-265);  x = b_x / b_z, y = b_y / b_z;  Brown-Conrady (k1, k2, p1, p2, k3) when dist != NULL
+//   (:137-143);  u = fx x_d + cx, v = fy y_d + cy;  residue = interpolator(u, v).
+// The solver never calls this: ceres::Solve evaluates every block in the gfx950 kernels (project_point_var).
+template <typename T, typename Interp>
+bool variant_residue(const T *const quat, const T *const t, T *residue, const Interp &interp, double fx, double fy, double cx,
+                     double cy, double X, double Y, double Z, const double *dist, const double *T12, const double *T12inv) {
+  double a[3] = {X, Y, Z};
+  if (T12inv) {
+    for (int i = 0; i < 3; ++i) a[i] = T12inv[4 * i] * X + T12inv[4 * i + 1] * Y + T12inv[4 * i + 2] * Z + T12inv[4 * i + 3];
+  }
+  const T w = quat[0], qx = quat[1], qy = quat[2], qz = quat[3];
+  const T one(1.0), two(2.0);
+  const T R[9] = {one - two * (qy * qy + qz * qz), two * (qx * qy - w * qz), two * (qx * qz + w * qy),
+                  two * (qx * qy + w * qz), one - two * (qx * qx + qz * qz), two * (qy * qz - w * qx),
+                  two * (qx * qz - w * qy), two * (qy * qz + w * qx), one - two * (qx * qx + qy * qy)};
+  T b[3];
+  for (int i = 0; i < 3; ++i) b[i] = R[3 * i] * T(a[0]) + R[3 * i + 1] * T(a[1]) + R[3 * i + 2] * T(a[2]) + t[i];
+  if (T12) {
+    T c[3];
+    for (int i = 0; i < 3; ++i) c[i] = T(T12[4 * i]) * b[0] + T(T12[4 * i + 1]) * b[1] + T(T12[4 * i + 2]) * b[2] + T(T12[4 * i + 3]);
+    for (int i = 0; i < 3; ++i) b[i] = c[i];
+  }
+  if (b[2] < T(0.01) && b[2] > T(-0.01)) return false;
+  const T x = b[0] / b[2], y = b[1] / b[2];
+  T xd = x, yd = y;
+  if (dist) {
+    const double k1 = dist[0], k2 = dist[1], p1 = dist[2], p2 = dist[3], k3 = dist[4];
+    const T r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+    const T radial = T(1.0) + T(k1) * r2 + T(k2) * r4 + T(k3) * r6;
+    xd = x * radial + T(2.0 * p1) * x * y + T(p2) * (r2 + T(2.0) * x * x);
+    yd = y * radial + T(2.0 * p2) * x * y + T(p1) * (r2 + T(2.0) * y * y);
+  }
+  const T u = T(fx) * xd + T(cx);
+  const T v = T(fy) * yd + T(cy);
+  interp.Evaluate(u, v, &residue[0]);
+  return true;
+}
+}  // namespace ea_shim
+
 // distortion (utils.h:102-177)
 class EAResidueEx {
  public:
@@ -75,6 +117,12 @@ class EAResidueEx {
               const double a_Xz, const Interpolator &__interpolated_a)
       : interp_a(__interpolated_a), fx(fx), fy(fy), cx(cx), cy(cy), k1(k1), k2(k2), p1(p1), p2(p2), k3(k3),
         a_Xx(a_Xx), a_Xy(a_Xy), a_Xz(a_Xz) {}
+  // `template <typename T>` as upstream; host-side probe (see ea_shim::variant_residue)
+  template <typename T>
+  bool operator()(const T *const quat, const T *const t, T *residue) const {
+    const double d[5] = {k1, k2, p1, p2, k3};
+    return ea_shim::variant_residue(quat, t, residue, interp_a, fx, fy, cx, cy, a_Xx, a_Xy, a_Xz, d, nullptr, nullptr);
+  }
   static ceres::CostFunction *Create(const double fx, const double fy, const double cx, const double cy,
                                      const double k1, const double k2, const double p1, const double p2,
                                      const double k3, const double a_Xx, const double a_Xy, const double a_Xz,
@@ -108,6 +156,11 @@ class EAResidueSecondCam {
                      const Interpolator &__interpolated_a)
       : interp_a(__interpolated_a), fx(fx), fy(fy), cx(cx), cy(cy), a_Xx(a_Xx), a_Xy(a_Xy), a_Xz(a_Xz) {
     for (int i = 0; i < 16; ++i) { T12[i] = ptrans_1to2[i]; T12inv[i] = ptrans_1to2_inv[i]; }
+  }
+  // `template <typename T>` as upstream; host-side probe (see ea_shim::variant_residue)
+  template <typename T>
+  bool operator()(const T *const quat, const T *const t, T *residue) const {
+    return ea_shim::variant_residue(quat, t, residue, interp_a, fx, fy, cx, cy, a_Xx, a_Xy, a_Xz, nullptr, T12, T12inv);
   }
   static ceres::CostFunction *Create(const double fx, const double fy, const double cx, const double cy,
                                      const double a_Xx, const double a_Xy, const double a_Xz,
@@ -144,6 +197,12 @@ class EAResidueSecondCamEx {
       : interp_a(__interpolated_a), fx(fx), fy(fy), cx(cx), cy(cy), k1(k1), k2(k2), p1(p1), p2(p2), k3(k3),
         a_Xx(a_Xx), a_Xy(a_Xy), a_Xz(a_Xz) {
     for (int i = 0; i < 16; ++i) { T12[i] = ptrans_1to2[i]; T12inv[i] = ptrans_1to2_inv[i]; }
+  }
+  // `template <typename T>` as upstream; host-side probe (see ea_shim::variant_residue)
+  template <typename T>
+  bool operator()(const T *const quat, const T *const t, T *residue) const {
+    const double d[5] = {k1, k2, p1, p2, k3};
+    return ea_shim::variant_residue(quat, t, residue, interp_a, fx, fy, cx, cy, a_Xx, a_Xy, a_Xz, d, T12, T12inv);
   }
   static ceres::CostFunction *Create(const double fx, const double fy, const double cx, const double cy,
                                      const double k1, const double k2, const double p1, const double p2,

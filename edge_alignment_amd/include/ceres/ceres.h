@@ -32,7 +32,6 @@ enum MinimizerType { LINE_SEARCH, TRUST_REGION };
 enum TrustRegionStrategyType { LEVENBERG_MARQUARDT, DOGLEG };
 enum DoglegType { TRADITIONAL_DOGLEG, SUBSPACE_DOGLEG };
 enum TerminationType { CONVERGENCE, NO_CONVERGENCE, FAILURE, USER_SUCCESS, USER_FAILURE };
-enum Ownership { DO_NOT_TAKE_OWNERSHIP, TAKE_OWNERSHIP };
 
 // ---- cost functions ------------------------------------------------------------------------
 // The facade never differentiates anything: a cost function is only a carrier of the per-block
@@ -54,6 +53,12 @@ struct EABlockInfo {
 class CostFunction {
  public:
   virtual ~CostFunction() {}
+  // Ceres' interface: residuals and (nullable, per parameter block nullable) row-major Jacobians of ONE block on the host.
+  // A probe for spot checks -- ceres::Solve never calls it, every block is evaluated by the gfx950 kernels.
+  virtual bool Evaluate(double const *const *parameters, double *residuals, double **jacobians) const {
+    (void)parameters; (void)residuals; (void)jacobians;
+    return false;
+  }
   // true if this block is an edge-alignment block; fills info
   virtual bool DescribeEdgeAlignmentBlock(EABlockInfo *) const { return false; }
 };
@@ -64,6 +69,23 @@ template <typename Functor, int kNumResiduals, int N0 = 0, int N1 = 0, int N2 = 
 class AutoDiffCostFunction : public CostFunction {
  public:
   explicit AutoDiffCostFunction(Functor *functor) : functor_(functor) {}
+  // forward-mode differentiation of the functor's templated operator() with Jet<double, N0 + N1> (two parameter
+  // blocks, as every cost function of the reference has: q[4], t[3])
+  bool Evaluate(double const *const *parameters, double *residuals, double **jacobians) const override {
+    static_assert(N2 == 0, "two parameter blocks");
+    if (!jacobians) return (*functor_)(parameters[0], parameters[1], residuals);
+    typedef Jet<double, N0 + N1> J;
+    J p0[N0 > 0 ? N0 : 1], p1[N1 > 0 ? N1 : 1], r[kNumResiduals];
+    for (int i = 0; i < N0; ++i) p0[i] = J(parameters[0][i], i);
+    for (int i = 0; i < N1; ++i) p1[i] = J(parameters[1][i], N0 + i);
+    if (!(*functor_)(p0, p1, r)) return false;
+    for (int k = 0; k < kNumResiduals; ++k) {
+      residuals[k] = r[k].a;
+      if (jacobians[0]) for (int i = 0; i < N0; ++i) jacobians[0][k * N0 + i] = r[k].v[i];
+      if (jacobians[1]) for (int i = 0; i < N1; ++i) jacobians[1][k * N1 + i] = r[k].v[N0 + i];
+    }
+    return true;
+  }
   bool DescribeEdgeAlignmentBlock(EABlockInfo *info) const override {
     if (kNumResiduals != 1 || N0 != 4 || N1 != 3 || N2 != 0) return false;
     return functor_->ea_describe(info);
@@ -78,11 +100,39 @@ class AutoDiffCostFunction : public CostFunction {
 class LocalParameterization {
  public:
   virtual ~LocalParameterization() {}
+  virtual bool Plus(const double *x, const double *delta, double *x_plus_delta) const = 0;
+  virtual bool ComputeJacobian(const double *x, double *jacobian) const = 0;  // GlobalSize x LocalSize, row-major
+  virtual int GlobalSize() const = 0;
+  virtual int LocalSize() const = 0;
   virtual bool IsQuaternion() const { return false; }
 };
-// q+ = [cos|d|, sin|d|/|d| d] (x) q  — applied on the device by the LM-step kernel
+// q+ = [cos|d|, sin|d|/|d| d] (x) q  — applied on the device by the LM-step kernel; the host forms below are Ceres'
+// public definition (local_parameterization.cc), for callers that probe the parameterisation themselves
 class QuaternionParameterization : public LocalParameterization {
  public:
+  bool Plus(const double *x, const double *delta, double *x_plus_delta) const override {
+    const double n = std::sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
+    if (n > 0.0) {
+      const double s = std::sin(n) / n;
+      const double d[4] = {std::cos(n), s * delta[0], s * delta[1], s * delta[2]};
+      x_plus_delta[0] = d[0] * x[0] - d[1] * x[1] - d[2] * x[2] - d[3] * x[3];
+      x_plus_delta[1] = d[0] * x[1] + d[1] * x[0] + d[2] * x[3] - d[3] * x[2];
+      x_plus_delta[2] = d[0] * x[2] - d[1] * x[3] + d[2] * x[0] + d[3] * x[1];
+      x_plus_delta[3] = d[0] * x[3] + d[1] * x[2] - d[2] * x[1] + d[3] * x[0];
+    } else {
+      for (int i = 0; i < 4; ++i) x_plus_delta[i] = x[i];
+    }
+    return true;
+  }
+  bool ComputeJacobian(const double *x, double *J) const override {
+    J[0] = -x[1]; J[1] = -x[2]; J[2] = -x[3];
+    J[3] = x[0];  J[4] = x[3];  J[5] = -x[2];
+    J[6] = -x[3]; J[7] = x[0];  J[8] = x[1];
+    J[9] = x[2];  J[10] = -x[1]; J[11] = x[0];
+    return true;
+  }
+  int GlobalSize() const override { return 4; }
+  int LocalSize() const override { return 3; }
   bool IsQuaternion() const override { return true; }
 };
 
