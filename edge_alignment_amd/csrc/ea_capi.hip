@@ -668,8 +668,10 @@ static void fill_desc(const ea_problem *p, ProblemDesc &d) {
 
 // (re)build descriptors when any problem (or one of its terms) changed
 static int batch_build(ea_batch *b) {
+  // every entry point that launches or allocates passes through here first: the calling thread's current device is the
+  // batch's from now on (a process driving several GPUs may have switched between calls)
+  HIPCHK(hipSetDevice(b->device));
   if (b->needs_drain) {  // launches of an abandoned solve may still be queued on (or stuck in) the stream
-    HIPCHK(hipSetDevice(b->device));
     HIPCHK(hipStreamSynchronize(b->stream));
     b->needs_drain = false;
   }
@@ -685,7 +687,6 @@ static int batch_build(ea_batch *b) {
   if (!dirty) return EA_OK;
   b->built = false;  // until the last allocation and upload below has succeeded
   if (b->bench_graph) { (void)hipGraphExecDestroy(b->bench_graph); b->bench_graph = nullptr; b->bench_graph_steps = 0; }
-  HIPCHK(hipSetDevice(b->device));
   // terms of a problem follow it; all share its pose
   std::vector<const ea_problem *> terms;
   std::vector<int> term_group;
