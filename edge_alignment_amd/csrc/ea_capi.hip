@@ -711,15 +711,38 @@ static int batch_build(ea_batch *b) {
   any_variant |= b->t_variant;  // a part of a larger batch runs the kernel form the whole batch runs
   b->any_variant = any_variant;
   b->terms_are_groups = terms.size() == b->probs.size() ? 1 : 0;
-  // Launch shape, measured on MI355X (profiles/r01_sweep*.txt).  Small problems are latency-bound: one
-  // point per lane and as many waves as possible.  Large fp32 problems take 1024-thread workgroups with 2-4
-  // points per lane: the kernel time hardly moves, but the partial rows to fold drop to a few hundred.
+  // Launch shape, measured on MI355X (profiles/r01_sweep*.txt, r02_single_shape_sweep.txt, r02_batch_shape_sweep.txt): what
+  // counts is the (evaluate, fold) step and the LM iteration, i.e. the kernel AND the number of partial rows behind it.
+  // Small problems are latency-bound: one point per lane and as many waves as possible.  From ~1e5 points two points
+  // per lane cost the kernel nothing and halve the rows; larger clouds take 1024-thread workgroups (fp32: 2-4 points per
+  // lane on top): the kernel time hardly moves, the rows drop to a few hundred.
   int nt_auto = 256, ppt_auto = 1;
-  if (b->dtype == EA_F32) {
+  if (terms.size() == 1) {
+    if (b->dtype == EA_F32) {
+      if (max_n >= 800000) { nt_auto = 1024; ppt_auto = 4; }
+      else if (max_n >= 300000) { nt_auto = 1024; ppt_auto = 2; }
+      else if (max_n >= 150000) { nt_auto = 1024; ppt_auto = 1; }   // 2e5: step 6.3 us, against 6.7 at 256 x 4
+      else if (max_n >= 80000) ppt_auto = 2;                        // 1e5: step 5.7 us / solve 159 us, against 6.3 / 177
+    } else {
+      // fp64 runs ONE 1024-thread workgroup per CU (128-VGPR budget): that shape pays when its workgroups fill whole
+      // rounds of the 256 CUs (3.4e5 points = 1.33 rounds: 8.8 us against 6.0 us at 256 x 2)
+      const int64_t wg1024 = (max_n + 1023) / 1024, rounds = (wg1024 + 255) / 256;
+      if (max_n >= 150000 && (rounds == 1 || wg1024 * 4 >= rounds * 256 * 3)) nt_auto = 1024;
+      else if (max_n >= 80000) ppt_auto = 2;
+    }
+  } else if (b->dtype == EA_F32) {
     if (max_n >= 800000) { nt_auto = 1024; ppt_auto = 4; }
     else if (max_n >= 300000) { nt_auto = 1024; ppt_auto = 2; }
     else if (max_n >= 150000) { nt_auto = 256; ppt_auto = 4; }
-    else ppt_auto = 1;  // batches of small problems included: 32 x 50k runs 17.3 us at one point per lane, 18.4 at two
+    else {
+      // batches of small problems: one point per lane (latency-bound up to ~32 pairs; in raster order two points per lane
+      // cost 4-6 % at every size) -- except large batches stored tile by tile, where two points per lane halve the
+      // butterfly per point and still read neighbouring texels: 64 x 50k 23.5 -> 21.4 us, 128 x 50k 47.7 -> 41.3 us
+      // (0.63 -> 0.69 / 0.71 of the HBM roofline; profiles/r02_batch_shape_sweep.txt)
+      bool all_tiled = true;
+      for (const ea_problem *p : terms) all_tiled = all_tiled && p->order_tile_used > 0;
+      ppt_auto = (all_tiled && total >= 2400000) ? 2 : 1;
+    }
   } else {
     ppt_auto = total >= 80000 ? 2 : 1;  // same kernel time at 1e5 points, half the rows for the LM step to fold
   }
