@@ -437,7 +437,7 @@ def main():
     if not args.no_extras and rank == 0 and world == 1:
         leg[0] = "other workloads"
         from edge_alignment_amd import synth
-        def measure(problems, dtype, esz, loss, tile=None, valu_key=None):
+        def measure(problems, dtype, esz, loss, tile=None, valu_key=None, traffic_key=None):
             Ps = []
             for cfgx in problems:
                 Px = capi.Problem(*cfgx["K"], dtype=dtype, device=local_rank)
@@ -458,6 +458,15 @@ def main():
                    "point_order_tile_px": Ps[0].point_order}
             if valu_key:
                 res["valu_issue"] = valu_issue(valu_key, msk)
+            if traffic_key:   # HBM-side bytes per launch from the PMC passes (profiles/pmc_traffic.json) over the live kernel time
+                try:
+                    tb = json.load(open(pmc_path)).get(traffic_key, {}).get("hbm_bytes_per_launch")
+                    if tb:
+                        res["traffic"] = tb
+                        res["traffic_GBps"] = tb / (msk * 1e-3) / 1e9
+                        res["traffic_frac_of_measured_stream_copy_6290GBps"] = tb / (msk * 1e-3) / 1e9 / 6290.0
+                except Exception:
+                    pass
             if m > 1 and tile is None:  # the production shape of BASELINE config C4: all frame pairs of a GPU solved by one launch sequence
                 Bx.solve(Q, T)
                 tsv = time.perf_counter()
@@ -502,9 +511,10 @@ def main():
         # 64 pairs per launch: where the launch has grown out of its ramp and tail (profiles/r02_batch_size_sweep.txt);
         # 256 pairs (fp32: 468 MB): beyond the 256 MB Infinity Cache that serves repeated launches over a smaller
         # batch, i.e. the rate with every byte coming from HBM
-        others["batch64_c2_fp32_tile16"] = measure(batch * 2, capi.EA_F32, 4, (capi.LOSS_CAUCHY, 1.0), tile=16)
+        others["batch64_c2_fp32_tile16"] = measure(batch * 2, capi.EA_F32, 4, (capi.LOSS_CAUCHY, 1.0), tile=16, traffic_key="batch64_c2_fp32_tile16")
         others["batch64_c2_fp64_tile16"] = measure(batch * 2, capi.EA_F64, 8, (capi.LOSS_CAUCHY, 1.0), tile=16)
-        others["batch256_c2_fp32_tile16_beyond_infinity_cache"] = measure(batch * 8, capi.EA_F32, 4, (capi.LOSS_CAUCHY, 1.0), tile=16)
+        others["batch256_c2_fp32_tile16_beyond_infinity_cache"] = measure(batch * 8, capi.EA_F32, 4, (capi.LOSS_CAUCHY, 1.0), tile=16,
+                                                                          traffic_key="batch256_c2_fp32_tile16")
 
     # Last, because it is the one measurement whose collective pattern (RCCL calls enqueued on the library's stream from a
     # callback, four per round) has only met a one-rank group so far: the point-sharded solve with the exchange kept on

@@ -20,12 +20,14 @@ if which in ('all', 'lm'):
     run(synth.config_c2_twin(seed=7, n_points=100000), capi.EA_F64, (capi.LOSS_CAUCHY, 1.0), 50)
 if which in ('all', 'c5'):
     run(synth.config_c5(), capi.EA_F32, (capi.LOSS_TRIVIAL, 1.0), 50)
-if which in ('batch32f32', 'batch32f64'):
+if which in ('batch32f32', 'batch32f64', 'batchf32', 'batchf64'):   # batchf32 / batchf64: pairs=N (default 32)
     dtype = capi.EA_F32 if which.endswith('f32') else capi.EA_F64
     Ps = []
     tile = [int(kv.split('=')[1]) for kv in sys.argv[2:] if kv.startswith('tile=')]
-    for i in range(32):
-        cfg = synth.config_c2_twin(seed=100 + i)
+    pairs = ([int(kv.split('=')[1]) for kv in sys.argv[2:] if kv.startswith('pairs=')] or [32])[0]
+    cfgs = [synth.config_c2_twin(seed=100 + i) for i in range(min(pairs, 32))]
+    for i in range(pairs):
+        cfg = cfgs[i % 32]
         P = capi.Problem(*cfg['K'], dtype=dtype)
         if tile:
             P.set_point_order(tile[0])   # storage order of the points: tiles of this many pixels
@@ -33,8 +35,8 @@ if which in ('batch32f32', 'batch32f64'):
         Ps.append(P)
     B = capi.Batch(Ps)
     for kv in sys.argv[2:]:
-        if kv.startswith('tile='):
+        if kv.startswith('tile=') or kv.startswith('pairs='):
             continue
         k, v = kv.split('='); B.set_tuning(k, int(v))
-    ms, _ = B.bench_eval(np.tile(q0, (32, 1)), np.tile(t0, (32, 1)), 5, 30, kernel_pass=False)
+    ms, _ = B.bench_eval(np.tile(q0, (pairs, 1)), np.tile(t0, (pairs, 1)), 5, 30, kernel_pass=False)
     print('ms/step', ms / 30, 'tiles', B.info('num_tiles'), 'ppt', B.info('points_per_thread'), 'threads', B.info('threads'))
