@@ -641,6 +641,7 @@ __device__ __forceinline__ void wave_reduce32_f64(double (&v)[32], int lane) {
   v[0] += lane_xchg<kDppQuadXor1>(v[0]);
 }
 
+#ifndef EA_TU_VARIANT
 // self-test of the cross-lane primitives: one wave, lane L loads in[s*64+L] for slot s; dumps the
 // stages of wave_reduce32_f32 (a: 16x64, b: 8x64, c: 4x64, d: 2x64) and the fp64 butterfly result
 __global__ void ea_selftest_reduce_kernel(const float *in, float *stage_a, float *stage_b, float *stage_c,
@@ -674,6 +675,7 @@ __global__ void ea_selftest_reduce_kernel(const float *in, float *stage_a, float
   wave_reduce32_f64(w, lane);
   if ((lane & 1) == 0) out_f64[swap_slot_f64(lane)] = w[0];
 }
+#endif  // !EA_TU_VARIANT
 
 template <typename T> using GPtr = const T __attribute__((address_space(1))) *;
 
@@ -1023,6 +1025,7 @@ __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
   EA_STAMP(7);  // row stored
 }
 
+#ifndef EA_TU_VARIANT
 // ------------------------------------------------------------------------------------------------
 // per-point outputs (parity / "EAResidue batch Evaluate" view): r[n], J[n*6]
 
@@ -1371,22 +1374,16 @@ __global__ void ea_pad_image_kernel(const T *__restrict__ src, int H, int W, T *
   const int sv = min(max(v - kImagePad, 0), H - 1);
   dst[(size_t)v * pitch + u] = src[(size_t)sv * W + su];
 }
+#endif  // !EA_TU_VARIANT
 
 // ------------------------------------------------------------------------------------------------
 // launchers (called from ea_capi.cpp)
 
-hipError_t launch_eval_fused(int dtype, int ppt, int nt, int variant, const ProblemDesc *probs, int nterms, int chunk,
-                             int max_chunks, int xcd_remap, const PoseState *poses, double *partials,
-                             int lds_bytes, int terms_are_groups, int buffer_loads, const void *x0, const void *y0,
-                             const void *z0, int n0, hipStream_t stream) {
-  if (nterms <= 0 || max_chunks <= 0) return hipSuccess;
-  const int chunks_per_xcd = (max_chunks + 7) / 8;
-  const dim3 grid(xcd_remap ? chunks_per_xcd * 8 : max_chunks, nterms);
-  if (chunk <= 0 || chunk > 0xffff) return hipErrorInvalidValue;  // (NT * PPT <= 4096)
-  const int shape = chunk | ((xcd_remap ? 1 : 0) << 16) | ((terms_are_groups ? 1 : 0) << 17);
-  const int esz = dtype == 1 ? 4 : 8;
-  const int lds_texels = lds_bytes > 0 ? lds_bytes / esz : 0;
-  const size_t shmem = (size_t)kHdrBytes + (size_t)lds_texels * esz;
+// The fused evaluation lives in two translation units: this file as it is (plain functor, every launch shape) and the
+// same file compiled with -DEA_TU_VARIANT through ea_kernels_var.hip (the distortion / second-camera functors only).
+// They differ in ONE compiler setting: the plain kernels are scheduled for instruction-level parallelism
+// (-mllvm -amdgpu-sched-strategy=max-ilp: -2 .. -4 % kernel time), which costs the variant kernels a wave of occupancy in
+// fp64 (123 -> 136 VGPRs) and 4-7 % of their time -- they keep the default strategy (build.py).
 #define EA_LAUNCH_B(T, P, L, N, V, B)                                                              \
   hipLaunchKernelGGL((ea_eval_fused_kernel<T, P, L, N, V, B>), grid, dim3(N), shmem, stream, x0, y0, z0, n0, shape, \
                      chunks_per_xcd, probs, poses, partials, lds_texels)
@@ -1394,14 +1391,47 @@ hipError_t launch_eval_fused(int dtype, int ppt, int nt, int variant, const Prob
   do {                                                                                             \
     if (buffer_loads && (L) == 0) EA_LAUNCH_B(T, P, 0, N, V, true); else EA_LAUNCH_B(T, P, L, N, V, false); \
   } while (0)
+#define EA_LAUNCH_PROLOGUE                                                                          \
+  if (nterms <= 0 || max_chunks <= 0) return hipSuccess;                                            \
+  const int chunks_per_xcd = (max_chunks + 7) / 8;                                                  \
+  const dim3 grid(xcd_remap ? chunks_per_xcd * 8 : max_chunks, nterms);                             \
+  if (chunk <= 0 || chunk > 0xffff) return hipErrorInvalidValue; /* (NT * PPT <= 4096) */           \
+  const int shape = chunk | ((xcd_remap ? 1 : 0) << 16) | ((terms_are_groups ? 1 : 0) << 17);       \
+  const int esz = dtype == 1 ? 4 : 8;                                                               \
+  const int lds_texels = lds_bytes > 0 ? lds_bytes / esz : 0;                                       \
+  const size_t shmem = (size_t)kHdrBytes + (size_t)lds_texels * esz;
+
+#ifdef EA_TU_VARIANT
+// distortion / second-camera terms: 256-thread workgroups, L2 path, 1-2 points per lane
+hipError_t launch_eval_fused_var(int dtype, int ppt, const ProblemDesc *probs, int nterms, int chunk, int max_chunks,
+                                 int xcd_remap, const PoseState *poses, double *partials, int terms_are_groups,
+                                 int buffer_loads, const void *x0, const void *y0, const void *z0, int n0,
+                                 hipStream_t stream) {
+  const int lds_bytes = 0;
+  EA_LAUNCH_PROLOGUE
+  if (dtype == 1) { if (ppt == 1) EA_LAUNCH(float, 1, 0, 256, true); else EA_LAUNCH(float, 2, 0, 256, true); }
+  else { if (ppt == 1) EA_LAUNCH(double, 1, 0, 256, true); else EA_LAUNCH(double, 2, 0, 256, true); }
+  return hipGetLastError();
+}
+#else
+hipError_t launch_eval_fused_var(int dtype, int ppt, const ProblemDesc *probs, int nterms, int chunk, int max_chunks,
+                                 int xcd_remap, const PoseState *poses, double *partials, int terms_are_groups,
+                                 int buffer_loads, const void *x0, const void *y0, const void *z0, int n0,
+                                 hipStream_t stream);  // ea_kernels_var.hip
+
+hipError_t launch_eval_fused(int dtype, int ppt, int nt, int variant, const ProblemDesc *probs, int nterms, int chunk,
+                             int max_chunks, int xcd_remap, const PoseState *poses, double *partials,
+                             int lds_bytes, int terms_are_groups, int buffer_loads, const void *x0, const void *y0,
+                             const void *z0, int n0, hipStream_t stream) {
+  if (variant)
+    return launch_eval_fused_var(dtype, ppt, probs, nterms, chunk, max_chunks, xcd_remap, poses, partials, terms_are_groups,
+                                 buffer_loads, x0, y0, z0, n0, stream);
+  EA_LAUNCH_PROLOGUE
 #define EA_LAUNCH_L(T, P, N)                                                          \
   do {                                                                                \
     if (lds_texels > 0) EA_LAUNCH(T, P, 1, N, false); else EA_LAUNCH(T, P, 0, N, false); \
   } while (0)
-  if (variant) {  // distortion / second-camera terms: 256-thread workgroups, L2 path, 1-2 points per lane
-    if (dtype == 1) { if (ppt == 1) EA_LAUNCH(float, 1, 0, 256, true); else EA_LAUNCH(float, 2, 0, 256, true); }
-    else { if (ppt == 1) EA_LAUNCH(double, 1, 0, 256, true); else EA_LAUNCH(double, 2, 0, 256, true); }
-  } else if (dtype == 1) {
+  if (dtype == 1) {
     if (nt == 1024) { if (ppt == 1) EA_LAUNCH_L(float, 1, 1024); else if (ppt == 2) EA_LAUNCH_L(float, 2, 1024); else EA_LAUNCH_L(float, 4, 1024); }
     else if (ppt == 1) EA_LAUNCH_L(float, 1, 256);
     else if (ppt == 2) EA_LAUNCH_L(float, 2, 256);
@@ -1412,8 +1442,6 @@ hipError_t launch_eval_fused(int dtype, int ppt, int nt, int variant, const Prob
     else EA_LAUNCH_L(double, 2, 256);
   }
 #undef EA_LAUNCH_L
-#undef EA_LAUNCH
-#undef EA_LAUNCH_B
   return hipGetLastError();
 }
 
@@ -1482,5 +1510,10 @@ hipError_t launch_pad_image(int dtype, const void *src, int H, int W, void *dst,
     hipLaunchKernelGGL((ea_pad_image_kernel<double>), grid, block, 0, stream, (const double *)src, H, W, (double *)dst, pitch);
   return hipGetLastError();
 }
+
+#endif  // EA_TU_VARIANT
+#undef EA_LAUNCH_PROLOGUE
+#undef EA_LAUNCH
+#undef EA_LAUNCH_B
 
 }  // namespace ea
