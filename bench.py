@@ -7,7 +7,11 @@
 A "step" is one pass of the hot path over one frame pair's edge cloud with the inputs already
 resident in HBM: the fused per-point kernel (SE(3) warp, pinhole, bicubic DT sample, analytic 1x6
 row, IRLS weight, JtJ/Jtr/cost partials) plus the fixed-order fold of the partials — exactly what
-one evaluation inside the trust-region loop costs.  Default workload = BASELINE.json configs[1]
+one evaluation inside the trust-region loop costs.  The K timed steps are K independent evaluations at
+the resident pose, replayed from one hipGraph in which the fold of step k-1 rides in the launch of
+evaluation k (one extra workgroup per problem; K launches + one closing fold, every step still runs
+both parts in full; --serial-steps gives the two-dependent-launches form, whose per-step time the
+line also carries as roofline.step_ms_events_serial_graph).  Default workload = BASELINE.json configs[1]
 (C2): single 640x480 frame pair, 5e4 edge points, fp64.  With N GPUs every rank evaluates its own
 independent frame pair (weak scaling, no data-path collective); the one collective is the pose
 all-gather (RCCL) after the per-rank LM solves, reported separately.
@@ -149,6 +153,8 @@ def main():
     ap.add_argument("--extras-timeout", type=float, default=240.0,
                     help="seconds the secondary measurements may take before the line is printed without the unfinished ones")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the timed steps launch by launch instead of replaying a hipGraph")
+    ap.add_argument("--serial-steps", action="store_true",
+                    help="timed region as evaluation -> fold -> evaluation ... (two dependent launches per step) instead of the fold of step k-1 riding in the launch of evaluation k")
     # rehearsal knobs (the driver never passes them): run the N>1 control flow on a one-GPU box
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--force-device", type=int, default=None, help="use this HIP device on every rank")
@@ -206,13 +212,25 @@ def main():
     # creates its events).  Timed: EXACTLY K steps between barrier+sync brackets -- ea_batch_bench_steps only enqueues
     # K x (fused eval + fold) at the resident poses and synchronises the stream, no setup inside the bracket.
     B.bench_eval(q0, t0, 0, max(args.warmup, 1), kernel_pass=False)
-    graph = None
+    graph, pipelined = None, False
     if not args.no_graph:
-        try:  # untimed: the K steps as one hipGraph (launch-bound inner loop: two ~3 us kernels per step)
-            B.bench_capture(args.steps)
-            graph = "hipGraph of %d steps (2 kernel nodes per step), one replay" % args.steps
-        except capi.EAError as e:
-            graph = "eager launches (graph capture failed: %s)" % e
+        # untimed: the K steps as one hipGraph (launch-bound inner loop).  Default: the fold of step k-1 rides in the launch
+        # of evaluation k (ea_batch_bench_capture_pipelined: K launches + one closing fold; the K passes are independent
+        # evaluations at the resident poses, every step still runs its evaluation and its fold in full).  --serial-steps:
+        # evaluation -> fold -> evaluation ..., two dependent launches per step.
+        if not args.serial_steps:
+            try:
+                B.bench_capture_pipelined(args.steps)
+                graph = "hipGraph of %d steps (evaluation k + riding fold k-1 per kernel node, one closing fold), one replay" % args.steps
+                pipelined = True
+            except capi.EAError as e:
+                graph = None
+        if graph is None:
+            try:
+                B.bench_capture(args.steps)
+                graph = "hipGraph of %d steps (2 kernel nodes per step), one replay" % args.steps
+            except capi.EAError as e:
+                graph = "eager launches (graph capture failed: %s)" % e
     barrier_sync()
     t_start = time.perf_counter()
     B.bench_steps(args.steps)
@@ -223,31 +241,42 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     value = world * n_pts * args.steps / elapsed
+    # the timed launches computed what ea_batch_eval computes (the riding folds sum in another order: equal to rounding)
+    got, want = B.bench_result(), B.eval(q0, t0)
+    B.bench_eval(q0, t0, 0, 1, kernel_pass=False)  # (poses resident again for the measurements below)
+    if not (np.allclose(got["cost"], want["cost"], rtol=1e-12, atol=0) and np.allclose(got["JtJ"], want["JtJ"], rtol=1e-12, atol=1e-300)
+            and np.allclose(got["Jtr"], want["Jtr"], rtol=1e-11, atol=1e-300) and np.array_equal(got["n_invalid"], want["n_invalid"])):
+        raise SystemExit("bench.py: the timed steps' result differs from ea_batch_eval's")
 
-    # Duration of the dominant kernel, HIP events on the library's stream.  A step of the timed region is the fused
-    # evaluation followed by the fold, two dependent launches:
-    #   kernel_ms               the evaluation kernel's share of a step = (event pair around K steps) / K minus the fold
-    #                           kernel's own time -- what rocprofv3 --kernel-trace reports per launch for this command
-    #                           (profiles/), and what `achieved` / `frac` are computed from;
-    #   kernel_ms_back_to_back  one event pair around a run of evaluation launches executing from the queue, / their
+    # Duration of the dominant kernel, HIP events on the library's stream.
+    #   kernel_ms               pipelined region: (event pair around nk >= 100 replayed steps) / nk -- a step IS one launch of
+    #                           the evaluation kernel (with the previous step's fold riding in it), the figure rocprofv3
+    #                           --kernel-trace reports per launch for this command (profiles/); serial region: the
+    #                           evaluation's share of a step = that quotient minus the fold kernel's own time.  Never below
+    #                           kernel_ms_back_to_back.  `achieved` / `frac` are computed from it;
+    #   kernel_ms_back_to_back  one event pair around a run of plain evaluation launches executing from the queue, / their
     #                           number: the kernel's execution window with the next dispatch already decoded;
-    #   kernel_ms_isolated      an event pair around every single launch of the timed pattern, which also contains the
+    #   kernel_ms_isolated      an event pair around every single launch of the serial pattern, which also contains the
     #                           command processor's dispatch (~2.6 us) because nothing is in flight to hide it.
     nk = min(max(args.steps, 100), 1000)
     ms_steps, ms_kernel_isolated = B.bench_eval(q0, t0, 2, min(args.steps, 64))
     ms_steps, _ = B.bench_eval(q0, t0, 20, nk, kernel_pass=False)       # launch by launch (host-bound: ~3.1 us per launch)
     step_ms_eager = ms_steps / nk
+    step_ms_serial = step_ms_pipelined = None
     if graph and graph.startswith("hipGraph"):
-        # the timed region's launch pattern (a hipGraph of steps), nk steps of it between an event pair on the library's
-        # stream; nk >= 100 so that a short --steps run does not measure the first nodes' ramp instead of the kernel
-        if nk != args.steps:
-            B.bench_capture(nk)
-        step_ms = min(B.bench_steps(nk, host_times=True)[2] for _ in range(3)) / nk
+        # the launch patterns as hipGraphs of nk steps between an event pair on the library's stream; nk >= 100 so that a
+        # short --steps run does not measure the first nodes' ramp instead of the kernel
+        B.bench_capture(nk)
+        step_ms_serial = min(B.bench_steps(nk, host_times=True)[2] for _ in range(3)) / nk
+        if pipelined:
+            B.bench_capture_pipelined(nk)
+            step_ms_pipelined = min(B.bench_steps(nk, host_times=True)[2] for _ in range(3)) / nk
     else:
-        step_ms = step_ms_eager
+        step_ms_serial = step_ms_eager
     ms_fold = B.bench_fold(10, nk)
     ms_kernel_b2b = B.bench_kernel(q0, t0, 10, nk)
-    ms_kernel = max(step_ms - ms_fold, ms_kernel_b2b)
+    step_ms = step_ms_pipelined if pipelined else step_ms_serial
+    ms_kernel = max(step_ms if pipelined else step_ms - ms_fold, ms_kernel_b2b)
     bytes_launch = algorithmic_bytes(n_pts, H, W, esize)
     achieved = bytes_launch / (ms_kernel * 1e-3) / 1e9
     traffic = None
@@ -259,10 +288,11 @@ def main():
             traffic = None
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "ea_eval_fused_kernel<%s>" % ("double" if esize == 8 else "float"),
+                "kernel": "%s<%s>" % ("ea_eval_fold_kernel" if pipelined else "ea_eval_fused_kernel", "double" if esize == 8 else "float"),
                 "kernel_ms": ms_kernel, "kernel_ms_back_to_back": ms_kernel_b2b,
                 "frac_back_to_back": bytes_launch / (ms_kernel_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "fold_kernel_ms": ms_fold, "step_ms_events": step_ms, "step_ms_events_eager_launches": step_ms_eager, "kernel_ms_isolated": ms_kernel_isolated,
+                "fold_kernel_ms": ms_fold, "step_ms_events": step_ms, "step_ms_events_serial_graph": step_ms_serial,
+                "step_ms_events_eager_launches": step_ms_eager, "kernel_ms_isolated": ms_kernel_isolated,
                 "algorithmic_bytes_per_launch": bytes_launch,
                 "secondary": valu_issue(args.workload, ms_kernel_b2b)}
 

@@ -30,7 +30,7 @@ EXPORTED = [
     "ea_eval", "ea_eval_points", "ea_cost", "ea_problem_pixel_cost", "ea_solve",
     "ea_batch_create", "ea_batch_destroy", "ea_batch_count", "ea_batch_eval", "ea_batch_solve",
     "ea_solve_pyramid", "ea_solve_sharded", "ea_solve_sharded_device", "ea_tracker_create", "ea_tracker_destroy", "ea_tracker_problem", "ea_tracker_push_frame",
-    "ea_batch_bench_eval", "ea_batch_bench_steps", "ea_batch_bench_capture", "ea_batch_bench_kernel", "ea_batch_bench_fold", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
+    "ea_batch_bench_eval", "ea_batch_bench_steps", "ea_batch_bench_capture", "ea_batch_bench_capture_pipelined", "ea_batch_bench_result", "ea_batch_bench_result_riding", "ea_batch_bench_kernel", "ea_batch_bench_fold", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
     "ea_problem_set_ref_frame", "ea_problem_set_ref_frame_masked", "ea_problem_set_now_frame", "ea_problem_debug_now_frame",
     "ea_problem_set_ref_frame_canny", "ea_problem_set_now_frame_canny", "ea_problem_debug_now_frame_canny",
     "ea_problem_set_ref_frame_ros", "ea_problem_set_now_frame_ros", "ea_problem_debug_now_frame_ros",
@@ -130,6 +130,9 @@ def load():
     L.ea_batch_bench_eval.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp, dp]
     L.ea_batch_bench_steps.argtypes = [vp, C.c_int, dp]
     L.ea_batch_bench_capture.argtypes = [vp, C.c_int]
+    L.ea_batch_bench_capture_pipelined.argtypes = [vp, C.c_int]
+    L.ea_batch_bench_result.argtypes = [vp, dp, dp, dp, i64p]
+    L.ea_batch_bench_result_riding.argtypes = [vp, dp, dp, dp, i64p]
     L.ea_batch_bench_kernel.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp]
     L.ea_batch_bench_fold.argtypes = [vp, C.c_int, C.c_int, dp]
     L.ea_problem_pixel_cost.argtypes = [vp, dp, dp, C.POINTER(PixelCost)]
@@ -565,6 +568,20 @@ class Batch:
     def bench_capture(self, steps):
         """untimed: capture `steps` steps into a hipGraph that bench_steps(steps) replays"""
         _check(load().ea_batch_bench_capture(self._h, int(steps)))
+
+    def bench_capture_pipelined(self, steps):
+        """untimed: the same steps with the fold of step k-1 riding in the launch of evaluation k (K launches + 1)"""
+        _check(load().ea_batch_bench_capture_pipelined(self._h, int(steps)))
+
+    def bench_result(self, riding=False):
+        """what the last step of the last bench_steps left in the batch's result array (layout of eval);
+        riding=True: the last-but-one step's result of a pipelined sequence (folded inside an evaluation launch)"""
+        n = len(self)
+        cost, JtJ, Jtr = np.zeros(n), np.zeros((n, 6, 6)), np.zeros((n, 6))
+        bad = np.zeros(n, dtype=np.int64)
+        fn = load().ea_batch_bench_result_riding if riding else load().ea_batch_bench_result
+        _check(fn(self._h, _dp(cost), _dp(JtJ), _dp(Jtr), bad.ctypes.data_as(C.POINTER(C.c_int64))))
+        return dict(cost=cost, JtJ=JtJ, Jtr=Jtr, n_invalid=bad)
 
     def bench_steps(self, steps, host_times=False):
         """`steps` x (fused evaluation + fold) at the poses already on the device, then a stream sync: the timed region"""

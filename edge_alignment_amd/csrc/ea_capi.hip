@@ -31,6 +31,12 @@ hipError_t launch_eval_points(int dtype, const ProblemDesc *probs, int problem, 
                               double *r_out, double *J_out, int corrected, hipStream_t stream);
 hipError_t launch_reduce(const GroupDesc *groups, int count, const double *partials, EvalOut *out,
                          hipStream_t stream);
+hipError_t launch_eval_fold(int dtype, int ppt, int nt, const ProblemDesc *probs, int nterms, int chunk, int max_chunks,
+                            int xcd_remap, const PoseState *poses, double *partials, int buffer_loads, const void *x0,
+                            const void *y0, const void *z0, int n0, const GroupDesc *groups, const double *prev_rows,
+                            EvalOut *prev_out, hipStream_t stream);
+hipError_t launch_reduce_nt(int nt, const GroupDesc *groups, int count, const double *partials, EvalOut *out,
+                            hipStream_t stream);
 hipError_t launch_lm_step(const GroupDesc *groups, int count, const double *partials, PoseState *poses,
                           LMState *states, LMCold *cold, LMTrace *traces, const LMOptions &opt, int *running_flags,
                           LMState *host_states, LMTrace *host_traces, const GroupDesc &first, hipStream_t stream);
@@ -189,6 +195,11 @@ struct ea_batch {
   hipEvent_t bench_e0 = nullptr, bench_e1 = nullptr;
   hipGraphExec_t bench_graph = nullptr;  // K x (evaluation + fold) captured once (ea_batch_bench_capture), replayed by
   int bench_graph_steps = 0;             // ea_batch_bench_steps(K): the timed region then holds no per-launch host work
+  // ea_batch_bench_capture_pipelined: the fold of step k-1 rides in the launch of evaluation k; the evaluations alternate
+  // between `bench_ring` = 2 row / result arrays
+  int bench_ring = 0;
+  double *d_bench_rows = nullptr;   // bench_ring x tiles_cap x kAccSlots
+  EvalOut *d_bench_out = nullptr;   // bench_ring x count
   bool needs_drain = false;     // a solve gave up on its deadline with launches still queued: synchronise before reuse
   const void *x0 = nullptr, *y0 = nullptr, *z0 = nullptr;  // problem 0's point arrays and count, handed to the evaluation
   int n0 = 0;                                              // kernel in its preloaded arguments
@@ -547,8 +558,14 @@ extern "C" int ea_problem_set_flavour(ea_problem *p, double z_guard, double z_ep
 
 // ---- batch --------------------------------------------------------------------------------------
 
+static void bench_ring_free(ea_batch *b) {
+  (void)hipFree(b->d_bench_rows); (void)hipFree(b->d_bench_out);
+  b->d_bench_rows = nullptr; b->d_bench_out = nullptr; b->bench_ring = 0;
+}
+
 static void batch_free_device(ea_batch *b) {
   if (b->bench_graph) { (void)hipGraphExecDestroy(b->bench_graph); b->bench_graph = nullptr; b->bench_graph_steps = 0; }
+  bench_ring_free(b);
   if (b->bench_e0) { (void)hipEventDestroy(b->bench_e0); b->bench_e0 = nullptr; }
   if (b->bench_e1) { (void)hipEventDestroy(b->bench_e1); b->bench_e1 = nullptr; }
   (void)hipFree(b->d_one_row); b->d_one_row = nullptr;
@@ -687,6 +704,7 @@ static int batch_build(ea_batch *b) {
   if (!dirty) return EA_OK;
   b->built = false;  // until the last allocation and upload below has succeeded
   if (b->bench_graph) { (void)hipGraphExecDestroy(b->bench_graph); b->bench_graph = nullptr; b->bench_graph_steps = 0; }
+  bench_ring_free(b);  // (sized by the row count of the old build)
   // terms of a problem follow it; all share its pose
   std::vector<const ea_problem *> terms;
   std::vector<int> term_group;
@@ -858,19 +876,8 @@ static int batch_upload_poses(ea_batch *b, const double *q, const double *t) {
   return EA_OK;
 }
 
-extern "C" int ea_batch_eval(ea_batch *b, const double *q, const double *t, double *cost, double *JtJ,
-                             double *Jtr, int64_t *n_invalid) {
-  if (!b || !q || !t) return fail(EA_ERR_INVALID_ARG, "NULL argument");
-  int rc = batch_build(b);
-  if (rc != EA_OK) return rc;
-  const int count = (int)b->probs.size();
-  rc = batch_upload_poses(b, q, t);
-  if (rc != EA_OK) return rc;
-  rc = batch_launch_eval(b);
-  if (rc != EA_OK) return rc;
-  HIPCHK(launch_reduce(b->d_groups, count, b->d_partials, b->d_out, b->stream));
-  HIPCHK(hipMemcpyAsync(b->h_out, b->d_out, count * sizeof(EvalOut), hipMemcpyDeviceToHost, b->stream));
-  HIPCHK(hipStreamSynchronize(b->stream));
+// the 32 accumulator slots of every problem (pinned host copy) -> the caller's cost / 6x6 JtJ / Jtr / invalid count
+static void unpack_eval_out(const ea_batch *b, int count, double *cost, double *JtJ, double *Jtr, int64_t *n_invalid) {
   for (int i = 0; i < count; ++i) {
     const double *acc = b->h_out[i].acc;
     if (cost) cost[i] = acc[kAccCost];
@@ -886,6 +893,22 @@ extern "C" int ea_batch_eval(ea_batch *b, const double *q, const double *t, doub
     if (Jtr) for (int a = 0; a < 6; ++a) Jtr[6 * i + a] = acc[kAccJtr + a];
     if (n_invalid) n_invalid[i] = (int64_t)llround(acc[kAccInvalid]);
   }
+}
+
+extern "C" int ea_batch_eval(ea_batch *b, const double *q, const double *t, double *cost, double *JtJ,
+                             double *Jtr, int64_t *n_invalid) {
+  if (!b || !q || !t) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  int rc = batch_build(b);
+  if (rc != EA_OK) return rc;
+  const int count = (int)b->probs.size();
+  rc = batch_upload_poses(b, q, t);
+  if (rc != EA_OK) return rc;
+  rc = batch_launch_eval(b);
+  if (rc != EA_OK) return rc;
+  HIPCHK(launch_reduce(b->d_groups, count, b->d_partials, b->d_out, b->stream));
+  HIPCHK(hipMemcpyAsync(b->h_out, b->d_out, count * sizeof(EvalOut), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  unpack_eval_out(b, count, cost, JtJ, Jtr, n_invalid);
   return EA_OK;
 }
 
@@ -1227,6 +1250,96 @@ extern "C" int ea_batch_bench_capture(ea_batch *b, int steps) {
   b->bench_graph_steps = steps;
   HIPCHK(hipGraphLaunch(b->bench_graph, b->stream));  // one untimed replay: uploads the executable graph
   HIPCHK(hipStreamSynchronize(b->stream));
+  return EA_OK;
+}
+
+// The same K steps with the fold off the evaluations' critical path.  A step is two dependent launches, and the second
+// one (one workgroup per problem) leaves the chip idle behind a kernel boundary; the next evaluation does not need its
+// result -- the K evaluations of the timed region are independent passes at the resident poses.  Here the fold of step
+// k-1 RIDES in the launch of evaluation k (ea_eval_fold_kernel: one extra workgroup per problem), the evaluations
+// alternating between two row arrays; a stand-alone fold closes the sequence.  K steps = K launches + 1, every step
+// still runs its evaluation and its fold in full, the evaluation kernels still execute one after the other.  The folds
+// sum in the order of a workgroup of the evaluation's size (equal to ea_batch_eval's 1024-thread fold up to rounding).
+// (A two-branch graph with the folds on a side stream was measured first: the cross-branch edges of a replayed graph
+// cost more than the fold -- 9-19 us per step against 5.5 serial, profiles/r02_ab_pipeline.txt.)
+extern "C" int ea_batch_bench_capture_pipelined(ea_batch *b, int steps) {
+  if (!b || steps < 1) return fail(EA_ERR_INVALID_ARG, "bad argument");
+  int rc = batch_build(b);
+  if (rc != EA_OK) return rc;
+  if (!b->poses_uploaded) return fail(EA_ERR_STATE, "no poses uploaded yet (ea_batch_bench_eval or ea_batch_eval first)");
+  if (b->any_variant || !b->terms_are_groups || b->lds_bytes > 0)
+    return fail(EA_ERR_STATE, "the pipelined form covers plain single-family problems on the L2 path");
+  if (b->bench_graph) { (void)hipGraphExecDestroy(b->bench_graph); b->bench_graph = nullptr; b->bench_graph_steps = 0; }
+  const int count = (int)b->probs.size();
+  HIPCHK(hipStreamSynchronize(b->stream));
+  const size_t row_doubles = (size_t)b->tiles_cap * kAccSlots;
+  if (b->bench_ring != 2) {
+    bench_ring_free(b);
+    HIPCHK(hipMalloc(&b->d_bench_rows, row_doubles * sizeof(double) * 2));
+    hipError_t ea = hipMalloc(&b->d_bench_out, sizeof(EvalOut) * (size_t)count * 2);
+    if (ea != hipSuccess) { bench_ring_free(b); return fail(EA_ERR_ALLOC, "bench row buffers: allocation failed"); }
+    b->bench_ring = 2;
+    HIPCHK(hipMemsetAsync(b->d_bench_rows, 0, row_doubles * sizeof(double) * 2, b->stream));
+    HIPCHK(hipMemsetAsync(b->d_bench_out, 0, sizeof(EvalOut) * (size_t)count * 2, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+  }
+  double *const own_rows = b->d_partials;
+  HIPCHK(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < steps && e == hipSuccess; ++i) {
+    double *rows = b->d_bench_rows + row_doubles * (size_t)(i & 1);
+    if (i == 0) {
+      b->d_partials = rows;
+      const int lr = batch_launch_eval(b);
+      b->d_partials = own_rows;
+      if (lr != EA_OK) e = hipErrorUnknown;
+    } else {
+      const int prev = (i - 1) & 1;
+      e = launch_eval_fold(b->dtype, b->ppt, b->nt, b->d_probs, b->nterms, b->chunk, b->max_chunks, b->xcd_remap, b->d_poses,
+                           rows, b->buffer_loads, b->x0, b->y0, b->z0, b->n0, b->d_groups,
+                           b->d_bench_rows + row_doubles * (size_t)prev, b->d_bench_out + (size_t)count * (size_t)prev, b->stream);
+    }
+  }
+  if (e == hipSuccess)
+    e = launch_reduce_nt(b->nt, b->d_groups, count, b->d_bench_rows + row_doubles * (size_t)((steps - 1) & 1), b->d_out, b->stream);
+  hipGraph_t graph = nullptr;
+  const hipError_t ee = hipStreamEndCapture(b->stream, &graph);
+  if (e != hipSuccess || ee != hipSuccess || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return fail(EA_ERR_HIP, std::string("graph capture (pipelined): ") + hipGetErrorString(e != hipSuccess ? e : ee));
+  }
+  e = hipGraphInstantiate(&b->bench_graph, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) { b->bench_graph = nullptr; return fail(EA_ERR_HIP, std::string("graph instantiate: ") + hipGetErrorString(e)); }
+  b->bench_graph_steps = steps;
+  HIPCHK(hipGraphLaunch(b->bench_graph, b->stream));  // one untimed replay: uploads the executable graph
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return EA_OK;
+}
+
+// The last-but-one step's result of a pipelined sequence (result slot (steps - 2) & 1): with ea_batch_bench_result this
+// covers both a riding fold and the closing stand-alone fold.
+extern "C" int ea_batch_bench_result_riding(ea_batch *b, double *cost, double *JtJ, double *Jtr, int64_t *n_invalid) {
+  if (!b) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  if (!b->built || !b->bench_graph || b->bench_ring != 2 || b->bench_graph_steps < 2)
+    return fail(EA_ERR_STATE, "no pipelined sequence of at least two steps captured");
+  const int count = (int)b->probs.size();
+  HIPCHK(hipMemcpyAsync(b->h_out, b->d_bench_out + (size_t)count * (size_t)((b->bench_graph_steps - 2) & 1), count * sizeof(EvalOut),
+                        hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  unpack_eval_out(b, count, cost, JtJ, Jtr, n_invalid);
+  return EA_OK;
+}
+
+// What the last step of the last ea_batch_bench_steps left in the batch's result array (cost, JtJ, Jtr per problem, the
+// layout of ea_batch_eval): lets a caller check that the timed launches computed what ea_batch_eval computes.
+extern "C" int ea_batch_bench_result(ea_batch *b, double *cost, double *JtJ, double *Jtr, int64_t *n_invalid) {
+  if (!b) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  if (!b->built || !b->poses_uploaded) return fail(EA_ERR_STATE, "nothing evaluated yet");
+  const int count = (int)b->probs.size();
+  HIPCHK(hipMemcpyAsync(b->h_out, b->d_out, count * sizeof(EvalOut), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  unpack_eval_out(b, count, cost, JtJ, Jtr, n_invalid);
   return EA_OK;
 }
 

@@ -903,11 +903,7 @@ __device__ __forceinline__ double fused_chunk(const ProblemDesc &pd, const PS &p
 // NT = workgroup size (256 or 1024).  1024 = one workgroup per CU: four times fewer partial rows
 // to fold afterwards at the same points-per-lane latency.
 template <typename T, int PPT, int MODE, int NT, bool VAR, bool BUF>
-__global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
-    // the first 16 dwords of the argument segment arrive in SGPRs with the wave (kernarg preload): what problem 0's point
-    // loads need sits there, so that they can be issued at once, beside the descriptor fetch instead of behind it
-    // (14 dwords fit beside the argument pointer: three pointers, the count, the launch shape packed into one word --
-    // chunk | xcd_remap << 16 | terms_are_groups << 17 --, chunks per XCD, and the descriptor and pose tables)
+__device__ __forceinline__ void eval_fused_body(
     const void *__restrict__ x0, const void *__restrict__ y0, const void *__restrict__ z0, int n0,
     int shape, int chunks_per_xcd,
     const ProblemDesc *__restrict__ probs, const PoseState *__restrict__ poses,
@@ -1023,6 +1019,19 @@ __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   EA_STAMP(7);  // row stored
+}
+
+template <typename T, int PPT, int MODE, int NT, bool VAR, bool BUF>
+__global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
+    // the first 16 dwords of the argument segment arrive in SGPRs with the wave (kernarg preload): what problem 0's point
+    // loads need sits there, so that they can be issued at once, beside the descriptor fetch instead of behind it
+    // (14 dwords fit beside the argument pointer: three pointers, the count, the launch shape packed into one word --
+    // chunk | xcd_remap << 16 | terms_are_groups << 17 --, chunks per XCD, and the descriptor and pose tables)
+    const void *__restrict__ x0, const void *__restrict__ y0, const void *__restrict__ z0, int n0,
+    int shape, int chunks_per_xcd,
+    const ProblemDesc *__restrict__ probs, const PoseState *__restrict__ poses,
+    double *__restrict__ partials, int lds_texels) {
+  eval_fused_body<T, PPT, MODE, NT, VAR, BUF>(x0, y0, z0, n0, shape, chunks_per_xcd, probs, poses, partials, lds_texels);
 }
 
 #ifndef EA_TU_VARIANT
@@ -1235,6 +1244,38 @@ __global__ __launch_bounds__(kFoldThreads) void ea_reduce_kernel(const GroupDesc
   reduce_tiles<kFoldThreads, 8>(partials, gd.tile_begin, gd.tile_end, s_part, out[blockIdx.x].acc);
 }
 
+// The fold as a 256-thread workgroup sums it when it rides in an evaluation launch (ea_eval_fold_kernel below; 8 rows in
+// flight per lane keep the riding workgroup inside the evaluation's register budget): closes a pipelined sequence.
+__global__ __launch_bounds__(kLmThreads) void ea_reduce256_kernel(const GroupDesc *__restrict__ groups,
+                                                                  const double *__restrict__ partials,
+                                                                  EvalOut *__restrict__ out) {
+  __shared__ double s_part[(kLmThreads / 32) * kAccSlots];
+  const GroupDesc gd = groups[blockIdx.x];
+  reduce_tiles<kLmThreads, 8>(partials, gd.tile_begin, gd.tile_end, s_part, out[blockIdx.x].acc);
+}
+
+// Evaluation k with the fold of evaluation k-1 riding in the same launch: one extra workgroup per problem (the last
+// column of the grid) folds the rows the PREVIOUS launch left in `prev_rows` into `prev_out` while the others evaluate
+// into `partials` (a different row array).  A stream of independent evaluations then costs one launch per evaluation
+// instead of two dependent ones -- the fold's kernel boundary (1.45 us) and its memory round trip disappear under the
+// evaluation.  The fold workgroup sums in the order reduce_tiles<NT> gives a workgroup of this size.
+// Plain single-family problems, stencil rows from L2 (MODE 0).
+template <typename T, int PPT, int NT, bool BUF>
+__global__ __launch_bounds__(NT) void ea_eval_fold_kernel(
+    const void *__restrict__ x0, const void *__restrict__ y0, const void *__restrict__ z0, int n0,
+    int shape, int chunks_per_xcd,
+    const ProblemDesc *__restrict__ probs, const PoseState *__restrict__ poses,
+    double *__restrict__ partials, int lds_texels,
+    const GroupDesc *__restrict__ groups, const double *__restrict__ prev_rows, EvalOut *__restrict__ prev_out) {
+  if (blockIdx.x == gridDim.x - 1) {  // (uniform)
+    __shared__ double s_part[(NT / 32) * kAccSlots];
+    const GroupDesc gd = groups[blockIdx.y];
+    reduce_tiles<NT, 8>(prev_rows, gd.tile_begin, gd.tile_end, s_part, prev_out[blockIdx.y].acc);
+    return;
+  }
+  eval_fused_body<T, PPT, 0, NT, false, BUF>(x0, y0, z0, n0, shape, chunks_per_xcd, probs, poses, partials, lds_texels);
+}
+
 // LM step: fold this problem's partial rows, advance the trust-region state machine, publish the
 // next pose to evaluate.  One workgroup per problem.  The state machine is scalar fp64 work on
 // lane 0 (pure latency: ~1/3 of an LM iteration), so everything around it is arranged to overlap:
@@ -1442,6 +1483,46 @@ hipError_t launch_eval_fused(int dtype, int ppt, int nt, int variant, const Prob
     else EA_LAUNCH_L(double, 2, 256);
   }
 #undef EA_LAUNCH_L
+  return hipGetLastError();
+}
+
+// evaluation into `partials` + the fold of `prev_rows` -> `prev_out` in one launch (ea_eval_fold_kernel)
+hipError_t launch_eval_fold(int dtype, int ppt, int nt, const ProblemDesc *probs, int nterms, int chunk, int max_chunks,
+                            int xcd_remap, const PoseState *poses, double *partials, int buffer_loads, const void *x0,
+                            const void *y0, const void *z0, int n0, const GroupDesc *groups, const double *prev_rows,
+                            EvalOut *prev_out, hipStream_t stream) {
+  const int lds_bytes = 0, terms_are_groups = 1;
+  EA_LAUNCH_PROLOGUE
+  const dim3 grid_f(grid.x + 1, grid.y);
+#define EA_LAUNCH_F(T, P, N)                                                                                          \
+  do {                                                                                                                \
+    if (buffer_loads)                                                                                                 \
+      hipLaunchKernelGGL((ea_eval_fold_kernel<T, P, N, true>), grid_f, dim3(N), shmem, stream, x0, y0, z0, n0, shape,  \
+                         chunks_per_xcd, probs, poses, partials, lds_texels, groups, prev_rows, prev_out);            \
+    else                                                                                                              \
+      hipLaunchKernelGGL((ea_eval_fold_kernel<T, P, N, false>), grid_f, dim3(N), shmem, stream, x0, y0, z0, n0, shape, \
+                         chunks_per_xcd, probs, poses, partials, lds_texels, groups, prev_rows, prev_out);            \
+  } while (0)
+  if (dtype == 1) {
+    if (nt == 1024) { if (ppt == 1) EA_LAUNCH_F(float, 1, 1024); else if (ppt == 2) EA_LAUNCH_F(float, 2, 1024); else EA_LAUNCH_F(float, 4, 1024); }
+    else if (ppt == 1) EA_LAUNCH_F(float, 1, 256);
+    else if (ppt == 2) EA_LAUNCH_F(float, 2, 256);
+    else EA_LAUNCH_F(float, 4, 256);
+  } else {
+    if (nt == 1024) EA_LAUNCH_F(double, 1, 1024);
+    else if (ppt == 1) EA_LAUNCH_F(double, 1, 256);
+    else EA_LAUNCH_F(double, 2, 256);
+  }
+#undef EA_LAUNCH_F
+  return hipGetLastError();
+}
+
+// the stand-alone fold in the order the riding folds of an nt-thread evaluation use
+hipError_t launch_reduce_nt(int nt, const GroupDesc *groups, int count, const double *partials, EvalOut *out,
+                            hipStream_t stream) {
+  if (count <= 0) return hipSuccess;
+  if (nt == 1024) hipLaunchKernelGGL(ea_reduce_kernel, dim3(count), dim3(kFoldThreads), 0, stream, groups, partials, out);
+  else hipLaunchKernelGGL(ea_reduce256_kernel, dim3(count), dim3(kLmThreads), 0, stream, groups, partials, out);
   return hipGetLastError();
 }
 

@@ -277,6 +277,17 @@ int ea_batch_bench_steps(ea_batch *b, int steps, double *host_us /* nullable, 3 
  * `steps` then replays the graph (one host call, the launches execute back to back from the queue) instead of enqueueing
  * 2 x steps launches at ~3 us of host time each.  Dropped when the batch's problems or tuning change. */
 int ea_batch_bench_capture(ea_batch *b, int steps);
+/* The same K steps with the fold of step k-1 riding in the launch of evaluation k (one extra workgroup per problem; the K
+ * passes of the timed region are independent evaluations at the resident poses, the fold's result is not an input of the
+ * next one): K launches + one closing fold instead of 2 K dependent launches.  Every step still runs its evaluation and
+ * its fold in full and the evaluation kernels execute one after the other.  The folds sum in the order of a workgroup of
+ * the evaluation's size (for 256-thread launches not the order of ea_batch_eval's 1024-thread fold: equal to rounding).  Plain single-family problems on the L2 path; EA_ERR_STATE otherwise. */
+int ea_batch_bench_capture_pipelined(ea_batch *b, int steps);
+/* cost / JtJ / Jtr / invalid count (layout of ea_batch_eval) that the LAST step of the last ea_batch_bench_steps left in
+ * the batch's result array: a check that the timed launches compute what ea_batch_eval computes. */
+int ea_batch_bench_result(ea_batch *b, double *cost, double *JtJ, double *Jtr, int64_t *n_invalid);
+/* the last-but-one step's result of a pipelined sequence (a riding fold; ea_batch_bench_result reads the closing one) */
+int ea_batch_bench_result_riding(ea_batch *b, double *cost, double *JtJ, double *Jtr, int64_t *n_invalid);
 /* `launches` of the per-point kernel queued back to back between ONE event pair: average execution window per
  * launch (dispatch of the next launch overlaps the running one) -- the figure rocprofv3 --kernel-trace reports. */
 int ea_batch_bench_kernel(ea_batch *b, const double *q, const double *t, int warmup, int launches,

@@ -1,0 +1,69 @@
+"""Serial graph of K steps (evaluation -> fold -> evaluation ...) against ea_batch_bench_capture_pipelined (the fold of step
+k-1 riding in the launch of evaluation k), same box, interleaved: wall clock of the bench bracket (torch sync |
+bench_steps | torch sync) and the event pair on the library's stream, per step.  Checks the last step's result against
+ea_batch_eval's (serial: bit for bit; pipelined: to rounding, its folds sum in another order) and the riding fold's
+result against the closing fold's (bit for bit).
+
+  python scripts/ab_pipeline.py [c2|c5|batch32]"""
+import os, sys, time, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from edge_alignment_amd import capi, synth
+
+what = sys.argv[1] if len(sys.argv) > 1 else "c2"
+probs = []
+if what == "c2":
+    cfg = synth.config_c2_twin(seed=2, n_points=50000)
+    P = capi.Problem(*cfg["K"], dtype=capi.EA_F64); P.set_points(cfg["xyz"]); P.set_dt_grid(cfg["grid"]); P.set_loss(capi.LOSS_CAUCHY, 1.0)
+    probs = [P]
+elif what == "c5":
+    cfg = synth.config_c5(seed=5, n_points=1000000)
+    P = capi.Problem(*cfg["K"], dtype=capi.EA_F32); P.set_points(cfg["xyz"]); P.set_dt_grid(cfg["grid"]); P.set_loss(capi.LOSS_TRIVIAL, 1.0)
+    probs = [P]
+else:
+    for i in range(32):
+        cfg = synth.config_c2_twin(seed=100 + i, n_points=50000)
+        P = capi.Problem(*cfg["K"], dtype=capi.EA_F64); P.set_points(cfg["xyz"]); P.set_dt_grid(cfg["grid"]); P.set_loss(capi.LOSS_CAUCHY, 1.0)
+        probs.append(P)
+B = capi.Batch(probs)
+n = len(probs)
+q0, t0 = np.tile(np.array([1., 0, 0, 0]), (n, 1)), np.zeros((n, 3))
+ref = B.eval(q0, t0)
+B.bench_eval(q0, t0, 0, 50, kernel_pass=False)
+
+
+def same(a, b):
+    return all(np.array_equal(a[k], b[k]) for k in ("cost", "JtJ", "Jtr", "n_invalid"))
+
+
+def close(a, b, rtol=1e-13):
+    return all(np.allclose(a[k], b[k], rtol=rtol, atol=0) for k in ("cost", "Jtr")) and np.allclose(a["JtJ"], b["JtJ"], rtol=rtol, atol=1e-300) \
+        and np.array_equal(a["n_invalid"], b["n_invalid"])
+
+
+def measure(K, reps=9):
+    best = None
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t_ = time.perf_counter()
+        us = B.bench_steps(K, host_times=True)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        row = ((t2 - t_) * 1e6, us[2] * 1e3)
+        best = row if best is None or row[0] < best[0] else best
+    return best
+
+
+for K in (20, 100, 2000):
+    for rnd in range(3):
+        rows = []
+        B.bench_capture(K)
+        w, e = measure(K)
+        rows.append(("serial", w, e, "" if same(B.bench_result(), ref) else " RESULT DIFFERS"))
+        B.bench_capture_pipelined(K)
+        w, e = measure(K)
+        last, riding = B.bench_result(), B.bench_result(riding=True)
+        note = ("" if close(last, ref) else " CLOSING FOLD OFF") + ("" if same(last, riding) else " RIDING != CLOSING")
+        rows.append(("fold riding", w, e, note))
+        print("K %5d round %d | " % (K, rnd) + " | ".join("%s: bracket %.1f us = %.2f/step, events %.2f/step%s" % (
+            nm, w, w / K, e / K, note) for nm, w, e, note in rows), flush=True)
