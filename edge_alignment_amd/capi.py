@@ -30,7 +30,7 @@ EXPORTED = [
     "ea_eval", "ea_eval_points", "ea_cost", "ea_problem_pixel_cost", "ea_solve",
     "ea_batch_create", "ea_batch_destroy", "ea_batch_count", "ea_batch_eval", "ea_batch_solve",
     "ea_solve_pyramid", "ea_solve_sharded", "ea_solve_sharded_device", "ea_tracker_create", "ea_tracker_destroy", "ea_tracker_problem", "ea_tracker_push_frame",
-    "ea_batch_bench_eval", "ea_batch_bench_steps", "ea_batch_bench_capture", "ea_batch_bench_capture_pipelined", "ea_batch_bench_result", "ea_batch_bench_result_riding", "ea_batch_bench_kernel", "ea_batch_bench_fold", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
+    "ea_batch_bench_eval", "ea_batch_bench_steps", "ea_batch_bench_capture", "ea_batch_bench_capture_pipelined", "ea_batch_bench_result", "ea_batch_bench_result_riding", "ea_batch_bench_kernel", "ea_batch_bench_rows", "ea_batch_row_offsets", "ea_batch_eval_rows_device", "ea_batch_eval_rows", "ea_batch_bench_fold", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
     "ea_problem_set_ref_frame", "ea_problem_set_ref_frame_masked", "ea_problem_set_now_frame", "ea_problem_debug_now_frame",
     "ea_problem_set_ref_frame_canny", "ea_problem_set_now_frame_canny", "ea_problem_debug_now_frame_canny",
     "ea_problem_set_ref_frame_ros", "ea_problem_set_now_frame_ros", "ea_problem_debug_now_frame_ros",
@@ -135,6 +135,10 @@ def load():
     L.ea_batch_bench_result_riding.argtypes = [vp, dp, dp, dp, i64p]
     L.ea_batch_bench_kernel.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp]
     L.ea_batch_bench_fold.argtypes = [vp, C.c_int, C.c_int, dp]
+    L.ea_batch_row_offsets.argtypes = [vp, i64p]
+    L.ea_batch_eval_rows_device.argtypes = [vp, dp, dp, C.c_int, C.c_int, vp, vp, C.c_int64, i64p]
+    L.ea_batch_eval_rows.argtypes = [vp, dp, dp, C.c_int, C.c_int, vp, vp, C.c_int64, i64p]
+    L.ea_batch_bench_rows.argtypes = [vp, dp, dp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int64, C.c_int, C.c_int, dp]
     L.ea_problem_pixel_cost.argtypes = [vp, dp, dp, C.POINTER(PixelCost)]
     L.ea_solve_sharded.argtypes = [vp, C.POINTER(Options), ALLREDUCE_FN, vp, dp, dp, C.POINTER(Summary)]
     L.ea_solve_sharded_device.argtypes = [vp, C.POINTER(Options), DEVICE_ALLREDUCE_FN, vp, vp, dp, dp, C.POINTER(Summary)]
@@ -522,6 +526,7 @@ class Batch:
 
     def __init__(self, problems):
         self.problems = list(problems)
+        self.dtype = self.problems[0].dtype if self.problems else EA_F64
         arr = (C.c_void_p * len(self.problems))(*[p.handle for p in self.problems])
         self._h = C.c_void_p()
         _check(load().ea_batch_create(C.byref(self._h), arr, len(self.problems)))
@@ -596,6 +601,41 @@ class Batch:
         q, t = _f64(q).reshape(-1, 4), _f64(t).reshape(-1, 3)
         ms = C.c_double()
         _check(load().ea_batch_bench_kernel(self._h, _dp(q), _dp(t), warmup, launches, C.byref(ms)))
+        return ms.value
+
+    def row_offsets(self):
+        """rows of problem i in the materialised outputs: [offsets[i], offsets[i + 1])"""
+        off = np.zeros(len(self) + 1, dtype=np.int64)
+        _check(load().ea_batch_row_offsets(self._h, off.ctypes.data_as(C.POINTER(C.c_int64))))
+        return off
+
+    def eval_rows(self, q, t, corrected=True, layout=0):
+        """materialised mode into host arrays of the batch's dtype: r [rows], J [rows, 6] (layout 0) or [6, rows] (layout 1)"""
+        q, t = _f64(q).reshape(-1, 4), _f64(t).reshape(-1, 3)
+        n = int(self.row_offsets()[-1])
+        dt = np.float32 if self.dtype == EA_F32 else np.float64
+        r = np.zeros(n, dtype=dt)
+        J = np.zeros((n, 6) if layout == 0 else (6, n), dtype=dt)
+        bad = C.c_int64()
+        _check(load().ea_batch_eval_rows(self._h, _dp(q), _dp(t), int(corrected), int(layout), r.ctypes.data_as(C.c_void_p),
+                                         J.ctypes.data_as(C.c_void_p), n, C.byref(bad)))
+        return r, J, bad.value
+
+    def eval_rows_device(self, q, t, r_ptr, J_ptr, capacity_rows, corrected=True, layout=0):
+        """materialised mode into the caller's device arrays (raw pointers, e.g. torch tensor .data_ptr()); returns n_invalid"""
+        q, t = _f64(q).reshape(-1, 4), _f64(t).reshape(-1, 3)
+        bad = C.c_int64()
+        _check(load().ea_batch_eval_rows_device(self._h, _dp(q), _dp(t), int(corrected), int(layout), C.c_void_p(r_ptr),
+                                                C.c_void_p(J_ptr), int(capacity_rows), C.byref(bad)))
+        return bad.value
+
+    def bench_rows(self, q, t, warmup, launches, corrected=True, layout=0, mode=1, r_ptr=None, J_ptr=None, capacity_rows=0):
+        """mean ms of the materialised-mode kernel over `launches` back-to-back launches (one event pair)"""
+        q, t = _f64(q).reshape(-1, 4), _f64(t).reshape(-1, 3)
+        ms = C.c_double()
+        _check(load().ea_batch_bench_rows(self._h, _dp(q), _dp(t), int(corrected), int(layout), int(mode),
+                                          C.c_void_p(r_ptr) if r_ptr else None, C.c_void_p(J_ptr) if J_ptr else None,
+                                          int(capacity_rows), warmup, launches, C.byref(ms)))
         return ms.value
 
     def bench_fold(self, warmup, launches):

@@ -27,6 +27,9 @@ hipError_t launch_eval_fused(int dtype, int ppt, int nt, int variant, const Prob
                              const void *z0, int n0, hipStream_t stream);
 hipError_t launch_pixel_cost(int dtype, const ProblemDesc *probs, int problem, int n, const PoseState *poses, void *partials,
                              hipStream_t stream);
+hipError_t launch_eval_rows(int dtype, int variant, int buffer_loads, int layout, int staged, const ProblemDesc *probs, int nterms,
+                            long long max_n, const PoseState *poses, int corrected, int nontemporal, long long total_rows,
+                            void *r_out, void *J_out, unsigned int *n_invalid, hipStream_t stream);
 hipError_t launch_eval_points(int dtype, const ProblemDesc *probs, int problem, int n, const PoseState *poses,
                               double *r_out, double *J_out, int corrected, hipStream_t stream);
 hipError_t launch_reduce(const GroupDesc *groups, int count, const double *partials, EvalOut *out,
@@ -207,6 +210,13 @@ struct ea_batch {
   hipEvent_t round_done = nullptr;  // behind the last step kernel of a round of ea_solve_sharded_device
   GroupDesc *d_one_row = nullptr;  // {0, 1, 0, 1}: "one partial row" for the step kernel of ea_solve_sharded_device
   bool poses_uploaded = false;  // d_poses holds caller-supplied poses (ea_batch_bench_steps re-evaluates at them)
+  // materialised mode (ea_batch_eval_rows*): rows of all terms, in term order; library-owned output arrays on request
+  int64_t total_rows = 0, max_n = 0;
+  std::vector<int64_t> row_offsets;     // per problem (its terms are adjacent), count + 1 entries
+  void *d_rows_r = nullptr, *d_rows_J = nullptr;
+  int64_t rows_cap = 0;
+  unsigned int *d_rows_invalid = nullptr;
+  int t_rows_staged = -1, t_rows_nt = -1;
 };
 
 static int check_device(int device) {
@@ -564,6 +574,8 @@ static void bench_ring_free(ea_batch *b) {
 }
 
 static void batch_free_device(ea_batch *b) {
+  (void)hipFree(b->d_rows_r); (void)hipFree(b->d_rows_J); (void)hipFree(b->d_rows_invalid);
+  b->d_rows_r = b->d_rows_J = nullptr; b->d_rows_invalid = nullptr; b->rows_cap = 0;
   if (b->bench_graph) { (void)hipGraphExecDestroy(b->bench_graph); b->bench_graph = nullptr; b->bench_graph_steps = 0; }
   bench_ring_free(b);
   if (b->bench_e0) { (void)hipEventDestroy(b->bench_e0); b->bench_e0 = nullptr; }
@@ -782,11 +794,16 @@ static int batch_build(ea_batch *b) {
   std::vector<ProblemDesc> descs(terms.size());
   std::vector<GroupDesc> groups(b->probs.size());
   int rows = 0, max_chunks = 0;
+  int64_t row_begin = 0;
+  std::vector<int64_t> row_offsets(b->probs.size() + 1, 0);
   for (size_t k = 0; k < terms.size(); ++k) {
     const ea_problem *p = terms[k];
     ProblemDesc &d = descs[k];
     fill_desc(p, d);
     d.group = term_group[k];
+    d.row_begin = row_begin;
+    if (k == 0 || term_group[k - 1] != term_group[k]) row_offsets[(size_t)term_group[k]] = row_begin;
+    row_begin += p->n;
     const int nchunks = (int)((p->n + chunk - 1) / chunk);
     d.tile_begin = rows;
     rows += nchunks;
@@ -803,6 +820,10 @@ static int batch_build(ea_batch *b) {
   else { b->x0 = b->y0 = b->z0 = nullptr; b->n0 = 0; }
   b->ntiles = rows;
   b->max_chunks = max_chunks;
+  row_offsets[b->probs.size()] = row_begin;
+  b->row_offsets = row_offsets;
+  b->total_rows = row_begin;
+  b->max_n = max_n;
   if (b->nterms > b->terms_cap) {
     (void)hipFree(b->d_probs);
     b->d_probs = nullptr;
@@ -1430,6 +1451,129 @@ extern "C" int ea_batch_bench_fold(ea_batch *b, int warmup, int launches, double
   return EA_OK;
 }
 
+// ---- materialised mode (the "EAResidue batch Evaluate" view) ------------------------------------------------
+// Residual and 1x6 row of every point of every term, in the batch's dtype, into device arrays: the caller's or the
+// library's own.  Rows of problem i are [offsets[i], offsets[i+1]) (ea_batch_row_offsets), terms of a problem adjacent,
+// points in their storage order (ea_problem_get_points).
+
+static int rows_own_buffers(ea_batch *b) {
+  if (b->rows_cap >= b->total_rows && b->d_rows_r) return EA_OK;
+  (void)hipFree(b->d_rows_r); (void)hipFree(b->d_rows_J);
+  b->d_rows_r = b->d_rows_J = nullptr; b->rows_cap = 0;
+  const size_t es = b->dtype == EA_F32 ? 4 : 8;
+  const int64_t cap = std::max<int64_t>(b->total_rows, 1);
+  HIPCHK(hipMalloc(&b->d_rows_r, (size_t)cap * es));
+  hipError_t e = hipMalloc(&b->d_rows_J, (size_t)cap * 6 * es);
+  if (e != hipSuccess) { (void)hipFree(b->d_rows_r); b->d_rows_r = nullptr; return fail(EA_ERR_ALLOC, "row arrays: allocation failed"); }
+  b->rows_cap = cap;
+  return EA_OK;
+}
+
+// a caller's device pointer: non-NULL, 16-byte aligned, and -- where this runtime knows the allocation -- device memory of
+// the batch's GPU.  (Memory of another HIP runtime in the same process, e.g. the storage of a PyTorch-ROCm tensor, is
+// unknown to hipPointerGetAttributes here although kernels can address it: such pointers are taken on trust.)
+static int check_device_pointer(const ea_batch *b, const void *ptr, const char *what) {
+  if (!ptr) return fail(EA_ERR_INVALID_ARG, std::string(what) + " is NULL");
+  if (reinterpret_cast<uintptr_t>(ptr) % 16 != 0) return fail(EA_ERR_INVALID_ARG, std::string(what) + " must be 16-byte aligned");
+  hipPointerAttribute_t at;
+  const hipError_t e = hipPointerGetAttributes(&at, ptr);
+  if (e != hipSuccess) { (void)hipGetLastError(); return EA_OK; }
+  if (at.type == hipMemoryTypeHost) return fail(EA_ERR_INVALID_ARG, std::string(what) + " is host memory (device memory expected)");
+  if ((at.type == hipMemoryTypeDevice) && at.device != b->device)
+    return fail(EA_ERR_INVALID_ARG, std::string(what) + " lives on another device than the batch");
+  return EA_OK;
+}
+
+static int rows_launch(ea_batch *b, int corrected, int layout, int staged, int nontemporal, void *r_dev, void *J_dev) {
+  HIPCHK(launch_eval_rows(b->dtype, b->any_variant, b->buffer_loads, layout, staged, b->d_probs, b->nterms, b->max_n, b->d_poses,
+                          corrected ? 1 : 0, nontemporal, b->total_rows, r_dev, J_dev, b->d_rows_invalid, b->stream));
+  return EA_OK;
+}
+
+static int rows_prepare(ea_batch *b, const double *q, const double *t, int layout, void **r_dev, void **J_dev, int64_t capacity_rows) {
+  if (!b || !q || !t) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  if (layout != 0 && layout != 1) return fail(EA_ERR_INVALID_ARG, "layout: 0 = J row-major [rows][6], 1 = column-major [6][rows]");
+  int rc = batch_build(b);
+  if (rc != EA_OK) return rc;
+  if ((*r_dev == nullptr) != (*J_dev == nullptr)) return fail(EA_ERR_INVALID_ARG, "r_dev and J_dev: both or neither");
+  if (*r_dev) {
+    if (capacity_rows < b->total_rows) return fail(EA_ERR_INVALID_ARG, "capacity_rows is smaller than the batch's row count (ea_batch_row_offsets)");
+    if ((rc = check_device_pointer(b, *r_dev, "r_dev")) != EA_OK) return rc;
+    if ((rc = check_device_pointer(b, *J_dev, "J_dev")) != EA_OK) return rc;
+  } else {
+    if ((rc = rows_own_buffers(b)) != EA_OK) return rc;
+    *r_dev = b->d_rows_r; *J_dev = b->d_rows_J;
+  }
+  if (!b->d_rows_invalid) HIPCHK(hipMalloc(&b->d_rows_invalid, sizeof(unsigned int)));
+  return batch_upload_poses(b, q, t);
+}
+
+extern "C" int ea_batch_row_offsets(ea_batch *b, int64_t *offsets) {
+  if (!b || !offsets) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  int rc = batch_build(b);
+  if (rc != EA_OK) return rc;
+  for (size_t i = 0; i < b->row_offsets.size(); ++i) offsets[i] = b->row_offsets[i];
+  return EA_OK;
+}
+
+extern "C" int ea_batch_eval_rows_device(ea_batch *b, const double *q, const double *t, int corrected, int layout, void *r_dev,
+                                         void *J_dev, int64_t capacity_rows, int64_t *n_invalid) {
+  int rc = rows_prepare(b, q, t, layout, &r_dev, &J_dev, capacity_rows);
+  if (rc != EA_OK) return rc;
+  HIPCHK(hipMemsetAsync(b->d_rows_invalid, 0, sizeof(unsigned int), b->stream));
+  const int staged = b->t_rows_staged < 0 ? 1 : (b->t_rows_staged ? 1 : 0), nt = b->t_rows_nt < 0 ? 0 : (b->t_rows_nt ? 1 : 0);
+  if ((rc = rows_launch(b, corrected, layout, staged, nt, r_dev, J_dev)) != EA_OK) return rc;
+  unsigned int bad = 0;
+  HIPCHK(hipMemcpyAsync(&bad, b->d_rows_invalid, sizeof(bad), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));  // the rows are complete (and visible to any other stream) when this returns
+  if (n_invalid) *n_invalid = (int64_t)bad;
+  return EA_OK;
+}
+
+// the same into host arrays of the batch's dtype (library-owned device arrays + one copy each)
+extern "C" int ea_batch_eval_rows(ea_batch *b, const double *q, const double *t, int corrected, int layout, void *r_host,
+                                  void *J_host, int64_t capacity_rows, int64_t *n_invalid) {
+  if (!b) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  if (!r_host && !J_host) return fail(EA_ERR_INVALID_ARG, "r_host and J_host are both NULL");
+  int rc = batch_build(b);
+  if (rc != EA_OK) return rc;
+  if (capacity_rows < b->total_rows) return fail(EA_ERR_INVALID_ARG, "capacity_rows is smaller than the batch's row count (ea_batch_row_offsets)");
+  rc = ea_batch_eval_rows_device(b, q, t, corrected, layout, nullptr, nullptr, 0, n_invalid);
+  if (rc != EA_OK) return rc;
+  const size_t es = b->dtype == EA_F32 ? 4 : 8;
+  if (b->total_rows > 0) {
+    if (r_host) HIPCHK(hipMemcpy(r_host, b->d_rows_r, (size_t)b->total_rows * es, hipMemcpyDeviceToHost));
+    if (J_host) HIPCHK(hipMemcpy(J_host, b->d_rows_J, (size_t)b->total_rows * 6 * es, hipMemcpyDeviceToHost));
+  }
+  return EA_OK;
+}
+
+// `launches` of the materialised-mode kernel queued back to back between one event pair (the stream held on a host
+// function while they are enqueued), average execution window per launch.  mode: bit 0 = LDS-staged row-major stores,
+// bit 1 = non-temporal stores.  r_dev / J_dev NULL: the library's own arrays.
+extern "C" int ea_batch_bench_rows(ea_batch *b, const double *q, const double *t, int corrected, int layout, int mode, void *r_dev,
+                                   void *J_dev, int64_t capacity_rows, int warmup, int launches, double *ms_per_launch) {
+  if (!ms_per_launch || launches < 1 || warmup < 0) return fail(EA_ERR_INVALID_ARG, "bad argument");
+  int rc = rows_prepare(b, q, t, layout, &r_dev, &J_dev, capacity_rows);
+  if (rc != EA_OK) return rc;
+  HIPCHK(hipMemsetAsync(b->d_rows_invalid, 0, sizeof(unsigned int), b->stream));
+  EventPair evp;
+  HIPCHK(hipEventCreate(&evp.e0));
+  HIPCHK(hipEventCreate(&evp.e1));
+  const int staged = mode & 1, nt = (mode >> 1) & 1;
+  for (int i = 0; i < warmup; ++i) if ((rc = rows_launch(b, corrected, layout, staged, nt, r_dev, J_dev)) != EA_OK) return rc;
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipLaunchHostFunc(b->stream, [](void *) { std::this_thread::sleep_for(std::chrono::milliseconds(3)); }, nullptr));
+  HIPCHK(hipEventRecord(evp.e0, b->stream));
+  for (int i = 0; i < launches; ++i) if ((rc = rows_launch(b, corrected, layout, staged, nt, r_dev, J_dev)) != EA_OK) return rc;
+  HIPCHK(hipEventRecord(evp.e1, b->stream));
+  HIPCHK(hipEventSynchronize(evp.e1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, evp.e0, evp.e1));
+  *ms_per_launch = (double)ms / launches;
+  return EA_OK;
+}
+
 extern "C" int ea_batch_set_tuning(ea_batch *b, const char *key, int value) {
   if (!b || !key) return fail(EA_ERR_INVALID_ARG, "NULL argument");
   const std::string k(key);
@@ -1442,6 +1586,8 @@ extern "C" int ea_batch_set_tuning(ea_batch *b, const char *key, int value) {
   else if (k == "test_stall_ms") { b->t_test_stall_ms = value; return EA_OK; }
   else if (k == "test_fail_build") { b->t_test_fail_build = value; return EA_OK; }
   else if (k == "solve_streams") { b->t_streams = value; return EA_OK; }
+  else if (k == "rows_staged") { b->t_rows_staged = value; return EA_OK; }
+  else if (k == "rows_nontemporal") { b->t_rows_nt = value; return EA_OK; }
   else return fail(EA_ERR_INVALID_ARG, "unknown tuning key: " + k);
   b->built = false;
   return EA_OK;
@@ -1458,6 +1604,7 @@ extern "C" int ea_batch_get_info(const ea_batch *b, const char *key, int64_t *va
   else if (k == "threads") *value = b->nt;
   else if (k == "buffer_loads") *value = b->buffer_loads;
   else if (k == "num_points") { int64_t s = 0; for (auto *p : b->probs) s += p->n; *value = s; }
+  else if (k == "num_rows") *value = b->total_rows;
   else return fail(EA_ERR_INVALID_ARG, "unknown info key: " + k);
   return EA_OK;
 }

@@ -1102,6 +1102,153 @@ __global__ __launch_bounds__(kBlockThreads) void ea_eval_points_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Materialised mode (the "EAResidue batch Evaluate" view): residual and 1x6 row of EVERY point written out in
+// the problem's arithmetic type -- what N calls of AutoDiffCostFunction<EAResidue,1,4,3>::Evaluate followed by the
+// parameterisation's 4x3 plus-Jacobian produce (standalone/utils.h:48-92, standalone_edge_align.cpp:271-278), for a caller
+// that runs its own solver on the rows.  One point per lane, 256-lane workgroups, the chunk -> XCD mapping and the
+// raw-buffer stencil loads of the fused kernel, no reduction.  Unlike the fused mode this one IS bandwidth-bound:
+// 3 s bytes in and 7 s bytes out per point plus one pass over the DT image (s = sizeof(T)).
+//   LAYOUT 0: J row-major [rows][6] (what Ceres hands its linear solver); the 6 values of a lane are 24 / 48 contiguous
+//             bytes, so a wavefront's 64 rows go through an LDS transpose and leave as three stores of 64 x 8 / 16
+//             contiguous bytes (STAGED; the direct form -- three 8/16-byte stores per lane at a 24/48-byte stride -- is kept
+//             for comparison);
+//   LAYOUT 1: J column-major [6][total rows] (six coalesced stores, no staging).
+// Rows of a functor that returned false are NaN (and counted): Ceres fails the whole evaluation in that case.
+// `corrected`: rows scaled by sqrt(rho'(r^2)) (Ceres' Corrector with alpha = 0, as the fused mode accumulates them).
+template <typename T> struct PairOf;
+template <> struct PairOf<float> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct PairOf<double> { typedef double type __attribute__((ext_vector_type(2))); };
+template <typename T> using Pair = typename PairOf<T>::type;  // two consecutive elements: one 8- / 16-byte access
+
+template <typename T, bool VAR, bool BUF, int LAYOUT, bool STAGED>
+__global__ __launch_bounds__(kBlockThreads) void ea_eval_rows_kernel(
+    const ProblemDesc *__restrict__ probs, const PoseState *__restrict__ poses, int chunks_per_xcd, int corrected, int nontemporal,
+    long long total_rows, T *__restrict__ r_out, T *__restrict__ J_out, unsigned int *__restrict__ n_invalid) {
+  constexpr int NT = kBlockThreads;
+  const int bx = blockIdx.x;
+  const int c = (bx & 7) * chunks_per_xcd + (bx >> 3);
+  const ProblemDesc pd = probs[blockIdx.y];
+  const long long start = (long long)c * NT;
+  if (start >= pd.n) return;  // (uniform)
+  const PoseState *psp = poses + pd.group;
+  PoseLite<T> ps;
+  {
+    const T *R_ = Uni<T>::R(*psp), *t_ = Uni<T>::t(*psp);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) ps.R[i] = R_[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ps.t[i] = t_[i];
+    ps.unit_q = psp->unit_q;
+    ps.full = psp;
+  }
+  const int count = min(NT, (int)(pd.n - start));
+  const int tid = threadIdx.x;
+  const int j = min(tid, count - 1);  // lanes past the end re-read the chunk's last point and store nothing
+  const bool inb = tid < count;
+  T X, Y, Z;
+  if constexpr (BUF) {
+    const __amdgpu_buffer_rsrc_t rx = make_raw_buffer(static_cast<const T *>(pd.x) + start, (unsigned)count * (unsigned)sizeof(T));
+    const __amdgpu_buffer_rsrc_t ry = make_raw_buffer(static_cast<const T *>(pd.y) + start, (unsigned)count * (unsigned)sizeof(T));
+    const __amdgpu_buffer_rsrc_t rz = make_raw_buffer(static_cast<const T *>(pd.z) + start, (unsigned)count * (unsigned)sizeof(T));
+    const int poff = j * (int)sizeof(T);
+    X = buf_load_elem<T>(rx, poff); Y = buf_load_elem<T>(ry, poff); Z = buf_load_elem<T>(rz, poff);
+  } else {
+    X = static_cast<const T *>(pd.x)[start + j]; Y = static_cast<const T *>(pd.y)[start + j]; Z = static_cast<const T *>(pd.z)[start + j];
+  }
+  const int pitch = pd.pitch;
+  T f, Fu, Fv, J[6];
+  int state;
+  auto sample = [&](int iu, int iv, T fu, T fv) {
+    if constexpr (BUF) {
+      const __amdgpu_buffer_rsrc_t rimg = make_raw_buffer(pd.dt, (unsigned)pitch * (unsigned)(pd.H + 2 * kImagePad) * (unsigned)sizeof(T));
+      const int voff = ((iv + (kImagePad - 1)) * pitch + (iu + (kImagePad - 1))) * (int)sizeof(T);
+      bicubic<T>(fu, fv, [&](int l) { return buf_load_row4<T>(rimg, voff, l * pitch * (int)sizeof(T)); }, f, Fu, Fv);
+    } else {
+      const GPtr<T> base = (GPtr<T>)(static_cast<const T *>(pd.dt) + (size_t)kImagePad * (size_t)pitch + kImagePad) +
+                           ((ptrdiff_t)(iv - 1) * pitch + (iu - 1));
+      bicubic<T>(fu, fv, [&](int l) { return load_row4<T>(base + (ptrdiff_t)l * pitch); }, f, Fu, Fv);
+    }
+  };
+  if constexpr (VAR) {
+    ProjV<T> pv;
+    project_point_var<T>(pd, ps, X, Y, Z, pv);
+    state = pv.state;
+    sample(pv.iu, pv.iv, pv.fu, pv.fv);
+    jacobian_row_var<T>(pd, ps, pv, Fu, Fv, J);
+  } else {
+    Proj<T> pr;
+    project_point<T>(pd, ps, X, Y, Z, pr);
+    state = pr.state;
+    sample(pr.iu, pr.iv, pr.fu, pr.fv);
+    jacobian_row<T>(pd, ps, pr, X, Y, Z, Fu, Fv, J);
+  }
+  T sc = T(1);
+  if (corrected) {  // (uniform)
+    T rho, w;
+    loss_eval<T>(pd.loss_kind, Uni<T>::loss_a(pd), Uni<T>::loss_inv_b(pd), f * f, rho, w);
+    sc = t_sqrt<T>(w);
+  }
+  const bool bad = state == 2;
+  if (__any(bad)) {  // (uniform test first: the common wavefront has nothing to mark)
+    if (bad) {
+      sc = (T)__builtin_nan("");
+      f = T(1);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) J[a] = T(1);
+      if (inb) atomicAdd(n_invalid, 1u);
+    }
+  }
+  f *= sc;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) J[a] *= sc;
+  const long long row0 = pd.row_begin + start;  // first row of this workgroup
+  auto put = [&](T *p, T v) { if (nontemporal) __builtin_nontemporal_store(v, p); else *p = v; };
+  if (inb) put(r_out + row0 + tid, f);
+  if constexpr (LAYOUT == 1) {
+    if (inb) {
+#pragma unroll
+      for (int a = 0; a < 6; ++a) put(J_out + (long long)a * total_rows + row0 + tid, J[a]);
+    }
+  } else if constexpr (!STAGED) {
+    if (inb) {
+      Pair<T> *dst = reinterpret_cast<Pair<T> *>(J_out + (row0 + tid) * 6);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        Pair<T> v;
+        v.x = J[2 * k]; v.y = J[2 * k + 1];
+        if (nontemporal) __builtin_nontemporal_store(v, dst + k); else dst[k] = v;
+      }
+    }
+  } else {
+    // wavefront-local transpose: lane l writes its 6 values at [6 l .. 6 l + 5] of the wavefront's 384-element strip, then
+    // reads elements (2 l, 2 l + 1) + 128 k, k = 0..2, and stores them: each store instruction of the wavefront covers
+    // 64 x 2 consecutive elements.  LDS operations of one wavefront complete in order; nothing else touches the strip.
+    __shared__ __align__(16) T s_rows[(NT / 64) * 384];
+    const int lane = tid & 63, wave = tid >> 6;
+    T *strip = s_rows + wave * 384;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      Pair<T> v;
+      v.x = J[2 * k]; v.y = J[2 * k + 1];
+      *reinterpret_cast<Pair<T> *>(strip + 6 * lane + 2 * k) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int valid = 6 * max(0, min(64, count - 64 * wave));  // elements of the strip that belong to real points
+    T *dst = J_out + (row0 + 64 * wave) * 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int e = 2 * lane + 128 * k;
+      const Pair<T> v = *reinterpret_cast<const Pair<T> *>(strip + e);
+      if (e < valid) {
+        if (nontemporal) __builtin_nontemporal_store(v, reinterpret_cast<Pair<T> *>(dst + e)); else *reinterpret_cast<Pair<T> *>(dst + e) = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The reference's own quantitative self-check (standalone_edge_align.cpp:2494-2567 before the solve, :2704-2776 after):
 // every point warped by the pose, divided by its depth, pushed through K, truncated `(int)` to a pixel, the distance
 // transform read at that pixel; total, maximum and where the maximum sits.  One partial per workgroup
@@ -1536,6 +1683,35 @@ hipError_t launch_eval_points(int dtype, const ProblemDesc *probs, int problem, 
   else
     hipLaunchKernelGGL((ea_eval_points_kernel<double>), dim3(grid), dim3(kBlockThreads), 0, stream, probs, problem,
                        poses, r_out, J_out, corrected);
+  return hipGetLastError();
+}
+
+// materialised mode: rows of every term of the batch into the caller's device arrays (ea_eval_rows_kernel)
+hipError_t launch_eval_rows(int dtype, int variant, int buffer_loads, int layout, int staged, const ProblemDesc *probs, int nterms,
+                            long long max_n, const PoseState *poses, int corrected, int nontemporal, long long total_rows,
+                            void *r_out, void *J_out, unsigned int *n_invalid, hipStream_t stream) {
+  if (nterms <= 0 || max_n <= 0) return hipSuccess;
+  const int chunks = (int)((max_n + kBlockThreads - 1) / kBlockThreads);
+  const int chunks_per_xcd = (chunks + 7) / 8;
+  const dim3 grid(chunks_per_xcd * 8, nterms);
+#define EA_ROWS(T, V, B, L, S)                                                                                              \
+  hipLaunchKernelGGL((ea_eval_rows_kernel<T, V, B, L, S>), grid, dim3(kBlockThreads), 0, stream, probs, poses, chunks_per_xcd, \
+                     corrected, nontemporal, total_rows, static_cast<T *>(r_out), static_cast<T *>(J_out), n_invalid)
+#define EA_ROWS_L(T, V, B)                                                                    \
+  do {                                                                                        \
+    if (layout == 1) EA_ROWS(T, V, B, 1, false);                                              \
+    else if (staged) EA_ROWS(T, V, B, 0, true);                                               \
+    else EA_ROWS(T, V, B, 0, false);                                                          \
+  } while (0)
+  if (variant) {  // distortion / second-camera terms: flat addressing
+    if (dtype == 1) EA_ROWS_L(float, true, false); else EA_ROWS_L(double, true, false);
+  } else if (buffer_loads) {
+    if (dtype == 1) EA_ROWS_L(float, false, true); else EA_ROWS_L(double, false, true);
+  } else {
+    if (dtype == 1) EA_ROWS_L(float, false, false); else EA_ROWS_L(double, false, false);
+  }
+#undef EA_ROWS_L
+#undef EA_ROWS
   return hipGetLastError();
 }
 

@@ -46,7 +46,8 @@ struct ProblemDesc {
   int32_t group;                 // which pose / LM state this residual family belongs to
   // residual variants of standalone/utils.h:102-421 (variant != 0 selects the variant kernel)
   int32_t variant;               // bit 0: Brown-Conrady distortion, bit 1: second camera of a rigid rig
-  int32_t pad_[3];
+  int64_t row_begin;             // this term's first row in the batch's materialised outputs (ea_batch_eval_rows_device)
+  int32_t pad_[2];
   double dist[5];                // k1, k2, p1, p2, k3
   double A[9], d[3];             // second camera: b = A (R a' + t) + d,  [A d] = affine part of T12
   double Ai[9], di[3];           //                a' = Ai a + di,        [Ai di] = affine part of T12^-1
@@ -71,6 +72,8 @@ struct PoseState {
   int32_t active;    // 0: the problem's workgroups return immediately (solve finished)
   int32_t pad_[2];
 };
+
+static_assert(sizeof(ProblemDesc) % 8 == 0, "ProblemDesc is fetched as whole scalar dwords");
 
 // Result of one reduced evaluation
 struct EvalOut {

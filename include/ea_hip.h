@@ -259,6 +259,25 @@ int ea_batch_eval(ea_batch *b, const double *q, const double *t, double *cost, d
 int ea_batch_solve(ea_batch *b, const ea_options *opt, double *q, double *t,
                    ea_summary *summaries);
 
+/* ---- materialised mode: the "EAResidue batch Evaluate" view -------------------------------------------------------
+ * Replaces N calls of ceres::AutoDiffCostFunction<EAResidue,1,4,3>::Evaluate followed by the parameterisation's 4x3
+ * plus-Jacobian (standalone/utils.h:48-92, standalone_edge_align.cpp:261-278): residual r and the effective 1x6 row
+ * [d r / d delta | d r / d t] of EVERY point, written in the batch's dtype (float / double) -- for a caller that runs its
+ * own solver on the rows.  Rows of problem i are [offsets[i], offsets[i+1]) (terms of a problem adjacent, points in
+ * their storage order: ea_problem_get_points).  layout 0: J row-major [rows][6]; 1: column-major [6][rows].
+ * corrected != 0: rows scaled by sqrt(rho'(r^2)) (Ceres' Corrector, alpha = 0).  A functor that returns false
+ * (utils.h:70-73) leaves a NaN row and is counted in *n_invalid (Ceres fails the whole evaluation then).
+ * This mode is bandwidth-bound: 3 s bytes in, 7 s bytes out per point plus one pass over the DT image. */
+int ea_batch_row_offsets(ea_batch *b, int64_t *offsets /* count + 1 */);
+/* into DEVICE memory of the batch's GPU owned by the caller (e.g. the storage of a torch tensor), 16-byte aligned,
+ * capacity_rows >= offsets[count]; complete and visible when the call returns (the batch's stream is synchronised).
+ * r_dev == J_dev == NULL: into the library's own arrays (then read them with ea_batch_eval_rows). */
+int ea_batch_eval_rows_device(ea_batch *b, const double *q, const double *t, int corrected, int layout, void *r_dev,
+                              void *J_dev, int64_t capacity_rows, int64_t *n_invalid);
+/* the same into host arrays of the batch's dtype holding capacity_rows >= offsets[count] rows (either may be NULL) */
+int ea_batch_eval_rows(ea_batch *b, const double *q, const double *t, int corrected, int layout, void *r_host,
+                       void *J_host, int64_t capacity_rows, int64_t *n_invalid);
+
 /* ---- measurement hooks (used by bench.py; timing is done with HIP events on the stream the
  * kernels are launched on) ------------------------------------------------------------- */
 /* Upload the poses once, run `warmup` untimed then `steps` timed fused evaluations
@@ -292,10 +311,14 @@ int ea_batch_bench_result_riding(ea_batch *b, double *cost, double *JtJ, double 
  * launch (dispatch of the next launch overlaps the running one) -- the figure rocprofv3 --kernel-trace reports. */
 int ea_batch_bench_kernel(ea_batch *b, const double *q, const double *t, int warmup, int launches,
                           double *ms_per_launch);
+/* the same for the materialised-mode kernel; mode bit 0: LDS-staged row-major stores, bit 1: non-temporal stores;
+ * r_dev / J_dev NULL: the library's own arrays */
+int ea_batch_bench_rows(ea_batch *b, const double *q, const double *t, int corrected, int layout, int mode, void *r_dev,
+                        void *J_dev, int64_t capacity_rows, int warmup, int launches, double *ms_per_launch);
 /* the same for the fold kernel of ea_batch_eval, over the partial rows the last evaluation left */
 int ea_batch_bench_fold(ea_batch *b, int warmup, int launches, double *ms_per_launch);
 /* tuning knobs: key in {"lds_bytes", "points_per_thread", "use_lds", "xcd_remap", "threads", "buffer_loads",
- * "solve_streams"};
+ * "solve_streams", "rows_staged", "rows_nontemporal"};
  * value < 0 restores the default */
 int ea_batch_set_tuning(ea_batch *b, const char *key, int value);
 int ea_batch_get_info(const ea_batch *b, const char *key, int64_t *value);
