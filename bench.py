@@ -298,6 +298,22 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_launch,
                 "secondary": valu_issue(args.workload, ms_kernel_b2b)}
 
+    # Materialised mode of the same workload ("report both numbers"): r and the 1x6 row of every point written
+    # out in the batch's dtype (ea_batch_eval_rows_device), the bandwidth-bound form of the path: 3 s in + 7 s out per
+    # point + one pass over the DT image.  Back-to-back launches between one event pair on the library's stream.
+    def materialised(Bx, Q, T, n_points, images, es, launches=100):
+        msr = min(Bx.bench_rows(Q, T, 5, launches, corrected=True, layout=0, mode=1) for _ in range(2))
+        by = 10 * es * n_points + sum(h * w * es for h, w in images)
+        return {"kernel": "ea_eval_rows_kernel<%s>" % ("double" if es == 8 else "float"), "kernel_ms": msr,
+                "evals_per_s": n_points / (msr * 1e-3), "algorithmic_bytes_per_launch": by, "achieved": by / (msr * 1e-3) / 1e9,
+                "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": by / (msr * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "layout": "r [rows], J row-major [rows][6] through a wavefront-local LDS transpose, corrected rows"}
+    try:
+        mat = materialised(B, q0, t0, n_pts, [(H, W)], esize)
+    except capi.EAError as e:
+        mat = {"error": str(e)}
+    B.bench_eval(q0, t0, 0, 1, kernel_pass=False)
+
     # The line's mandatory part is complete here.  Everything below is secondary; a watchdog prints the line without the
     # unfinished measurements if they take longer than --extras-timeout (a collective meeting a real node for the first
     # time must not cost the scaling record) and ends the process; every rank runs one.
@@ -312,7 +328,7 @@ def main():
                            "tiles": B.info("num_tiles"), "points_per_thread": B.info("points_per_thread"),
                            "lds_bytes": B.info("lds_bytes"), "point_order_tile_px": P.point_order,
                            "timed_region": graph or "eager launches"},
-                "roofline": roofline}
+                "roofline": roofline, "materialised_mode": mat}
     extras, others, leg = {}, {}, ["start"]
 
     def compose(note=None):
@@ -506,6 +522,11 @@ def main():
                         res["traffic_frac_of_measured_stream_copy_6290GBps"] = tb / (msk * 1e-3) / 1e9 / 6290.0
                 except Exception:
                     pass
+            try:
+                mm = materialised(Bx, Q, T, npts, [cfgx["image"].shape for cfgx in problems], esz, launches=50)
+                res["materialised_mode"] = {k: mm[k] for k in ("kernel_ms", "evals_per_s", "achieved", "frac", "algorithmic_bytes_per_launch")}
+            except capi.EAError as e:
+                res["materialised_mode"] = {"error": str(e)}
             if m > 1 and tile is None:  # the production shape of BASELINE config C4: all frame pairs of a GPU solved by one launch sequence
                 Bx.solve(Q, T)
                 tsv = time.perf_counter()

@@ -137,6 +137,14 @@ class QuaternionParameterization : public LocalParameterization {
 };
 
 // ---- problem --------------------------------------------------------------------------------
+// ceres/crs_matrix.h: compressed-row sparse matrix as Problem::Evaluate hands it out
+struct CRSMatrix {
+  CRSMatrix() : num_rows(0), num_cols(0) {}
+  int num_rows, num_cols;
+  std::vector<int> cols, rows;
+  std::vector<double> values;
+};
+
 class Problem {
  public:
   Problem() {}
@@ -171,14 +179,16 @@ class Problem {
 
   // src/SolveEA.cpp:241  problem.Evaluate(Problem::EvaluateOptions(), &cost, &residuals, NULL, NULL)
   // cost = 1/2 sum rho(r^2); residuals: one per block in the order they were added, loss-corrected like Ceres'
-  // apply_loss_function = true; gradient: the 6 tangent-space entries (J^T r).  The sparse Jacobian is not offered.
+  // apply_loss_function = true; gradient: the 6 tangent-space entries (J^T r); jacobian: one row per block in the same
+  // order, six columns [d r / d delta (3) | d r / d t (3)] -- the parameter blocks' local sizes in the order
+  // AddResidualBlock names them (quaternion, translation) -- as a compressed-row matrix with dense rows.
   struct EvaluateOptions {
     bool apply_loss_function = true;
     int ea_dtype = EA_F64;
     int ea_device = 0;
   };
   inline bool Evaluate(const EvaluateOptions &opt, double *cost, std::vector<double> *residuals,
-                       std::vector<double> *gradient, void *jacobian);
+                       std::vector<double> *gradient, CRSMatrix *jacobian);
 
  private:
   struct Block {
@@ -336,9 +346,19 @@ class ProblemAccess {  // keeps Problem's internals private to user code
   }
 
   static bool Evaluate(Problem *problem, const Problem::EvaluateOptions &opt, double *cost, std::vector<double> *residuals,
-                       std::vector<double> *gradient, void *jacobian) {
-    if (jacobian) return false;  // the N x 6 Jacobian is never materialised on this path
+                       std::vector<double> *gradient, CRSMatrix *jacobian) {
     const auto &blocks = problem->blocks_;
+    if (jacobian) {
+      jacobian->num_rows = (int)blocks.size();
+      jacobian->num_cols = blocks.empty() ? 0 : 6;
+      jacobian->rows.assign(blocks.size() + 1, 0);
+      jacobian->cols.assign(blocks.size() * 6, 0);
+      jacobian->values.assign(blocks.size() * 6, 0.0);
+      for (size_t i = 0; i < blocks.size(); ++i) {
+        jacobian->rows[i + 1] = (int)(6 * (i + 1));
+        for (int a = 0; a < 6; ++a) jacobian->cols[6 * i + a] = a;
+      }
+    }
     if (blocks.empty()) {
       if (cost) *cost = 0.0;
       if (residuals) residuals->clear();
@@ -353,13 +373,17 @@ class ProblemAccess {  // keeps Problem's internals private to user code
     double c = 0.0, JtJ[36], Jtr[6];
     int64_t bad = 0;
     if (rc == EA_OK) rc = ea_eval(ps[0], q, t, &c, JtJ, Jtr, &bad);  // the problem with all its terms
-    if (rc == EA_OK && residuals) {
-      residuals->assign(blocks.size(), 0.0);
+    if (rc == EA_OK && (residuals || jacobian)) {
+      if (residuals) residuals->assign(blocks.size(), 0.0);
       for (size_t k = 0; k < ps.size() && rc == EA_OK; ++k) {
-        std::vector<double> r(order[k].size());
-        // a term evaluated on its own: its residuals in the order its blocks were added
-        rc = ea_eval_points(ps[k], q, t, r.data(), nullptr, opt.apply_loss_function ? 1 : 0);
-        for (size_t i = 0; i < r.size(); ++i) (*residuals)[order[k][i]] = r[i];
+        std::vector<double> r(order[k].size()), J(jacobian ? order[k].size() * 6 : 0);
+        // a term evaluated on its own: its residuals (and 1x6 rows) in the order its blocks were added
+        rc = ea_eval_points(ps[k], q, t, r.data(), jacobian ? J.data() : nullptr, opt.apply_loss_function ? 1 : 0);
+        for (size_t i = 0; i < r.size(); ++i) {
+          if (residuals) (*residuals)[order[k][i]] = r[i];
+          if (jacobian)
+            for (int a = 0; a < 6; ++a) jacobian->values[6 * (size_t)order[k][i] + a] = J[6 * i + a];
+        }
       }
     }
     for (auto *p : ps)
@@ -434,7 +458,7 @@ class ProblemAccess {  // keeps Problem's internals private to user code
 };
 
 inline bool Problem::Evaluate(const EvaluateOptions &opt, double *cost, std::vector<double> *residuals,
-                              std::vector<double> *gradient, void *jacobian) {
+                              std::vector<double> *gradient, CRSMatrix *jacobian) {
   return ProblemAccess::Evaluate(this, opt, cost, residuals, gradient, jacobian);
 }
 

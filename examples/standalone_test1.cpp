@@ -6,7 +6,9 @@
 //   int32 N, int32 rows(H), int32 cols(W), double fx,fy,cx,cy, double a_X[4*N] (column-major 4xN),
 //   double e_disTrans[H*W] (column-major H x W, as cv::cv2eigen fills an Eigen::MatrixXd)
 // Output: one line "q0 q1 q2 q3 t0 t1 t2 iterations termination initial_cost final_cost".
+#include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <iostream>
@@ -56,6 +58,19 @@ int main(int argc, char **argv) {
   const bool eval_ok = problem.Evaluate(ceres::Problem::EvaluateOptions(), &cost0, &all_residues, &grad0, NULL);
   double r2 = 0.0;
   for (double r : all_residues) r2 += r * r;
+  // the same call with the Jacobian handed out (ceres::CRSMatrix, one dense 1x6 row per block): J^T r must be the gradient
+  ceres::CRSMatrix jac0;
+  std::vector<double> res_again;
+  const bool jac_ok = problem.Evaluate(ceres::Problem::EvaluateOptions(), NULL, &res_again, NULL, &jac0);
+  double jtr_err = 0.0, gmax = 0.0;
+  if (jac_ok && jac0.num_rows == (int)res_again.size() && jac0.num_cols == 6 && grad0.size() == 6) {
+    double g[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < jac0.num_rows; ++i)
+      for (int k = jac0.rows[i]; k < jac0.rows[i + 1]; ++k) g[jac0.cols[k]] += jac0.values[k] * res_again[i];
+    for (int a = 0; a < 6; ++a) { jtr_err = std::max(jtr_err, std::fabs(g[a] - grad0[a])); gmax = std::max(gmax, std::fabs(grad0[a])); }
+  } else {
+    jtr_err = 1e300;
+  }
   std::cerr << "Evaluate: ok " << eval_ok << " cost " << cost0 << " residuals " << all_residues.size() << " NumParameterBlocks "
             << problem.NumParameterBlocks() << " NumParameters " << problem.NumParameters() << " NumResidualBlocks "
             << problem.NumResidualBlocks() << "\n";
@@ -73,9 +88,9 @@ int main(int argc, char **argv) {
   std::cerr << summary.FullReport() << "\n";
   // ---- end of reference text --------------------------------------------------------------------
 
-  std::printf("%.17g %.17g %.17g %.17g %.17g %.17g %.17g %d %d %.17g %.17g %d %.17g %d %.17g %d\n", b_quat_a[0], b_quat_a[1],
+  std::printf("%.17g %.17g %.17g %.17g %.17g %.17g %.17g %d %d %.17g %.17g %d %.17g %d %.17g %d %d %.17g\n", b_quat_a[0], b_quat_a[1],
               b_quat_a[2], b_quat_a[3], b_t_a[0], b_t_a[1], b_t_a[2], summary.num_successful_steps + summary.num_unsuccessful_steps,
               (int)summary.termination_type, summary.initial_cost, summary.final_cost, (int)eval_ok, cost0,
-              (int)all_residues.size(), 0.5 * r2, (int)grad0.size());
+              (int)all_residues.size(), 0.5 * r2, (int)grad0.size(), jac0.num_rows, gmax > 0 ? jtr_err / gmax : jtr_err);
   return summary.termination_type == ceres::FAILURE ? 1 : 0;
 }

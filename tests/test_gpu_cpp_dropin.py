@@ -52,6 +52,8 @@ def test_edge_align_test1_call_sequence(binaries, bundled_pair, golden, tmp_path
         assert int(v[11]) == 1 and v[12] == pytest.approx(v[9], rel=1e-12)
         assert int(v[13]) == -(-bundled_pair["aX"].shape[1] // stride) and int(v[15]) == 6
         assert 0.0 < v[14] <= v[12] * (1 + 1e-12)
+        # Evaluate with the Jacobian handed out (ceres::CRSMatrix, dense 1x6 rows): one row per block, J^T r = gradient
+        assert int(v[16]) == int(v[13]) and v[17] < 1e-10
 
 
 def test_solve_ea_class_dogleg(binaries, oracle, bundled_pair, tmp_path):
