@@ -236,6 +236,7 @@ class Problem:
         cam = Camera(fx, fy, cx, cy)
         _check(load().ea_problem_create(C.byref(self._h), C.byref(cam), dtype, device))
         self.dtype = dtype
+        self.device = device
         self._keep = []
 
     def close(self):
@@ -621,9 +622,29 @@ class Batch:
                                          J.ctypes.data_as(C.c_void_p), n, C.byref(bad)))
         return r, J, bad.value
 
-    def eval_rows_device(self, q, t, r_ptr, J_ptr, capacity_rows, corrected=True, layout=0):
-        """materialised mode into the caller's device arrays (raw pointers, e.g. torch tensor .data_ptr()); returns n_invalid"""
+    def eval_rows_device(self, q, t, r_ptr, J_ptr, capacity_rows=None, corrected=True, layout=0):
+        """materialised mode into the caller's device arrays; returns n_invalid.  r_ptr / J_ptr: torch tensors on the batch's
+        GPU (checked here: device, dtype, contiguity, size) or raw device addresses (then capacity_rows is required and
+        the addresses are taken on trust)"""
         q, t = _f64(q).reshape(-1, 4), _f64(t).reshape(-1, 3)
+        if hasattr(r_ptr, "data_ptr") or hasattr(J_ptr, "data_ptr"):
+            import torch
+            want = torch.float32 if self.dtype == EA_F32 else torch.float64
+            rows = None
+            for name, x, per_row in (("r", r_ptr, 1), ("J", J_ptr, 6)):
+                if not hasattr(x, "data_ptr"):
+                    raise TypeError("%s: pass torch tensors for both outputs or raw addresses for both" % name)
+                if not x.is_cuda or x.dtype != want or not x.is_contiguous():
+                    raise ValueError("%s must be a contiguous %s tensor on the batch's GPU" % (name, want))
+                if x.device.index is not None and x.device.index != self.problems[0].device:
+                    raise ValueError("%s lives on cuda:%d, the batch on device %d" % (name, x.device.index, self.problems[0].device))
+                n = x.numel() // per_row
+                rows = n if rows is None else min(rows, n)
+            capacity_rows = rows if capacity_rows is None else min(int(capacity_rows), rows)
+            torch.cuda.current_stream(r_ptr.device).synchronize()   # the tensors' producers are done before the library writes
+            r_ptr, J_ptr = r_ptr.data_ptr(), J_ptr.data_ptr()
+        if capacity_rows is None:
+            raise ValueError("capacity_rows is required with raw addresses")
         bad = C.c_int64()
         _check(load().ea_batch_eval_rows_device(self._h, _dp(q), _dp(t), int(corrected), int(layout), C.c_void_p(r_ptr),
                                                 C.c_void_p(J_ptr), int(capacity_rows), C.byref(bad)))

@@ -1120,8 +1120,12 @@ template <> struct PairOf<float> { typedef float type __attribute__((ext_vector_
 template <> struct PairOf<double> { typedef double type __attribute__((ext_vector_type(2))); };
 template <typename T> using Pair = typename PairOf<T>::type;  // two consecutive elements: one 8- / 16-byte access
 
+#ifndef EA_ROWS_WAVES_F64
+#define EA_ROWS_WAVES_F64 4  // (fp64 occupancy target of the rows kernel, wavefronts per SIMD: A/B knob, scripts/ab_rows.sh)
+#endif
 template <typename T, bool VAR, bool BUF, int LAYOUT, bool STAGED>
-__global__ __launch_bounds__(kBlockThreads) void ea_eval_rows_kernel(
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 ? EA_ROWS_WAVES_F64 : 8, 8)))
+void ea_eval_rows_kernel(
     const ProblemDesc *__restrict__ probs, const PoseState *__restrict__ poses, int chunks_per_xcd, int corrected, int nontemporal,
     long long total_rows, T *__restrict__ r_out, T *__restrict__ J_out, unsigned int *__restrict__ n_invalid) {
   constexpr int NT = kBlockThreads;

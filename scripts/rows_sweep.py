@@ -38,6 +38,14 @@ def run(name, cfgs, dtype, tile=None, loss=(capi.LOSS_CAUCHY, 1.0)):
         P.close()
 
 
+f64only = len(sys.argv) > 1 and sys.argv[1] == "f64only"
+if f64only:
+    batch = [synth.config_c2_twin(seed=100 + i) for i in range(32)]
+    run("c2", [synth.config_c2_twin(seed=2, n_points=50000)], capi.EA_F64)
+    run("batch32 raster", batch, capi.EA_F64)
+    run("batch32 tile16", batch, capi.EA_F64, tile=16)
+    run("c5 fp64", [synth.config_c5()], capi.EA_F64, loss=(capi.LOSS_TRIVIAL, 1.0))
+    sys.exit(0)
 run("c5", [synth.config_c5()], capi.EA_F32, loss=(capi.LOSS_TRIVIAL, 1.0))
 run("c2", [synth.config_c2_twin(seed=2, n_points=50000)], capi.EA_F64)
 batch = [synth.config_c2_twin(seed=100 + i) for i in range(32)]

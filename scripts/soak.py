@@ -1,6 +1,6 @@
 """Randomised soak of the HIP path against the CPU oracle (test infrastructure): random image sizes, point counts (empty
 included), losses, dtypes, poses (unit and non-unit quaternions), batches of 1-6 problems, every launch shape the
-heuristics or the tuning keys can select; every few cases a full solve.  usage: python scripts/soak.py [seconds] [seed]"""
+heuristics or the tuning keys can select; every few cases a full solve, the materialised rows against the fused sums, a pipelined sequence (riding fold).  usage: python scripts/soak.py [seconds] [seed]"""
 import os, sys, time, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from edge_alignment_amd import capi, synth
@@ -9,7 +9,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
 rng = np.random.default_rng(seed)
 t_end = time.time() + budget
-cases = solves = 0
+cases = solves = rows_checked = pipelines = 0
 worst = {"f64": 0.0, "f32": 0.0, "pose_f64": 0.0, "pose_f32": 0.0}
 while time.time() < t_end:
     m = int(rng.integers(1, 7))
@@ -62,6 +62,37 @@ while time.time() < t_end:
         assert rel <= lim, (cases, i, tag, rel, Xs[i].shape, loss)
         if slack == 1.0:
             worst[tag] = max(worst[tag], rel)
+    # materialised mode: the rows of every point, in a random layout / store form, must sum to the fused mode's system
+    # (any size, any launch shape), and their residuals must be the oracle's
+    if cases % 2 == 0:
+        layout = int(rng.integers(0, 2))
+        B.set_tuning("rows_staged", int(rng.integers(0, 2))); B.set_tuning("rows_nontemporal", int(rng.integers(0, 2)))
+        r, J, bad = B.eval_rows(Q, T, corrected=True, layout=layout)
+        Jr = (J if layout == 0 else J.T).astype(np.float64)
+        off = B.row_offsets()
+        assert bad == int(g["n_invalid"].sum()), (cases, "rows: invalid count")
+        for i in range(m):
+            n = Xs[i].shape[0]
+            assert off[i + 1] - off[i] == n, (cases, i)
+            if n == 0 or g["n_invalid"][i] or (dtype == capi.EA_F32 and n < 64):
+                continue
+            ri, Ji = r[off[i]:off[i + 1]].astype(np.float64), Jr[off[i]:off[i + 1]]
+            scale = max(np.abs(g["JtJ"][i]).max(), 1e-9)
+            lim = (1e-10 if dtype == capi.EA_F64 else 2e-4) * (100.0 if n <= 2 else (5.0 if (dtype == capi.EA_F32 and n < 1000) else 1.0))
+            assert np.abs(Ji.T @ Ji - g["JtJ"][i]).max() <= lim * scale, (cases, i, tag, "rows: JtJ", n)
+            rows_checked += 1
+    # the riding fold: a pipelined sequence of 2..5 steps ends on ea_batch_eval's sums (1e-13: another summation order),
+    # riding and closing folds agree bit for bit
+    if cases % 3 == 0 and B.info("lds_bytes") == 0:
+        k = int(rng.integers(2, 6))
+        B.bench_capture_pipelined(k)
+        B.bench_steps(k)
+        last, riding = B.bench_result(), B.bench_result(riding=True)
+        for key in ("cost", "JtJ", "Jtr"):
+            assert np.array_equal(last[key], riding[key]), (cases, "riding != closing", key)
+            assert np.abs(last[key] - g[key]).max() <= 1e-12 * max(np.abs(g[key]).max(), 1e-300), (cases, "riding fold vs eval", key)
+        assert np.array_equal(last["n_invalid"], g["n_invalid"]), (cases, "riding fold: invalid count")
+        pipelines += 1
     if cases % 5 == 0:
         i = int(rng.integers(m))
         if Xs[i].shape[0] >= 500:
@@ -85,5 +116,5 @@ while time.time() < t_end:
     for P in Ps:
         P.close()
     cases += 1
-print("soak ok: %d batches, %d solves, seed %d; worst relative sum error f64 %.2e f32 %.2e; worst pose difference f64 %.2e rad f32 %.2e rad" % (
-    cases, solves, seed, worst["f64"], worst["f32"], worst["pose_f64"], worst["pose_f32"]))
+print("soak ok: %d batches, %d solves, %d row sets, %d pipelined sequences, seed %d; worst relative sum error f64 %.2e f32 %.2e; worst pose difference f64 %.2e rad f32 %.2e rad" % (
+    cases, solves, rows_checked, pipelines, seed, worst["f64"], worst["f32"], worst["pose_f64"], worst["pose_f32"]))

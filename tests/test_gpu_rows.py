@@ -104,6 +104,18 @@ def test_rows_into_caller_owned_device_memory(hip):
         torch.cuda.synchronize()
         bad = B.eval_rows_device(Q, T, r.data_ptr(), J.data_ptr(), n + 8, corrected=True, layout=0)
         assert bad == 0
+        # the wrapper also takes the tensors themselves and checks them (device, dtype, contiguity, size)
+        r2, J2 = torch.zeros(n, dtype=torch.float32, device="cuda"), torch.zeros((n, 6), dtype=torch.float32, device="cuda")
+        assert B.eval_rows_device(Q, T, r2, J2) == 0
+        assert torch.equal(r2, r[:n]) and torch.equal(J2, J[:n])
+        with pytest.raises(ValueError):
+            B.eval_rows_device(Q, T, r2.double(), J2)            # wrong dtype
+        with pytest.raises(ValueError):
+            B.eval_rows_device(Q, T, r2.cpu(), J2)               # host tensor
+        with pytest.raises(ValueError):
+            B.eval_rows_device(Q, T, r2, J2.t())                 # not contiguous
+        with pytest.raises(hip.EAError):
+            B.eval_rows_device(Q, T, r2[: n - 3], J2)            # too few rows: the library refuses
         assert np.array_equal(r[:n].cpu().numpy(), want_r) and np.array_equal(J[:n].cpu().numpy(), want_J)
         assert float(r[n:].min()) == 7.0 and float(J[n:].min()) == 7.0   # nothing written past the rows
         # argument checks: capacity, alignment, a host pointer
