@@ -151,3 +151,43 @@ def test_failed_functor_rows_are_nan_and_counted(hip):
                 assert np.isfinite(Jr[ok]).all() and np.isfinite(r[ok]).all()
         finally:
             B.close(); P.close()
+
+
+def test_rows_of_variant_functors_and_shared_pose_terms(hip, oracle):
+    """EAResidueEx / EAResidueSecondCam[Ex] rows (standalone/utils.h:102-421) and a stereo problem whose two residual
+    families share one pose: rows of the terms adjacent, each against the oracle's Jet<7> restatement of its functor."""
+    K1, K2 = (130.0, 132.0, 79.5, 59.5), (128.0, 129.0, 81.0, 58.0)
+    DIST = (0.2624, -0.9531, -0.0054, 0.0026, 1.1633)
+    T12 = synth.rigid_4x4(synth.quat_from_axis_angle([0.1, 1.0, 0.2], 0.04), [0.11, 0.004, -0.012])
+    Qp = synth.quat_from_axis_angle([1, 2, 3], np.deg2rad(1.0)); Tp = np.array([0.01, -0.005, 0.02])
+    fams = synth.make_stereo_problem(120, 160, 4000, 2500, 6, K1, K2, T12, Qp, Tp, distortion=DIST)
+    O1 = oracle.OracleProblem(fams[0]["grid"], *K1, distortion=DIST)
+    O2 = oracle.OracleProblem(fams[1]["grid"], *K2, distortion=DIST, T12=T12)
+    q = synth.quat_mul(synth.quat_from_axis_angle([0.2, -1, 0.4], 0.004), Qp); t = Tp + 0.002
+    e1 = O1.eval(fams[0]["xyz"], q, t, oracle.JAC_JET, materialize=True)
+    e2 = O2.eval(fams[1]["xyz"], q, t, oracle.JAC_JET, materialize=True)
+    for dtype, tol_r, tol_J in ((hip.EA_F64, 1e-12, 1e-11), (hip.EA_F32, 5e-5, 5e-4)):
+        def mk(fam, K, t12):
+            P = hip.Problem(*K, dtype=dtype)
+            P.set_points(fam["xyz"]); P.set_dt_grid(fam["grid"]); P.set_loss(1, 1.0); P.set_distortion(*DIST)
+            if t12 is not None:
+                P.set_second_camera(t12)
+            return P
+        P1, P2 = mk(fams[0], K1, None), mk(fams[1], K2, T12)
+        P1.add_term(P2)
+        B = hip.Batch([P1])
+        try:
+            off = B.row_offsets()
+            assert list(off) == [0, 6500]
+            for layout in (0, 1):
+                r, J, bad = B.eval_rows(q, t, corrected=True, layout=layout)
+                Jr = J if layout == 0 else J.T
+                assert bad == 0
+                assert np.abs(r[:4000] - e1["r"]).max() < tol_r and np.abs(r[4000:] - e2["r"]).max() < tol_r
+                assert _rel(Jr[:4000], e1["J"]) < tol_J and _rel(Jr[4000:], e2["J"]) < tol_J
+            g = B.eval(q, t)
+            Jd, rd = Jr.astype(np.float64), r.astype(np.float64)
+            assert _rel(Jd.T @ Jd, g["JtJ"][0]) < (1e-11 if dtype == hip.EA_F64 else 1e-4)
+            assert _rel(Jd.T @ rd, g["Jtr"][0]) < (1e-11 if dtype == hip.EA_F64 else 1e-4)
+        finally:
+            B.close(); P1.close(); P2.close()
