@@ -1797,6 +1797,7 @@ extern "C" int ea_solve_sharded(ea_problem *p, const ea_options *opt_in, ea_allr
 extern "C" int ea_solve_sharded_device(ea_problem *p, const ea_options *opt_in, ea_device_allreduce_fn allreduce, void *user,
                                        double *device_sums, double q[4], double t[3], ea_summary *summary) {
   if (!p || !allreduce || !device_sums || !q || !t) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  if (reinterpret_cast<uintptr_t>(device_sums) % 16 != 0) return fail(EA_ERR_INVALID_ARG, "device_sums must be 16-byte aligned");
   const auto t0 = std::chrono::steady_clock::now();
   ea_options o;
   if (opt_in) o = *opt_in; else ea_default_options(&o);

@@ -47,6 +47,11 @@ namespace ea {
 // workgroup stamps s_memtime at the phase boundaries into a buffer of its own; no output value depends on it.
 #ifdef EA_STAMPS
 __device__ unsigned long long *g_stamp_buf = nullptr;
+#ifndef EA_STAMPS_EVAL
+// (the evaluation kernel's stamps need -DEA_STAMPS_EVAL on top: since the kernel head keeps its uniforms in named SGPRs the
+// stamped form of it no longer compiles on this toolchain -- "illegal VGPR to SGPR copy"; the LM-step stamps are unaffected)
+#define EA_STAMP(slot) do {} while (0)
+#else
 #define EA_STAMP(slot)                                                                              \
   do {                                                                                              \
     if (g_stamp_buf && threadIdx.x == 0) {                                                          \
@@ -57,6 +62,7 @@ __device__ unsigned long long *g_stamp_buf = nullptr;
       g_stamp_buf[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = t_;                 \
     }                                                                                               \
   } while (0)
+#endif
 __device__ unsigned long long *g_lm_stamp_buf = nullptr;  // [64 evaluations][8] kernel + [64][8] state-machine probes, problem 0
 __device__ int g_lm_probe_row = 0;
 #define EA_LM_STAMP(slot, eval)                                                                     \
@@ -1334,32 +1340,47 @@ constexpr int kFoldThreads = 1024;  // plain fold: 32 slots x 32 strided groups
 constexpr int kLmThreads = 256;     // fold + scalar LM code: 4 waves = one per SIMD, so the scalar code can keep
                                     // its ~300 live registers without spilling to scratch
 
+// LDS doubles reduce_tiles needs for a workgroup of NTHREADS threads
+template <int NTHREADS> constexpr int reduce_tiles_lds() { return (NTHREADS / 16 + NTHREADS / 256) * kAccSlots; }
+
+// A row is 32 doubles = 256 bytes.  Lanes fetch 16 bytes each (two slots): 16 lanes cover a row, a wavefront four rows per
+// load instruction.  (With 8 bytes per lane the fold of 196 rows was 128 wave-level load instructions through the one
+// texture-address unit of the CU at ~20 cycles each -- the instruction count, not the latency of the round trip, was what
+// the LM step waited for: in-kernel stamps, 4.7 k cycles for the fold.)  Thread (id, j) = (tid & 15, tid >> 4) sums slots
+// 2 id, 2 id + 1 of rows begin + j + u G, u = 0 .. U-1, G = NTHREADS / 16 row groups, round after round of U G rows.
 template <int NTHREADS, int U>
 __device__ __forceinline__ void reduce_tiles(const double *__restrict__ partials, int tile_begin,
-                                             int tile_end, double *s_part /* (NTHREADS/32) x 32 */,
+                                             int tile_end, double *s_part /* reduce_tiles_lds<NTHREADS>() */,
                                              double *out /* 32, threads 0..31 write */) {
-  constexpr int G = NTHREADS / 32;
-  static_assert(U == 8 || U == 16, "pairwise combine below");
+  constexpr int G = NTHREADS / 16, F = NTHREADS / 256;
+  static_assert(U == 4 || U == 8, "pairwise combine below");
+  static_assert(NTHREADS == 256 || NTHREADS == 1024, "final stage: 16 groups per thread");
+  typedef double D2 __attribute__((ext_vector_type(2)));
   const int tid = threadIdx.x;
-  const int id = tid & 31, j = tid >> 5;
-  // fixed summation order for a given tile count; U independent loads in flight per thread
-  double s[U];
+  const int id = tid & 15, j = tid >> 4;
+  // fixed summation order for a given tile count; 2 U independent loads in flight per thread
+  D2 s[U];
 #pragma unroll
-  for (int u = 0; u < U; ++u) s[u] = 0.0;
+  for (int u = 0; u < U; ++u) s[u] = D2{0.0, 0.0};
   // A round = U rows per lane.  Rows past the end are loaded from the last row (a valid address) and masked out
   // of the sum, so a round is U back-to-back loads with no branches; the first two rounds are issued together:
   // folds of up to 2 U G rows cost one memory round trip.
   const int last = tile_end - 1;
   if (tile_begin <= last) {  // uniform
-    auto load_round = [&](int base, double(&v)[U]) {
+    auto load_round = [&](int base, D2(&v)[U]) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = partials[(size_t)min(base + j + u * G, last) * kAccSlots + id];
+      for (int u = 0; u < U; ++u)
+        v[u] = *reinterpret_cast<const D2 *>(partials + (size_t)min(base + j + u * G, last) * kAccSlots + 2 * id);
     };
-    auto add_round = [&](int base, const double(&v)[U]) {
+    auto add_round = [&](int base, const D2(&v)[U]) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) s[u] += (base + j + u * G <= last) ? v[u] : 0.0;
+      for (int u = 0; u < U; ++u) {
+        const bool in = base + j + u * G <= last;
+        s[u].x += in ? v[u].x : 0.0;
+        s[u].y += in ? v[u].y : 0.0;
+      }
     };
-    double v0[U], v1[U];
+    D2 v0[U], v1[U];
     load_round(tile_begin, v0);
     if (tile_begin + U * G <= last) {  // uniform
       load_round(tile_begin + U * G, v1);
@@ -1377,22 +1398,42 @@ __device__ __forceinline__ void reduce_tiles(const double *__restrict__ partials
   for (int w = 1; w < U; w *= 2)
 #pragma unroll
     for (int u = 0; u + w < U; u += 2 * w) s[u] += s[u + w];
-  s_part[j * kAccSlots + id] = s[0];
+  *reinterpret_cast<D2 *>(s_part + j * kAccSlots + 2 * id) = s[0];
   __syncthreads();
-  if (tid < kAccSlots) {
-    double tot = 0.0;
+  // final stage: slot `tid & 31` over 16 row groups per thread, in group order; with 1024 threads four such partial sums per
+  // slot, combined in order by the first 32 threads
+  if constexpr (F == 1) {
+    if (tid < kAccSlots) {
+      double tot = 0.0;
 #pragma unroll
-    for (int k = 0; k < G; ++k) tot += s_part[k * kAccSlots + tid];
-    out[tid] = tot;
+      for (int k = 0; k < G; ++k) tot += s_part[k * kAccSlots + tid];
+      out[tid] = tot;
+    }
+  } else {
+    double *s_fin = s_part + G * kAccSlots;
+    if (tid < kAccSlots * F) {
+      const int slot = tid & 31, f = tid >> 5;
+      double tot = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) tot += s_part[(16 * f + k) * kAccSlots + slot];
+      s_fin[f * kAccSlots + slot] = tot;
+    }
+    __syncthreads();
+    if (tid < kAccSlots) {
+      double tot = 0.0;
+#pragma unroll
+      for (int f = 0; f < F; ++f) tot += s_fin[f * kAccSlots + tid];
+      out[tid] = tot;
+    }
   }
 }
 
 __global__ __launch_bounds__(kFoldThreads) void ea_reduce_kernel(const GroupDesc *__restrict__ groups,
                                                                   const double *__restrict__ partials,
                                                                   EvalOut *__restrict__ out) {
-  __shared__ double s_part[(kFoldThreads / 32) * kAccSlots];
+  __shared__ __align__(16) double s_part[reduce_tiles_lds<kFoldThreads>()];
   const GroupDesc gd = groups[blockIdx.x];
-  reduce_tiles<kFoldThreads, 8>(partials, gd.tile_begin, gd.tile_end, s_part, out[blockIdx.x].acc);
+  reduce_tiles<kFoldThreads, 4>(partials, gd.tile_begin, gd.tile_end, s_part, out[blockIdx.x].acc);
 }
 
 // The fold as a 256-thread workgroup sums it when it rides in an evaluation launch (ea_eval_fold_kernel below; 8 rows in
@@ -1400,9 +1441,9 @@ __global__ __launch_bounds__(kFoldThreads) void ea_reduce_kernel(const GroupDesc
 __global__ __launch_bounds__(kLmThreads) void ea_reduce256_kernel(const GroupDesc *__restrict__ groups,
                                                                   const double *__restrict__ partials,
                                                                   EvalOut *__restrict__ out) {
-  __shared__ double s_part[(kLmThreads / 32) * kAccSlots];
+  __shared__ __align__(16) double s_part[reduce_tiles_lds<kLmThreads>()];
   const GroupDesc gd = groups[blockIdx.x];
-  reduce_tiles<kLmThreads, 8>(partials, gd.tile_begin, gd.tile_end, s_part, out[blockIdx.x].acc);
+  reduce_tiles<kLmThreads, 4>(partials, gd.tile_begin, gd.tile_end, s_part, out[blockIdx.x].acc);
 }
 
 // Evaluation k with the fold of evaluation k-1 riding in the same launch: one extra workgroup per problem (the last
@@ -1419,9 +1460,9 @@ __global__ __launch_bounds__(NT) void ea_eval_fold_kernel(
     double *__restrict__ partials, int lds_texels,
     const GroupDesc *__restrict__ groups, const double *__restrict__ prev_rows, EvalOut *__restrict__ prev_out) {
   if (blockIdx.x == gridDim.x - 1) {  // (uniform)
-    __shared__ double s_part[(NT / 32) * kAccSlots];
+    __shared__ __align__(16) double s_part[reduce_tiles_lds<NT>()];
     const GroupDesc gd = groups[blockIdx.y];
-    reduce_tiles<NT, 8>(prev_rows, gd.tile_begin, gd.tile_end, s_part, prev_out[blockIdx.y].acc);
+    reduce_tiles<NT, 4>(prev_rows, gd.tile_begin, gd.tile_end, s_part, prev_out[blockIdx.y].acc);
     return;
   }
   eval_fused_body<T, PPT, 0, NT, false, BUF>(x0, y0, z0, n0, shape, chunks_per_xcd, probs, poses, partials, lds_texels);
@@ -1441,7 +1482,7 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_step_kernel(
     int *__restrict__ progress /* pinned host: [running x n | evals x n] */,
     LMState *__restrict__ host_states, LMTrace *__restrict__ host_traces /* pinned host, nullable: final delivery */,
     GroupDesc first /* = groups[0], by value: problem 0's row range needs no dependent load */) {
-  __shared__ double s_part[(kLmThreads / 32) * kAccSlots];
+  __shared__ __align__(16) double s_part[reduce_tiles_lds<kLmThreads>()];
   __shared__ double s_acc[kAccSlots];
   __shared__ LMState s_st;
   __shared__ PoseState s_ps;
@@ -1473,9 +1514,12 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_step_kernel(
   const int running = states[p].running;
   const int evals_before = states[p].num_evals;  // (a register copy: the LDS copy is rewritten by lane 0 below)
   const double state_word = tid < kStateWords ? reinterpret_cast<const double *>(states + p)[tid] : 0.0;
-  if (!running) return;  // uniform
   EA_LM_STAMP(1, ev_);
-  reduce_tiles<kLmThreads, 16>(partials, gd.tile_begin, gd.tile_end, s_part, s_acc);
+  // The rows are fetched WITHOUT waiting for the running flag: the flag's round trip (0.5 us of the 2.5 us this kernel spends
+  // before its first arithmetic, in-kernel stamps) then travels beside the rows' instead of in front of it.  A finished
+  // problem folds rows nobody reads and leaves below.
+  reduce_tiles<kLmThreads, 8>(partials, gd.tile_begin, gd.tile_end, s_part, s_acc);
+  if (!running) return;  // uniform
   if (tid < kStateWords) reinterpret_cast<double *>(&s_st)[tid] = state_word;
   __syncthreads();
   EA_LM_STAMP(2, ev_);

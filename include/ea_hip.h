@@ -220,7 +220,7 @@ typedef int (*ea_allreduce_fn)(double *buf, int count, void *user);
 int ea_solve_sharded(ea_problem *p, const ea_options *opt, ea_allreduce_fn allreduce, void *user, double q[4], double t[3],
                      ea_summary *summary);
 /* The same solve with the exchange kept ON THE STREAM ("no host round-trip"): per iteration
- * the library enqueues, on one HIP stream, fused evaluation -> fold into `device_sums` (32 doubles of DEVICE memory owned
+ * the library enqueues, on one HIP stream, fused evaluation -> fold into `device_sums` (32 doubles of 16-byte aligned DEVICE memory owned
  * by the caller, e.g. the storage of a torch tensor) -> `allreduce(device_sums, 32, stream, user)`, which must ENQUEUE an
  * in-place sum over all ranks on that stream (RCCL: ncclAllReduce on it, or torch.distributed under an ExternalStream)
  * and return without waiting -> the trust-region step kernel, which reads `device_sums`.  Iterations are enqueued in

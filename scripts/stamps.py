@@ -25,9 +25,10 @@ def run(name, cfg, dtype, loss, tune=None):
         print('   %-12s median %7.0f  p90 %7.0f' % (nm, np.median(d[:, i]), np.percentile(d[:, i], 90)))
     print('   workgroup total median %.0f; first start -> last end %.0f; start spread %.0f' % (np.median(st[:, 7] - st[:, 0]), st[:, 7].max() - t_first, st[:, 0].max() - t_first))
     B.close(); P.close()
-run('c2 f64', synth.config_c2_twin(), capi.EA_F64, (capi.LOSS_CAUCHY, 1.0))
-run('lm1e5 f64', synth.config_c2_twin(seed=7, n_points=100000), capi.EA_F64, (capi.LOSS_CAUCHY, 1.0))
-run('c5 f32', synth.config_c5(), capi.EA_F32, (capi.LOSS_TRIVIAL, 1.0))
+if len(sys.argv) > 1 and sys.argv[1] == 'eval':   # (needs a library built with -DEA_STAMPS -DEA_STAMPS_EVAL)
+    run('c2 f64', synth.config_c2_twin(), capi.EA_F64, (capi.LOSS_CAUCHY, 1.0))
+    run('lm1e5 f64', synth.config_c2_twin(seed=7, n_points=100000), capi.EA_F64, (capi.LOSS_CAUCHY, 1.0))
+    run('c5 f32', synth.config_c5(), capi.EA_F32, (capi.LOSS_TRIVIAL, 1.0))
 
 def run_lm(name, cfg):
     P = capi.Problem(*cfg['K'], dtype=capi.EA_F64); P.set_points(cfg['xyz']); P.set_dt_grid(cfg['grid']); P.set_loss(capi.LOSS_CAUCHY, 1.0)
