@@ -1530,14 +1530,15 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_step_kernel(
   LMPending pend;
   double acc[kAccSlots];
   if (tid == 0) {
-    LMState st = s_st;
+    LMState st;
+    lm_copy_state(&st, &s_st);
 #pragma unroll
     for (int i = 0; i < kAccSlots; ++i) acc[i] = s_acc[i];
     if (EA_UNLIKELY(st.num_evals == 0)) lm_begin<STRAT>(&st, cold + p, traces + p, &opt, acc, &pend);
     else lm_advance<STRAT>(&st, cold + p, traces + p, &opt, acc, &pend);
     EA_LM_STAMP(3, ev_);
     make_pose_core(st.cand, st.rot_transposed, st.running, &s_ps, /*zero_unused_G=*/false);
-    s_st = st;
+    lm_copy_state(&s_st, &st);
     s_trace_it = pend.trace_it;
     EA_LM_STAMP(4, ev_);
   }

@@ -69,6 +69,22 @@ struct LMCold {
   double dl_diag[6], dl_grad[6], dl_gn[6];
 };
 
+// member-by-member copy (the step kernel's register copy of the state: a whole-struct copy left the members the LM strategy
+// never touches -- mu, alpha, dogleg_step_norm -- in a private array, which the compiler placed in LDS behind a read of the
+// dispatch packet for the workgroup's shape: a scalar load from the queue's ring buffer on the state machine's critical path)
+EA_HD inline void lm_copy_state(LMState *d, const LMState *s) {
+  for (int i = 0; i < 7; ++i) { d->x[i] = s->x[i]; d->cand[i] = s->cand[i]; }
+  d->x_norm = s->x_norm; d->cost = s->cost;
+  for (int i = 0; i < 6; ++i) { d->S[i] = s->S[i]; d->diagonal[i] = s->diagonal[i]; }
+  d->radius = s->radius; d->decrease_factor = s->decrease_factor;
+  d->mu = s->mu; d->alpha = s->alpha; d->dogleg_step_norm = s->dogleg_step_norm;
+  d->model_cost_change = s->model_cost_change; d->gradient_max_norm = s->gradient_max_norm;
+  d->reuse_diagonal = s->reuse_diagonal; d->dl_reuse = s->dl_reuse; d->iteration = s->iteration; d->running = s->running;
+  d->termination = s->termination; d->why = s->why; d->num_successful = s->num_successful; d->num_unsuccessful = s->num_unsuccessful;
+  d->num_consecutive_invalid = s->num_consecutive_invalid; d->num_evals = s->num_evals; d->rot_transposed = s->rot_transposed;
+  d->pad_ = s->pad_;
+}
+
 // packed upper-triangle index of (a,b), a <= b, 6x6
 EA_HD constexpr int sym6(int a, int b) { return a <= b ? a * 6 - a * (a - 1) / 2 + (b - a) : b * 6 - b * (b - 1) / 2 + (a - b); }
 
