@@ -105,12 +105,41 @@ EA_HD inline double norm_n(const double *v, int n) {
 }
 
 // QuaternionParameterization::Plus: x_plus = [cos|d|, sin|d|/|d| d] (x) x
-EA_HD inline void quat_plus(const double x[4], const double d[3], double out[4]) {
-  const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-  if (EA_LIKELY(nd > 0.0)) {
-    double sn, cs;
-    sincos(nd, &sn, &cs);
-    const double s = sn / nd;
+// `small_expected`: which of the two forms below is laid out as the fall-through path -- a trust-region step is small, the
+// (minus) gradient that Ceres pushes through Plus for its gradient_max_norm is not
+EA_HD inline void quat_plus(const double x[4], const double d[3], double out[4], bool small_expected = true) {
+  const double n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  if (EA_LIKELY(n2 > 0.0)) {
+    double s, cs;  // s = sin|d| / |d|, cs = cos|d|
+    const bool small = n2 < 0.25;
+    if (small_expected ? EA_LIKELY(small) : EA_UNLIKELY(small)) {
+      // |d| < 0.5 rad -- every step of a converging solve: both are even functions of |d|, evaluated as Taylor polynomials in
+      // |d|^2 (relative error < 1e-16 on this range, checked against 80-bit sin / cos) -- no square root, no argument
+      // reduction, no division: ~20 dependent-free FMAs instead of ~120 instructions, twice per iteration on the one
+      // lane every LM iteration waits for.
+      s = n2 * 2.8114572543455206e-15 - 7.6471637318198164e-13;
+      s = s * n2 + 1.6059043836821613e-10;
+      s = s * n2 - 2.505210838544172e-08;
+      s = s * n2 + 2.7557319223985893e-06;
+      s = s * n2 - 0.00019841269841269841;
+      s = s * n2 + 0.0083333333333333332;
+      s = s * n2 - 0.16666666666666666;
+      s = s * n2 + 1.0;
+      cs = n2 * -1.5619206968586225e-16 + 4.7794773323873853e-14;
+      cs = cs * n2 - 1.1470745597729725e-11;
+      cs = cs * n2 + 2.08767569878681e-09;
+      cs = cs * n2 - 2.7557319223985888e-07;
+      cs = cs * n2 + 2.4801587301587302e-05;
+      cs = cs * n2 - 0.0013888888888888889;
+      cs = cs * n2 + 0.041666666666666664;
+      cs = cs * n2 - 0.5;
+      cs = cs * n2 + 1.0;
+    } else {
+      const double nd = sqrt(n2);
+      double sn;
+      sincos(nd, &sn, &cs);
+      s = sn / nd;
+    }
     const double q0 = cs, q1 = s * d[0], q2 = s * d[1], q3 = s * d[2];
     out[0] = q0 * x[0] - q1 * x[1] - q2 * x[2] - q3 * x[3];
     out[1] = q0 * x[1] + q1 * x[0] + q2 * x[3] - q3 * x[2];
@@ -121,8 +150,8 @@ EA_HD inline void quat_plus(const double x[4], const double d[3], double out[4])
   }
 }
 
-EA_HD inline void pose_plus(const double x[7], const double delta[6], double out[7]) {
-  quat_plus(x, delta, out);
+EA_HD inline void pose_plus(const double x[7], const double delta[6], double out[7], bool small_expected = true) {
+  quat_plus(x, delta, out, small_expected);
   for (int i = 0; i < 3; ++i) out[4 + i] = x[4 + i] + delta[3 + i];
 }
 
@@ -331,7 +360,7 @@ EA_HD inline void lm_take_system(LMState *s, LMPending *pend, const double acc[k
   double neg[6], xp[7], m = 0.0;
 #pragma unroll
   for (int i = 0; i < 6; ++i) neg[i] = -acc[kAccJtr + i];
-  pose_plus(s->x, neg, xp);
+  pose_plus(s->x, neg, xp, /*small_expected=*/false);
 #pragma unroll
   for (int i = 0; i < 7; ++i) m = fmax(m, fabs(s->x[i] - xp[i]));
   s->gradient_max_norm = m;
