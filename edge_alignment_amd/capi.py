@@ -30,7 +30,7 @@ EXPORTED = [
     "ea_eval", "ea_eval_points", "ea_cost", "ea_problem_pixel_cost", "ea_solve",
     "ea_batch_create", "ea_batch_destroy", "ea_batch_count", "ea_batch_eval", "ea_batch_solve",
     "ea_solve_pyramid", "ea_solve_sharded", "ea_solve_sharded_device", "ea_tracker_create", "ea_tracker_destroy", "ea_tracker_problem", "ea_tracker_push_frame",
-    "ea_batch_bench_eval", "ea_batch_bench_steps", "ea_batch_bench_capture", "ea_batch_bench_capture_pipelined", "ea_batch_bench_result", "ea_batch_bench_result_riding", "ea_batch_bench_kernel", "ea_batch_bench_rows", "ea_batch_row_offsets", "ea_batch_eval_rows_device", "ea_batch_eval_rows", "ea_batch_bench_fold", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
+    "ea_batch_bench_eval", "ea_batch_bench_steps", "ea_batch_bench_capture", "ea_batch_bench_capture_pipelined", "ea_batch_bench_result", "ea_batch_bench_result_riding", "ea_batch_bench_kernel", "ea_batch_bench_rows", "ea_batch_row_offsets", "ea_problem_num_rows", "ea_eval_rows", "ea_eval_rows_device", "ea_batch_eval_rows_device", "ea_batch_eval_rows", "ea_batch_bench_fold", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
     "ea_problem_set_ref_frame", "ea_problem_set_ref_frame_masked", "ea_problem_set_now_frame", "ea_problem_debug_now_frame",
     "ea_problem_set_ref_frame_canny", "ea_problem_set_now_frame_canny", "ea_problem_debug_now_frame_canny",
     "ea_problem_set_ref_frame_ros", "ea_problem_set_now_frame_ros", "ea_problem_debug_now_frame_ros",
@@ -136,6 +136,9 @@ def load():
     L.ea_batch_bench_kernel.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp]
     L.ea_batch_bench_fold.argtypes = [vp, C.c_int, C.c_int, dp]
     L.ea_batch_row_offsets.argtypes = [vp, i64p]
+    L.ea_problem_num_rows.argtypes = [vp, i64p]
+    L.ea_eval_rows.argtypes = [vp, dp, dp, C.c_int, C.c_int, vp, vp, C.c_int64, i64p]
+    L.ea_eval_rows_device.argtypes = [vp, dp, dp, C.c_int, C.c_int, vp, vp, C.c_int64, i64p]
     L.ea_batch_eval_rows_device.argtypes = [vp, dp, dp, C.c_int, C.c_int, vp, vp, C.c_int64, i64p]
     L.ea_batch_eval_rows.argtypes = [vp, dp, dp, C.c_int, C.c_int, vp, vp, C.c_int64, i64p]
     L.ea_batch_bench_rows.argtypes = [vp, dp, dp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int64, C.c_int, C.c_int, dp]
@@ -468,6 +471,19 @@ class Problem:
         r, J = np.zeros(n), np.zeros((n, 6))
         _check(load().ea_eval_points(self._h, _dp(q), _dp(t), _dp(r), _dp(J), int(corrected)))
         return r, J
+
+    def eval_rows(self, q, t, corrected=True, layout=0):
+        """materialised mode: r [rows], J [rows, 6] (layout 0) or [6, rows] (layout 1) in the problem's dtype, n_invalid"""
+        q, t = _f64(q), _f64(t)
+        n = C.c_int64()
+        _check(load().ea_problem_num_rows(self._h, C.byref(n)))
+        dt = np.float32 if self.dtype == EA_F32 else np.float64
+        r = np.zeros(n.value, dtype=dt)
+        J = np.zeros((n.value, 6) if layout == 0 else (6, n.value), dtype=dt)
+        bad = C.c_int64()
+        _check(load().ea_eval_rows(self._h, _dp(q), _dp(t), int(corrected), int(layout), r.ctypes.data_as(C.c_void_p),
+                                   J.ctypes.data_as(C.c_void_p), n.value, C.byref(bad)))
+        return r, J, bad.value
 
     def cost(self, q, t):
         q, t = _f64(q), _f64(t)

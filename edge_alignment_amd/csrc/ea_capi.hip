@@ -1615,6 +1615,12 @@ extern "C" int ea_batch_get_info(const ea_batch *b, const char *key, int64_t *va
 
 // ---- single-problem conveniences = batch of one ------------------------------------------------
 
+extern "C" int ea_batch_row_offsets(ea_batch *b, int64_t *offsets);
+extern "C" int ea_batch_eval_rows(ea_batch *b, const double *q, const double *t, int corrected, int layout, void *r_host,
+                                  void *J_host, int64_t capacity_rows, int64_t *n_invalid);
+extern "C" int ea_batch_eval_rows_device(ea_batch *b, const double *q, const double *t, int corrected, int layout, void *r_dev,
+                                         void *J_dev, int64_t capacity_rows, int64_t *n_invalid);
+
 static int self_batch(ea_problem *p, ea_batch **out) {
   if (!p) return fail(EA_ERR_INVALID_ARG, "NULL problem");
   if (!p->self) {
@@ -1633,6 +1639,34 @@ extern "C" int ea_eval(ea_problem *p, const double q[4], const double t[3], doub
   int rc = self_batch(p, &b);
   if (rc != EA_OK) return rc;
   return ea_batch_eval(b, q, t, cost, JtJ, Jtr, n_invalid);
+}
+
+// materialised mode of one problem (its terms included, in term order): rows = ea_problem_num_rows(p)
+extern "C" int ea_problem_num_rows(ea_problem *p, int64_t *rows) {
+  if (!rows) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  ea_batch *b;
+  int rc = self_batch(p, &b);
+  if (rc != EA_OK) return rc;
+  int64_t off[2];
+  rc = ea_batch_row_offsets(b, off);
+  if (rc == EA_OK) *rows = off[1];
+  return rc;
+}
+
+extern "C" int ea_eval_rows(ea_problem *p, const double q[4], const double t[3], int corrected, int layout, void *r_host,
+                            void *J_host, int64_t capacity_rows, int64_t *n_invalid) {
+  ea_batch *b;
+  int rc = self_batch(p, &b);
+  if (rc != EA_OK) return rc;
+  return ea_batch_eval_rows(b, q, t, corrected, layout, r_host, J_host, capacity_rows, n_invalid);
+}
+
+extern "C" int ea_eval_rows_device(ea_problem *p, const double q[4], const double t[3], int corrected, int layout, void *r_dev,
+                                   void *J_dev, int64_t capacity_rows, int64_t *n_invalid) {
+  ea_batch *b;
+  int rc = self_batch(p, &b);
+  if (rc != EA_OK) return rc;
+  return ea_batch_eval_rows_device(b, q, t, corrected, layout, r_dev, J_dev, capacity_rows, n_invalid);
 }
 
 extern "C" int ea_cost(ea_problem *p, const double q[4], const double t[3], double *cost, int64_t *n_invalid) {

@@ -278,6 +278,13 @@ int ea_batch_eval_rows_device(ea_batch *b, const double *q, const double *t, int
 int ea_batch_eval_rows(ea_batch *b, const double *q, const double *t, int corrected, int layout, void *r_host,
                        void *J_host, int64_t capacity_rows, int64_t *n_invalid);
 
+/* the same for one problem (its terms included, in term order; rows = ea_problem_num_rows) */
+int ea_problem_num_rows(ea_problem *p, int64_t *rows);
+int ea_eval_rows(ea_problem *p, const double q[4], const double t[3], int corrected, int layout, void *r_host, void *J_host,
+                 int64_t capacity_rows, int64_t *n_invalid);
+int ea_eval_rows_device(ea_problem *p, const double q[4], const double t[3], int corrected, int layout, void *r_dev, void *J_dev,
+                        int64_t capacity_rows, int64_t *n_invalid);
+
 /* ---- measurement hooks (used by bench.py; timing is done with HIP events on the stream the
  * kernels are launched on) ------------------------------------------------------------- */
 /* Upload the poses once, run `warmup` untimed then `steps` timed fused evaluations

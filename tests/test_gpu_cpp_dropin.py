@@ -186,3 +186,4 @@ def test_c_abi_from_plain_c(binaries, hip, bundled_pair, tmp_path):
     P.close()
     assert v[:4] == list(q) and v[4:7] == list(t)
     assert int(v[7]) == s["num_iterations"] and int(v[8]) == s["termination"] and v[9] == s["final_cost"]
+    assert 0.0 <= v[10] < 1e-12   # ea_eval_rows from C: J^T r of the rows is the gradient ea_eval reports
