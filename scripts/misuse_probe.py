@@ -293,6 +293,56 @@ def cases():
         r1 = c.lib.ea_solve_sharded(c.P, None, C.cast(None, capi.ALLREDUCE_FN), None, dp(q), dp(t), C.byref(s))
         r2 = c.lib.ea_solve_sharded_device(c.P, None, C.cast(None, capi.DEVICE_ALLREDUCE_FN), None, None, dp(q), dp(t), C.byref(s)) if hasattr(capi, "DEVICE_ALLREDUCE_FN") else "n/a"
         c.note = "%s %s" % (r1, r2); return -1 if r1 != 0 else 0
+    # ---- materialised mode and the pipelined measurement hook (round 2, second session)
+    VP = C.c_void_p
+    I64 = C.POINTER(C.c_int64)
+    @case("eval_rows: null outputs / null pose / bad layout / capacity too small")
+    def _(c):
+        n = C.c_int64(); bad = C.c_int64()
+        assert c.lib.ea_problem_num_rows(c.P, C.byref(n)) == 0 and n.value == len(c.xyz)
+        r = np.zeros(n.value); J = np.zeros((n.value, 6))
+        rp, Jp = r.ctypes.data_as(VP), J.ctypes.data_as(VP)
+        rcs = [c.lib.ea_eval_rows(c.P, dp(c.q), dp(c.t), 1, 0, None, None, n.value, C.byref(bad)),
+               c.lib.ea_eval_rows(c.P, NULLD, dp(c.t), 1, 0, rp, Jp, n.value, C.byref(bad)),
+               c.lib.ea_eval_rows(c.P, dp(c.q), dp(c.t), 1, 2, rp, Jp, n.value, C.byref(bad)),
+               c.lib.ea_eval_rows(c.P, dp(c.q), dp(c.t), 1, -1, rp, Jp, n.value, C.byref(bad)),
+               c.lib.ea_eval_rows(c.P, dp(c.q), dp(c.t), 1, 0, rp, Jp, n.value - 1, C.byref(bad)),
+               c.lib.ea_eval_rows(None, dp(c.q), dp(c.t), 1, 0, rp, Jp, n.value, C.byref(bad)),
+               c.lib.ea_problem_num_rows(c.P, None), c.lib.ea_problem_num_rows(None, C.byref(n))]
+        c.note = str(rcs)
+        ok = c.lib.ea_eval_rows(c.P, dp(c.q), dp(c.t), 1, 0, rp, Jp, n.value, None)   # n_invalid may be NULL
+        return -1 if (all(x != 0 for x in rcs) and ok == 0 and np.isfinite(J).all() and J.any()) else 0
+    @case("eval_rows_device: one pointer null / misaligned / host memory where the runtime can tell / capacity")
+    def _(c):
+        import torch
+        n = len(c.xyz); bad = C.c_int64()
+        r = torch.zeros(n + 2, dtype=torch.float64, device="cuda"); J = torch.zeros((n + 2, 6), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        rp, Jp = r.data_ptr(), J.data_ptr()
+        rcs = [c.lib.ea_eval_rows_device(c.P, dp(c.q), dp(c.t), 1, 0, VP(rp), None, n, C.byref(bad)),
+               c.lib.ea_eval_rows_device(c.P, dp(c.q), dp(c.t), 1, 0, None, VP(Jp), n, C.byref(bad)),
+               c.lib.ea_eval_rows_device(c.P, dp(c.q), dp(c.t), 1, 0, VP(rp + 8), VP(Jp), n, C.byref(bad)),
+               c.lib.ea_eval_rows_device(c.P, dp(c.q), dp(c.t), 1, 0, VP(rp), VP(Jp), n - 1, C.byref(bad)),
+               c.lib.ea_eval_rows_device(c.P, dp(c.q), dp(c.t), 1, 3, VP(rp), VP(Jp), n, C.byref(bad))]
+        c.note = str(rcs)
+        ok = c.lib.ea_eval_rows_device(c.P, dp(c.q), dp(c.t), 1, 0, VP(rp), VP(Jp), n + 2, C.byref(bad))
+        tail_untouched = float(r[n:].abs().max()) == 0.0 and float(J[n:].abs().max()) == 0.0
+        return -1 if (all(x != 0 for x in rcs) and ok == 0 and tail_untouched and float(J[:n].abs().max()) > 0) else 0
+    @case("batch rows: null offsets / null batch; bench hooks: steps 0, no poses, null result arrays")
+    def _(c):
+        off = np.zeros(2, dtype=np.int64)
+        b2 = C.c_void_p(); arr = (C.c_void_p * 1)(c.P2); assert c.lib.ea_batch_create(C.byref(b2), arr, 1) == 0
+        ms = C.c_double()
+        rcs = [c.lib.ea_batch_row_offsets(c.B, None), c.lib.ea_batch_row_offsets(None, off.ctypes.data_as(I64)),
+               c.lib.ea_batch_bench_capture_pipelined(c.B, 0), c.lib.ea_batch_bench_capture_pipelined(None, 4),
+               c.lib.ea_batch_bench_capture_pipelined(b2, 4),      # no poses uploaded on this batch yet
+               c.lib.ea_batch_bench_result(None, None, None, None, None), c.lib.ea_batch_bench_result(b2, None, None, None, None),
+               c.lib.ea_batch_bench_result_riding(c.B, None, None, None, None),   # nothing pipelined captured
+               c.lib.ea_batch_bench_rows(c.B, dp(c.q), dp(c.t), 1, 0, 1, None, None, 0, 0, 0, C.byref(ms)),   # launches 0
+               c.lib.ea_batch_bench_rows(c.B, dp(c.q), dp(c.t), 1, 0, 1, None, None, 0, 0, 3, None)]
+        c.note = str(rcs)
+        c.lib.ea_batch_destroy(b2)
+        return -1 if all(x != 0 for x in rcs) else 0
     return L
 
 

@@ -22,7 +22,7 @@ def _probe():
 
 def test_every_misuse_case_is_refused_and_leaves_the_handle_intact(hip):
     res = _probe().run_in_process()
-    assert len(res) >= 45
+    assert len(res) >= 48
     bad = [(v, n, m) for v, n, m in res if v != "ok" and "1x1 grid" not in n]
     assert not bad, "\n".join("%s: %s -- %s" % b for b in bad)
     # a 1x1 distance-transform grid is legal (Grid2D clamps every tap to its one texel): accepted, handle intact
