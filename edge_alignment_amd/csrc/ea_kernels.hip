@@ -1471,7 +1471,7 @@ __global__ __launch_bounds__(NT) void ea_eval_fold_kernel(
 // LM step: fold this problem's partial rows, advance the trust-region state machine, publish the
 // next pose to evaluate.  One workgroup per problem.  The state machine is scalar fp64 work on
 // lane 0 (pure latency: ~1/3 of an LM iteration), so everything around it is arranged to overlap:
-// the state words travel while the partial rows are fetched (16 loads in flight per lane), the
+// the state words travel while the partial rows are fetched (sixteen 16-byte loads in flight per lane), the
 // host's progress counter is posted before the arithmetic, lane 0 works on a register copy of the
 // state, and the pose's float mirrors / the write-back are lane-parallel.
 template <int STRAT>
