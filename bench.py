@@ -241,6 +241,16 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     value = world * n_pts * args.steps / elapsed
+    # what the bracket itself costs on idle GPUs (N > 1: the closing barrier is a collective inside the timed region; at
+    # K = 20 steps of ~3 us it is comparable to the work): reported beside the value, not subtracted from it
+    bracket_ms = None
+    if dist is not None:
+        costs = []
+        for _ in range(5):
+            tb = time.perf_counter()
+            barrier_sync()
+            costs.append(time.perf_counter() - tb)
+        bracket_ms = min(costs) * 1e3
     # the timed launches computed what ea_batch_eval computes (the riding folds sum in another order: equal to rounding)
     got, want = B.bench_result(), B.eval(q0, t0)
     B.bench_eval(q0, t0, 0, 1, kernel_pass=False)  # (poses resident again for the measurements below)
@@ -327,7 +337,8 @@ def main():
                            "parallelism": "independent frame pairs, one per GPU; single RCCL pose all-gather",
                            "tiles": B.info("num_tiles"), "points_per_thread": B.info("points_per_thread"),
                            "lds_bytes": B.info("lds_bytes"), "point_order_tile_px": P.point_order,
-                           "timed_region": graph or "eager launches"},
+                           "timed_region": graph or "eager launches",
+                           "closing_barrier_and_sync_ms_on_idle_gpus": bracket_ms},
                 "roofline": roofline, "materialised_mode": mat}
     extras, others, leg = {}, {}, ["start"]
 
