@@ -72,6 +72,7 @@ struct LMCold {
 // member-by-member copy (the step kernel's register copy of the state: a whole-struct copy left the members the LM strategy
 // never touches -- mu, alpha, dogleg_step_norm -- in a private array, which the compiler placed in LDS behind a read of the
 // dispatch packet for the workgroup's shape: a scalar load from the queue's ring buffer on the state machine's critical path)
+static_assert(sizeof(LMState) == 35 * sizeof(double) + 12 * sizeof(int), "lm_copy_state copies member by member: a new member goes there too");
 EA_HD inline void lm_copy_state(LMState *d, const LMState *s) {
   for (int i = 0; i < 7; ++i) { d->x[i] = s->x[i]; d->cand[i] = s->cand[i]; }
   d->x_norm = s->x_norm; d->cost = s->cost;
