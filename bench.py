@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--extras-timeout", type=float, default=240.0,
                     help="seconds the secondary measurements may take before the line is printed without the unfinished ones")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the timed steps launch by launch instead of replaying a hipGraph")
+    ap.add_argument("--collective-barrier", action="store_true", help="N > 1: bracket the timed region with torch.distributed.barrier() instead of the shared-memory barrier")
     ap.add_argument("--serial-steps", action="store_true",
                     help="timed region as evaluation -> fold -> evaluation ... (two dependent launches per step) instead of the fold of step k-1 riding in the launch of evaluation k")
     # rehearsal knobs (the driver never passes them): run the N>1 control flow on a one-GPU box
@@ -192,8 +193,21 @@ def main():
     if capi.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X (gfx950): " + capi.load().ea_last_error().decode())
 
+    # The barrier of the timed bracket.  Ranks of one node: an epoch barrier through shared memory (a few microseconds;
+    # edge_alignment_amd/dist.py NodeBarrier) -- the closing barrier sits INSIDE the timed region, and a collective-based one
+    # costs as much as the K = 20 steps it brackets.  Anything unexpected: torch.distributed.barrier().
+    node_barrier = None
+    if dist is not None and not args.collective_barrier:
+        try:
+            node_barrier = ead.NodeBarrier(rank, max(world, 1))
+        except Exception as e:
+            sys.stderr.write("bench.py: shared-memory barrier unavailable (%r); using torch.distributed.barrier()\n" % (e,))
+            node_barrier = None
+
     def barrier_sync():
-        if dist is not None:
+        if node_barrier is not None:
+            node_barrier.wait()
+        elif dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -338,7 +352,8 @@ def main():
                            "tiles": B.info("num_tiles"), "points_per_thread": B.info("points_per_thread"),
                            "lds_bytes": B.info("lds_bytes"), "point_order_tile_px": P.point_order,
                            "timed_region": graph or "eager launches",
-                           "closing_barrier_and_sync_ms_on_idle_gpus": bracket_ms},
+                           "closing_barrier_and_sync_ms_on_idle_gpus": bracket_ms,
+                           "bracket_barrier": None if dist is None else ("shared-memory epoch barrier (one node)" if node_barrier is not None else "torch.distributed.barrier")},
                 "roofline": roofline, "materialised_mode": mat}
     extras, others, leg = {}, {}, ["start"]
 
@@ -356,6 +371,11 @@ def main():
         if rank == 0:
             sys.stdout.write(json.dumps(compose("timed out after %.0f s in: %s" % (args.extras_timeout, leg[0]))) + "\n")
             sys.stdout.flush()
+        try:
+            if node_barrier is not None:
+                node_barrier.close()
+        except Exception:
+            pass
         os._exit(0)
     watchdog = threading.Timer(args.extras_timeout, on_timeout)
     watchdog.daemon = True
@@ -634,6 +654,8 @@ def main():
     P.close()
     if dist is not None:
         dist.barrier()
+        if node_barrier is not None:
+            node_barrier.close()
         dist.destroy_process_group()
     watchdog.cancel()
     if rank == 0:

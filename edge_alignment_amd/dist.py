@@ -164,3 +164,61 @@ def run_c4(rank, world_size, build_and_solve, per_gpu=32, device="cpu", total=No
                 "iterations_mean": its / per_gpu, "pose_gather_ms": gather_s * 1e3,
                 "converged": int(sum(1 for s in ss if s["termination"] == 0))})
     return out, (qa, ta, sa)
+
+
+class NodeBarrier:
+    """Barrier for the ranks of ONE node (one process per GPU) through POSIX shared memory: every rank owns a 64-byte line
+    holding the number of the last barrier it has entered; a rank leaves barrier k when every line reads >= k.  A few
+    microseconds per round instead of the tens a collective-based barrier costs -- which matters where the barrier sits
+    INSIDE a timed bracket of ~100 us (bench.py: K = 20 steps of ~3-5 us).  Needs a process group once, for the
+    rendezvous (name of the segment, a check that all ranks share a host); raises on anything unexpected so that the
+    caller can fall back to torch.distributed.barrier()."""
+
+    def __init__(self, rank, world_size):
+        import os
+        import secrets
+        import socket
+        from multiprocessing import resource_tracker, shared_memory
+        import torch.distributed as dist
+        hosts = [None] * world_size
+        dist.all_gather_object(hosts, socket.gethostname())
+        if len(set(hosts)) != 1:
+            raise RuntimeError("ranks live on different hosts: %s" % sorted(set(hosts)))
+        name = ["ea_barrier_%d_%s" % (os.getppid(), secrets.token_hex(4))] if rank == 0 else [None]
+        if rank == 0:
+            self._shm = shared_memory.SharedMemory(name=name[0], create=True, size=64 * world_size)
+            self._shm.buf[:] = bytes(64 * world_size)
+        dist.broadcast_object_list(name, src=0)   # (also orders the creation before the attaches)
+        if rank != 0:
+            self._shm = shared_memory.SharedMemory(name=name[0])
+            try:  # the creator unlinks; an attaching process must not (Python's resource tracker would, at its exit)
+                resource_tracker.unregister(self._shm._name, "shared_memory")
+            except Exception:
+                pass
+        self._slots = np.ndarray((world_size, 8), dtype=np.int64, buffer=self._shm.buf)
+        self.rank, self.world_size, self.epoch = rank, world_size, 0
+        dist.barrier()   # every rank is attached before the first wait
+
+    def wait(self, timeout_s=120.0):
+        import time
+        self.epoch += 1
+        self._slots[self.rank, 0] = self.epoch
+        col = self._slots[:, 0]
+        t0 = None
+        while not (col >= self.epoch).all():
+            if t0 is None:
+                t0 = time.perf_counter()
+            elif time.perf_counter() - t0 > timeout_s:
+                raise TimeoutError("NodeBarrier: rank(s) %s missing at barrier %d" % (np.nonzero(col < self.epoch)[0].tolist(), self.epoch))
+
+    def close(self):
+        shm, self._shm = getattr(self, "_shm", None), None
+        if shm is None:
+            return
+        self._slots = None
+        shm.close()
+        if self.rank == 0:
+            try:
+                shm.unlink()
+            except FileNotFoundError:
+                pass

@@ -181,3 +181,40 @@ def test_pose_gather_single_rank_is_a_copy():
     pg = ead.PoseGather(2, 1)
     q, t, st = pg.gather([[1, 0, 0, 0], [0, 1, 0, 0]], [[1, 2, 3], [4, 5, 6]], [0, 2])
     assert q.tolist() == [[1, 0, 0, 0], [0, 1, 0, 0]] and t.tolist() == [[1, 2, 3], [4, 5, 6]] and st.tolist() == [0, 2]
+
+
+def _barrier_worker(rank, world, port, out_dir):
+    import time
+    import torch.distributed as dist
+    from edge_alignment_amd import dist as ead
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    nb = ead.NodeBarrier(rank, world)
+    # a token only the last rank to arrive can have written must be visible to everybody who leaves the barrier
+    from multiprocessing import shared_memory  # noqa: F401  (the barrier's own segment carries the token: slot column 1)
+    late = 0
+    rng = np.random.default_rng(rank)
+    t0 = time.perf_counter()
+    rounds = 3000
+    for k in range(1, rounds + 1):
+        if rng.random() < 0.02:
+            time.sleep(0.0005)
+        nb._slots[rank, 1] = k          # written before entering barrier k
+        nb.wait()
+        if not (nb._slots[:, 1] >= k).all():
+            late += 1
+    el = time.perf_counter() - t0
+    np.savez(os.path.join(out_dir, "bar%d.npz" % rank), late=late, us=el / rounds * 1e6, epoch=nb.epoch)
+    dist.barrier()
+    nb.close()
+    dist.destroy_process_group()
+
+
+def test_node_barrier_world3(tmp_path):
+    """the shared-memory barrier of bench.py's timed bracket: nobody leaves barrier k before everybody has entered it"""
+    import torch.multiprocessing as mp
+    world = 3
+    mp.spawn(_barrier_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        d = np.load(tmp_path / ("bar%d.npz" % r))
+        assert int(d["late"]) == 0 and int(d["epoch"]) == 3000
+        assert float(d["us"]) < 2000.0
