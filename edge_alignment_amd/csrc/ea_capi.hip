@@ -235,7 +235,7 @@ static int check_device(int device) {
 }
 
 extern "C" const char *ea_last_error(void) { return g_err.c_str(); }
-extern "C" const char *ea_version(void) { return "edge_alignment_amd 0.1 (gfx950)"; }
+extern "C" const char *ea_version(void) { return "edge_alignment_amd 0.2 (gfx950)"; }
 
 extern "C" int ea_device_count(int *count) {
   if (!count) return fail(EA_ERR_INVALID_ARG, "count is NULL");
