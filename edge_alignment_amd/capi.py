@@ -28,7 +28,7 @@ EXPORTED = [
     "ea_problem_set_points_device", "ea_problem_set_dt", "ea_problem_set_dt_image_device",
     "ea_problem_set_loss", "ea_problem_set_flavour", "ea_problem_num_points",
     "ea_eval", "ea_eval_points", "ea_cost", "ea_problem_pixel_cost", "ea_solve",
-    "ea_batch_create", "ea_batch_destroy", "ea_batch_count", "ea_batch_eval", "ea_batch_solve",
+    "ea_release_cached_memory", "ea_batch_create", "ea_batch_destroy", "ea_batch_count", "ea_batch_eval", "ea_batch_solve",
     "ea_solve_pyramid", "ea_solve_sharded", "ea_solve_sharded_device", "ea_tracker_create", "ea_tracker_destroy", "ea_tracker_problem", "ea_tracker_push_frame",
     "ea_batch_bench_eval", "ea_batch_bench_steps", "ea_batch_bench_capture", "ea_batch_bench_capture_pipelined", "ea_batch_bench_result", "ea_batch_bench_result_riding", "ea_batch_bench_kernel", "ea_batch_bench_rows", "ea_batch_row_offsets", "ea_problem_num_rows", "ea_eval_rows", "ea_eval_rows_device", "ea_batch_eval_rows_device", "ea_batch_eval_rows", "ea_batch_bench_fold", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
     "ea_problem_set_ref_frame", "ea_problem_set_ref_frame_masked", "ea_problem_set_now_frame", "ea_problem_debug_now_frame",

@@ -11,6 +11,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
+#include <utility>
 #include <new>
 #include <string>
 #include <thread>
@@ -45,6 +48,8 @@ hipError_t launch_lm_step(const GroupDesc *groups, int count, const double *part
                           LMState *states, LMCold *cold, LMTrace *traces, const LMOptions &opt, int *running_flags,
                           LMState *host_states, LMTrace *host_traces, const GroupDesc &first, hipStream_t stream);
 hipError_t launch_pad_image(int dtype, const void *src, int H, int W, void *dst, int pitch, hipStream_t stream);
+hipError_t launch_grid_to_image(int dtype, const double *grid, int W, int H, void *dst, int pitch, hipStream_t stream);
+hipError_t launch_aos_to_soa(int dtype, const double *src, long long n, int stride, void *x, void *y, void *z, hipStream_t stream);
 hipError_t launch_selftest_reduce(const float *in, float *a, float *b, float *c, float *d, double *o32, double *o64,
                                   hipStream_t stream);
 // ea_preprocess.hip
@@ -107,6 +112,178 @@ struct EventList {
   ~EventList() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); }
 };
 }  // namespace
+
+
+// ---- resource cache -----------------------------------------------------------------------------------------------
+// A fresh problem's first solve used to cost 6 ms against 0.14 ms for the solve itself (scripts/upload_probe.py): three
+// hipMalloc for the points, one for the image, four hipMalloc + four hipHostMalloc + a stream for its batch, and the same
+// number of frees -- each a driver call of 0.1-1 ms, hipFree also a device synchronisation.  That is what the ceres facade
+// pays per ceres::Solve (one ea_problem per ceres::Problem, standalone_edge_align.cpp:256-293).  Freed device blocks,
+// pinned host blocks and streams are therefore kept and handed out again: device blocks to any request they fit without
+// wasting more than half, pinned blocks to requests of exactly their size and flags, streams to the next batch of the
+// device.  Bounded (kCacheMaxBytes per kind, kCacheMaxEntries blocks); ea_release_cached_memory() returns everything
+// to the driver.  A block is only put here by code that has drained the stream whose kernels may still WRITE it; kernels
+// of finished solves that are still queued only read (and discard) what the next owner may already be overwriting.
+namespace {
+struct CachedBlock { void *p; size_t bytes; int device; unsigned flags; };
+struct ResourceCache {
+  std::mutex mu;
+  std::vector<CachedBlock> dev, pinned;
+  std::vector<std::pair<int, hipStream_t>> streams;
+  std::unordered_map<void *, CachedBlock> live;  // what is handed out (size / device / flags of a pointer)
+  size_t dev_bytes = 0, pinned_bytes = 0;
+};
+ResourceCache &cache() { static ResourceCache *c = new ResourceCache; return *c; }  // (never destroyed: frees at exit race the runtime's teardown)
+constexpr size_t kCacheMaxBytes = (size_t)1 << 30;
+constexpr size_t kCacheMaxEntries = 256;
+
+hipError_t cached_malloc(void **out, size_t bytes, int device) {
+  *out = nullptr;
+  if (bytes == 0) bytes = 256;
+  bytes = (bytes + 255) & ~(size_t)255;
+  ResourceCache &c = cache();
+  {
+    std::lock_guard<std::mutex> g(c.mu);
+    size_t best = (size_t)-1;
+    for (size_t i = 0; i < c.dev.size(); ++i)
+      if (c.dev[i].device == device && c.dev[i].bytes >= bytes && c.dev[i].bytes <= 2 * bytes + 4096 &&
+          (best == (size_t)-1 || c.dev[i].bytes < c.dev[best].bytes))
+        best = i;
+    if (best != (size_t)-1) {
+      CachedBlock blk = c.dev[best];
+      c.dev.erase(c.dev.begin() + (long)best);
+      c.dev_bytes -= blk.bytes;
+      c.live[blk.p] = blk;
+      *out = blk.p;
+      return hipSuccess;
+    }
+  }
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {  // the cache may be what is in the way: give it back and try once more
+    (void)hipGetLastError();
+    extern void release_cached_memory_locked_free();
+    release_cached_memory_locked_free();
+    e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return e;
+  }
+  std::lock_guard<std::mutex> g(c.mu);
+  c.live[p] = CachedBlock{p, bytes, device, 0u};
+  *out = p;
+  return hipSuccess;
+}
+
+void cached_free(void *p) {
+  if (!p) return;
+  ResourceCache &c = cache();
+  CachedBlock blk{p, 0, -1, 0u};
+  {
+    std::lock_guard<std::mutex> g(c.mu);
+    auto it = c.live.find(p);
+    if (it != c.live.end()) {
+      blk = it->second;
+      c.live.erase(it);
+      if (c.dev_bytes + blk.bytes <= kCacheMaxBytes && c.dev.size() < kCacheMaxEntries) {
+        c.dev.push_back(blk);
+        c.dev_bytes += blk.bytes;
+        return;
+      }
+    }
+  }
+  (void)hipFree(p);
+}
+
+hipError_t cached_host_malloc(void **out, size_t bytes, unsigned flags, int device) {
+  *out = nullptr;
+  if (bytes == 0) bytes = 64;
+  ResourceCache &c = cache();
+  {
+    std::lock_guard<std::mutex> g(c.mu);
+    for (size_t i = 0; i < c.pinned.size(); ++i)
+      if (c.pinned[i].bytes == bytes && c.pinned[i].flags == flags && c.pinned[i].device == device) {
+        CachedBlock blk = c.pinned[i];
+        c.pinned.erase(c.pinned.begin() + (long)i);
+        c.pinned_bytes -= blk.bytes;
+        c.live[blk.p] = blk;
+        *out = blk.p;
+        return hipSuccess;
+      }
+  }
+  void *p = nullptr;
+  const hipError_t e = hipHostMalloc(&p, bytes, flags);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> g(c.mu);
+  c.live[p] = CachedBlock{p, bytes, device, flags};
+  *out = p;
+  return hipSuccess;
+}
+
+void cached_host_free(void *p) {
+  if (!p) return;
+  ResourceCache &c = cache();
+  {
+    std::lock_guard<std::mutex> g(c.mu);
+    auto it = c.live.find(p);
+    if (it != c.live.end()) {
+      const CachedBlock blk = it->second;
+      c.live.erase(it);
+      if (c.pinned_bytes + blk.bytes <= kCacheMaxBytes / 4 && c.pinned.size() < kCacheMaxEntries) {
+        c.pinned.push_back(blk);
+        c.pinned_bytes += blk.bytes;
+        return;
+      }
+    }
+  }
+  (void)hipHostFree(p);
+}
+
+hipError_t cached_stream_create(hipStream_t *out, int device) {
+  ResourceCache &c = cache();
+  {
+    std::lock_guard<std::mutex> g(c.mu);
+    for (size_t i = 0; i < c.streams.size(); ++i)
+      if (c.streams[i].first == device) {
+        *out = c.streams[i].second;
+        c.streams.erase(c.streams.begin() + (long)i);
+        return hipSuccess;
+      }
+  }
+  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+void cached_stream_destroy(hipStream_t s, int device) {  // (the caller has synchronised it)
+  if (!s) return;
+  ResourceCache &c = cache();
+  {
+    std::lock_guard<std::mutex> g(c.mu);
+    if (c.streams.size() < 64) { c.streams.emplace_back(device, s); return; }
+  }
+  (void)hipStreamDestroy(s);
+}
+
+void release_cached_memory_locked_free() {
+  ResourceCache &c = cache();
+  std::vector<CachedBlock> dev, pinned;
+  std::vector<std::pair<int, hipStream_t>> streams;
+  {
+    std::lock_guard<std::mutex> g(c.mu);
+    dev.swap(c.dev); pinned.swap(c.pinned); streams.swap(c.streams);
+    c.dev_bytes = c.pinned_bytes = 0;
+  }
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+  for (const CachedBlock &b : dev) { (void)hipSetDevice(b.device); (void)hipFree(b.p); }
+  for (const CachedBlock &b : pinned) (void)hipHostFree(b.p);
+  for (auto &st : streams) { (void)hipSetDevice(st.first); (void)hipStreamDestroy(st.second); }
+  if (cur >= 0) (void)hipSetDevice(cur);
+  (void)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int ea_release_cached_memory(void) {
+  release_cached_memory_locked_free();
+  return EA_OK;
+}
 
 struct ea_problem {
   int device = 0;
@@ -313,7 +490,7 @@ extern "C" int ea_problem_create(ea_problem **out, const ea_camera *cam, int dty
 
 static void free_points(ea_problem *p) {
   if (p->own_points) {
-    (void)hipFree(p->d_x); (void)hipFree(p->d_y); (void)hipFree(p->d_z);
+    cached_free(p->d_x); cached_free(p->d_y); cached_free(p->d_z);
   }
   p->d_x = p->d_y = p->d_z = nullptr;
   p->own_points = false;
@@ -336,9 +513,9 @@ static int reserve_points(ea_problem *p, int64_t n) {
   free_points(p);
   if (n == 0) return EA_OK;
   p->own_points = true;  // (before the allocations: a failure half-way leaves what was allocated to free_points)
-  HIPCHK(hipMalloc(&p->d_x, need));
-  HIPCHK(hipMalloc(&p->d_y, need));
-  HIPCHK(hipMalloc(&p->d_z, need));
+  HIPCHK(cached_malloc(&p->d_x, need, p->device));
+  HIPCHK(cached_malloc(&p->d_y, need, p->device));
+  HIPCHK(cached_malloc(&p->d_z, need, p->device));
   p->pts_cap = need;
   return EA_OK;
 }
@@ -380,9 +557,9 @@ extern "C" void ea_problem_destroy(ea_problem *p) {
   (void)hipSetDevice(p->device);
   if (p->self) ea_batch_destroy(p->self);
   free_points(p);
-  if (p->d_dt) (void)hipFree(p->d_dt);
-  if (p->ws) (void)hipFree(p->ws);
-  if (p->stage) (void)hipFree(p->stage);
+  if (p->d_dt) cached_free(p->d_dt);
+  if (p->ws) cached_free(p->ws);
+  if (p->stage) cached_free(p->stage);
   delete p;
 }
 
@@ -446,9 +623,27 @@ extern "C" int ea_problem_set_points(ea_problem *p, const double *xyz, int64_t n
   p->version++;
   if (n == 0) { free_points(p); return EA_OK; }
   const size_t esz = p->dtype == EA_F32 ? 4 : 8;
+  const int tile = p->order_tile < 0 ? (n >= kAutoOrderPoints ? 16 : 0) : p->order_tile;
+  if (tile == 0 && stride <= 8) {
+    // the caller's order, compact AoS: the array goes up as it is (one copy) and is split into x[], y[], z[] of the
+    // problem's dtype on the device -- no host pass over the points, one upload instead of three
+    int rc = reserve_points(p, n);
+    if (rc != EA_OK) return rc;
+    const size_t raw = ((size_t)(n - 1) * (size_t)stride + 3) * sizeof(double);
+    void *d_raw = nullptr;
+    HIPCHK(cached_malloc(&d_raw, raw, p->device));
+    hipError_t e = hipMemcpy(d_raw, xyz, raw, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_aos_to_soa(p->dtype, static_cast<const double *>(d_raw), n, (int)stride, p->d_x, p->d_y, p->d_z, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    cached_free(d_raw);
+    if (e != hipSuccess) { free_points(p); return fail(EA_ERR_HIP, std::string("ea_problem_set_points: ") + hipGetErrorString(e)); }
+    p->n = n;
+    p->order.clear();
+    p->order_tile_used = 0;
+    return EA_OK;
+  }
   std::vector<unsigned char> soa(3 * (size_t)n * esz);
   std::vector<int32_t> order;
-  const int tile = p->order_tile < 0 ? (n >= kAutoOrderPoints ? 16 : 0) : p->order_tile;
   if (tile > 0) tile_order(p, xyz, n, stride, tile, order);
   const int32_t *ord = order.empty() ? nullptr : order.data();
   for (int c = 0; c < 3; ++c) {
@@ -504,8 +699,8 @@ static int alloc_dt(ea_problem *p, int W, int H) {
   const size_t esz = p->dtype == EA_F32 ? 4 : 8;
   const size_t need = (size_t)p->pitch * (size_t)(H + 2 * kImagePad) * esz;
   if (p->d_dt && p->dt_cap >= need && p->dt_cap <= 4 * need) return EA_OK;  // same-size frame: keep the allocation
-  if (p->d_dt) { (void)hipFree(p->d_dt); p->d_dt = nullptr; p->dt_cap = 0; }
-  HIPCHK(hipMalloc(&p->d_dt, need));
+  if (p->d_dt) { cached_free(p->d_dt); p->d_dt = nullptr; p->dt_cap = 0; }
+  HIPCHK(cached_malloc(&p->d_dt, need, p->device));
   p->dt_cap = need;
   return EA_OK;
 }
@@ -519,19 +714,16 @@ extern "C" int ea_problem_set_dt(ea_problem *p, const double *data, int grid_row
   const int W = grid_rows, H = grid_cols;
   int rc = alloc_dt(p, W, H);
   if (rc != EA_OK) return rc;
-  const size_t esz = p->dtype == EA_F32 ? 4 : 8;
-  const int PH = H + 2 * kImagePad, PW = W + 2 * kImagePad;
-  std::vector<unsigned char> img((size_t)p->pitch * PH * esz, 0);
-  for (int v = 0; v < PH; ++v) {
-    const int sv = std::min(std::max(v - kImagePad, 0), H - 1);
-    for (int u = 0; u < PW; ++u) {
-      const int su = std::min(std::max(u - kImagePad, 0), W - 1);
-      const double val = data[(size_t)su * (size_t)grid_cols + sv];
-      if (p->dtype == EA_F32) reinterpret_cast<float *>(img.data())[(size_t)v * p->pitch + u] = (float)val;
-      else reinterpret_cast<double *>(img.data())[(size_t)v * p->pitch + u] = val;
-    }
-  }
-  HIPCHK(hipMemcpy(p->d_dt, img.data(), img.size(), hipMemcpyHostToDevice));
+  // The grid goes up as it is (one contiguous copy) and is transposed, bordered and converted on the device: the host loop
+  // this replaces read the caller's array with a stride of one grid row per element (0.28 -> 0.1x ms per 640 x 480 frame).
+  const size_t raw = (size_t)W * (size_t)H * sizeof(double);
+  void *d_raw = nullptr;
+  HIPCHK(cached_malloc(&d_raw, raw, p->device));
+  hipError_t e = hipMemcpy(d_raw, data, raw, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = launch_grid_to_image(p->dtype, static_cast<const double *>(d_raw), W, H, p->d_dt, p->pitch, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  cached_free(d_raw);
+  if (e != hipSuccess) return fail(EA_ERR_HIP, std::string("ea_problem_set_dt: ") + hipGetErrorString(e));
   p->version++;
   return EA_OK;
 }
@@ -584,11 +776,11 @@ static void batch_free_device(ea_batch *b) {
   if (b->bench_e1) { (void)hipEventDestroy(b->bench_e1); b->bench_e1 = nullptr; }
   (void)hipFree(b->d_one_row); b->d_one_row = nullptr;
   if (b->round_done) { (void)hipEventDestroy(b->round_done); b->round_done = nullptr; }
-  (void)hipFree(b->d_probs); (void)hipFree(b->d_groups); (void)hipFree(b->d_lm_block); (void)hipFree(b->d_cold);
-  (void)hipFree(b->d_partials); (void)hipFree(b->d_out);
-  (void)hipHostFree(b->h_lm_block); (void)hipHostFree(b->h_out);
-  (void)hipHostFree(b->h_progress); (void)hipHostFree(b->h_deliver);
-  if (b->h_desc) (void)hipHostFree(b->h_desc);
+  cached_free(b->d_probs); cached_free(b->d_groups); cached_free(b->d_lm_block); cached_free(b->d_cold);
+  cached_free(b->d_partials); cached_free(b->d_out);
+  cached_host_free(b->h_lm_block); cached_host_free(b->h_out);
+  cached_host_free(b->h_progress); cached_host_free(b->h_deliver);
+  if (b->h_desc) cached_host_free(b->h_desc);
   if (b->desc_done) (void)hipEventDestroy(b->desc_done);
   b->h_desc = nullptr; b->h_desc_cap = 0; b->desc_done = nullptr;
   b->d_probs = nullptr; b->d_groups = nullptr; b->d_poses = nullptr; b->d_partials = nullptr; b->d_traces = nullptr; b->d_cold = nullptr; b->d_lm_block = nullptr;
@@ -611,21 +803,21 @@ extern "C" int ea_batch_create(ea_batch **out, ea_problem *const *problems, int 
   b->device = problems[0]->device;
   b->dtype = problems[0]->dtype;
   hipError_t e = hipSetDevice(b->device);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = cached_stream_create(&b->stream, b->device);
   if (e != hipSuccess) { delete b; return fail(EA_ERR_HIP, hipGetErrorString(e)); }
   b->own_stream = true;
   const size_t c = (size_t)count;
   const size_t lm_bytes = c * (sizeof(LMState) + sizeof(LMTrace) + sizeof(PoseState));
-  e = hipMalloc(&b->d_groups, c * sizeof(GroupDesc));
-  if (e == hipSuccess) e = hipMalloc(&b->d_lm_block, lm_bytes);
-  if (e == hipSuccess) e = hipMalloc(&b->d_out, c * sizeof(EvalOut));
-  if (e == hipSuccess) e = hipMalloc(&b->d_cold, c * sizeof(LMCold));
-  if (e == hipSuccess) e = hipHostMalloc(&b->h_lm_block, lm_bytes);
-  if (e == hipSuccess) e = hipHostMalloc(&b->h_out, c * sizeof(EvalOut), hipHostMallocMapped);
+  e = cached_malloc(reinterpret_cast<void **>(&b->d_groups), c * sizeof(GroupDesc), b->device);
+  if (e == hipSuccess) e = cached_malloc(reinterpret_cast<void **>(&b->d_lm_block), lm_bytes, b->device);
+  if (e == hipSuccess) e = cached_malloc(reinterpret_cast<void **>(&b->d_out), c * sizeof(EvalOut), b->device);
+  if (e == hipSuccess) e = cached_malloc(reinterpret_cast<void **>(&b->d_cold), c * sizeof(LMCold), b->device);
+  if (e == hipSuccess) e = cached_host_malloc(reinterpret_cast<void **>(&b->h_lm_block), lm_bytes, hipHostMallocDefault, b->device);
+  if (e == hipSuccess) e = cached_host_malloc(reinterpret_cast<void **>(&b->h_out), c * sizeof(EvalOut), hipHostMallocMapped, b->device);
   if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&b->dv_out), b->h_out, 0);
-  if (e == hipSuccess) e = hipHostMalloc(&b->h_progress, 2 * c * sizeof(int), hipHostMallocMapped);
+  if (e == hipSuccess) e = cached_host_malloc(reinterpret_cast<void **>(&b->h_progress), 2 * c * sizeof(int), hipHostMallocMapped, b->device);
   if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&b->d_progress), b->h_progress, 0);
-  if (e == hipSuccess) e = hipHostMalloc(&b->h_deliver, c * (sizeof(LMState) + sizeof(LMTrace)), hipHostMallocMapped);
+  if (e == hipSuccess) e = cached_host_malloc(reinterpret_cast<void **>(&b->h_deliver), c * (sizeof(LMState) + sizeof(LMTrace)), hipHostMallocMapped, b->device);
   if (e == hipSuccess) {
     unsigned char *dv = nullptr;
     e = hipHostGetDevicePointer(reinterpret_cast<void **>(&dv), b->h_deliver, 0);
@@ -651,8 +843,9 @@ extern "C" int ea_batch_create(ea_batch **out, ea_problem *const *problems, int 
     std::memset(b->h_deliver, 0, c * (sizeof(LMState) + sizeof(LMTrace)));
   }
   if (e != hipSuccess) {
+    (void)hipStreamSynchronize(b->stream);
     batch_free_device(b);
-    (void)hipStreamDestroy(b->stream);
+    cached_stream_destroy(b->stream, b->device);
     delete b;
     return fail(EA_ERR_ALLOC, std::string("batch allocation: ") + hipGetErrorString(e));
   }
@@ -667,7 +860,7 @@ extern "C" void ea_batch_destroy(ea_batch *b) {
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   batch_free_device(b);
-  if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
+  if (b->own_stream && b->stream) cached_stream_destroy(b->stream, b->device);  // (synchronised above)
   for (ea_problem *p : b->probs)
     if (p && p->self == b) p->self = nullptr;
   delete b;
@@ -828,20 +1021,20 @@ static int batch_build(ea_batch *b) {
   b->total_rows = row_begin;
   b->max_n = max_n;
   if (b->nterms > b->terms_cap) {
-    (void)hipFree(b->d_probs);
+    cached_free(b->d_probs);
     b->d_probs = nullptr;
     b->terms_cap = b->nterms + 8;
-    HIPCHK(hipMalloc(&b->d_probs, (size_t)b->terms_cap * sizeof(ProblemDesc)));
+    HIPCHK(cached_malloc(reinterpret_cast<void **>(&b->d_probs), (size_t)b->terms_cap * sizeof(ProblemDesc), b->device));
   }
   if (b->t_test_fail_build) {  // (tests/test_gpu_robustness.py: a build that fails here must leave the batch dirty)
     b->t_test_fail_build = 0;
     return fail(EA_ERR_ALLOC, "batch build: injected allocation failure (test hook)");
   }
   if (b->ntiles > b->tiles_cap) {
-    (void)hipFree(b->d_partials);
+    cached_free(b->d_partials);
     b->d_partials = nullptr;
     b->tiles_cap = b->ntiles + b->ntiles / 4 + 16;
-    HIPCHK(hipMalloc(&b->d_partials, (size_t)b->tiles_cap * kAccSlots * sizeof(double)));
+    HIPCHK(cached_malloc(reinterpret_cast<void **>(&b->d_partials), (size_t)b->tiles_cap * kAccSlots * sizeof(double), b->device));
     // (stream-ordered on the batch's own stream: a null-stream memset is not ordered with a non-blocking stream and may
     // land after the first evaluation has written its rows)
     HIPCHK(hipMemsetAsync(b->d_partials, 0, (size_t)b->tiles_cap * kAccSlots * sizeof(double), b->stream));
@@ -851,10 +1044,10 @@ static int batch_build(ea_batch *b) {
     if (!b->desc_done) HIPCHK(hipEventCreateWithFlags(&b->desc_done, hipEventDisableTiming));
     else HIPCHK(hipEventSynchronize(b->desc_done));  // the staging block is free again (it always is by now)
     if (b->h_desc_cap < pb + gb) {
-      if (b->h_desc) (void)hipHostFree(b->h_desc);
+      if (b->h_desc) cached_host_free(b->h_desc);
       b->h_desc = nullptr;
-      b->h_desc_cap = (pb + gb) * 2 + 1024;
-      HIPCHK(hipHostMalloc(&b->h_desc, b->h_desc_cap));
+      b->h_desc_cap = ((pb + gb) * 2 + 1024 + 4095) & ~(size_t)4095;  // (whole pages: batches of equal shape find each other's block)
+      HIPCHK(cached_host_malloc(reinterpret_cast<void **>(&b->h_desc), b->h_desc_cap, hipHostMallocDefault, b->device));
     }
     std::memcpy(b->h_desc, descs.data(), pb);
     std::memcpy(b->h_desc + pb, groups.data(), gb);
@@ -2063,8 +2256,8 @@ struct WsCarver {
 static int ensure_ws(ea_problem *p, size_t bytes) {
   p->ws_now_kind = 0;  // every producer starts by calling this: whatever the workspace held is about to be overwritten
   if (p->ws_bytes >= bytes) return EA_OK;
-  if (p->ws) { (void)hipFree(p->ws); p->ws = nullptr; p->ws_bytes = 0; }
-  HIPCHK(hipMalloc(&p->ws, bytes));
+  if (p->ws) { cached_free(p->ws); p->ws = nullptr; p->ws_bytes = 0; }
+  HIPCHK(cached_malloc(reinterpret_cast<void **>(&p->ws), bytes, p->device));
   p->ws_bytes = bytes;
   return EA_OK;
 }
@@ -2346,8 +2539,8 @@ static int stage_scaled(ea_problem *p, const uint8_t *bgr, const float *depth, i
   // stage: [bgr full | depth full | bgr half | depth half] (the ping-pong partner of the full-size pair)
   const size_t need = np * 3 + np * 4 + np / 4 * 3 + np / 4 * 4 + 1024;
   if (p->stage_bytes < need) {
-    if (p->stage) { (void)hipFree(p->stage); p->stage = nullptr; p->stage_bytes = 0; }
-    HIPCHK(hipMalloc(&p->stage, need));
+    if (p->stage) { cached_free(p->stage); p->stage = nullptr; p->stage_bytes = 0; }
+    HIPCHK(cached_malloc(reinterpret_cast<void **>(&p->stage), need, p->device));
     p->stage_bytes = need;
   }
   WsCarver st{p->stage};

@@ -1611,6 +1611,40 @@ __global__ void ea_pad_image_kernel(const T *__restrict__ src, int H, int W, T *
   const int sv = min(max(v - kImagePad, 0), H - 1);
   dst[(size_t)v * pitch + u] = src[(size_t)sv * W + su];
 }
+
+// The reference's Grid2D view (rows index u, columns index v: data[u * H + v], doubles; standalone_edge_align.cpp:258) ->
+// the padded image in the problem's dtype: transpose, replicate the border, convert.  A 32 x 32 tile goes through LDS so
+// that both the reads (v contiguous in the source) and the writes (u contiguous in the image) are coalesced.
+template <typename T>
+__global__ __launch_bounds__(256) void ea_grid_to_image_kernel(const double *__restrict__ grid, int W, int H, T *__restrict__ dst, int pitch) {
+  __shared__ double s_tile[32][33];
+  const int PW = W + 2 * kImagePad, PH = H + 2 * kImagePad;
+  const int u0 = blockIdx.x * 32, v0 = blockIdx.y * 32;   // padded coordinates of the tile
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8 threads
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    // source element (u, v): v runs with tx (contiguous in the grid), u with ty + 8 k
+    const int u = u0 + ty + 8 * k, v = v0 + tx;
+    const int su = min(max(u - kImagePad, 0), W - 1), sv = min(max(v - kImagePad, 0), H - 1);
+    s_tile[ty + 8 * k][tx] = grid[(size_t)su * H + sv];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int v = v0 + ty + 8 * k, u = u0 + tx;
+    if (v < PH && u < PW) dst[(size_t)v * pitch + u] = (T)s_tile[tx][ty + 8 * k];
+  }
+}
+
+// the reference's AoS points (columns of a_X: x y z [w] per point, doubles; utils.cpp:268-280) -> SoA in the problem's dtype
+template <typename T>
+__global__ __launch_bounds__(256) void ea_aos_to_soa_kernel(const double *__restrict__ src, long long n, int stride, T *__restrict__ x,
+                                                            T *__restrict__ y, T *__restrict__ z) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double *s = src + i * stride;
+  x[i] = (T)s[0]; y[i] = (T)s[1]; z[i] = (T)s[2];
+}
 #endif  // !EA_TU_VARIANT
 
 // ------------------------------------------------------------------------------------------------
@@ -1814,6 +1848,21 @@ hipError_t launch_pad_image(int dtype, const void *src, int H, int W, void *dst,
     hipLaunchKernelGGL((ea_pad_image_kernel<float>), grid, block, 0, stream, (const float *)src, H, W, (float *)dst, pitch);
   else
     hipLaunchKernelGGL((ea_pad_image_kernel<double>), grid, block, 0, stream, (const double *)src, H, W, (double *)dst, pitch);
+  return hipGetLastError();
+}
+
+hipError_t launch_aos_to_soa(int dtype, const double *src, long long n, int stride, void *x, void *y, void *z, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (dtype == 1) hipLaunchKernelGGL((ea_aos_to_soa_kernel<float>), grid, dim3(256), 0, stream, src, n, stride, (float *)x, (float *)y, (float *)z);
+  else hipLaunchKernelGGL((ea_aos_to_soa_kernel<double>), grid, dim3(256), 0, stream, src, n, stride, (double *)x, (double *)y, (double *)z);
+  return hipGetLastError();
+}
+
+hipError_t launch_grid_to_image(int dtype, const double *grid, int W, int H, void *dst, int pitch, hipStream_t stream) {
+  dim3 block(256), tiles((W + 2 * kImagePad + 31) / 32, (H + 2 * kImagePad + 31) / 32);
+  if (dtype == 1) hipLaunchKernelGGL((ea_grid_to_image_kernel<float>), tiles, block, 0, stream, grid, W, H, (float *)dst, pitch);
+  else hipLaunchKernelGGL((ea_grid_to_image_kernel<double>), tiles, block, 0, stream, grid, W, H, (double *)dst, pitch);
   return hipGetLastError();
 }
 

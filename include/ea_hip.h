@@ -117,6 +117,11 @@ typedef struct ea_batch ea_batch;     /* several problems evaluated / solved by 
 
 /* ---- library ------------------------------------------------------------------------- */
 const char *ea_last_error(void);
+/* Device blocks, pinned host blocks and streams freed by ea_problem_destroy / ea_batch_destroy (and by re-sizing calls) are
+ * kept by the library and handed out again (bounded: 1 GiB of device memory, 256 MiB pinned): creating and destroying an
+ * ea_problem per solve -- what the ceres facade does per ceres::Solve -- then costs no driver allocation.  This returns
+ * everything that is cached to the driver. */
+int ea_release_cached_memory(void);
 const char *ea_version(void);
 int ea_device_count(int *count);            /* number of gfx950 devices visible */
 void ea_default_options(ea_options *opt);   /* ceres::Solver::Options() defaults used by test1 */

@@ -90,3 +90,40 @@ def test_failed_descriptor_build_leaves_the_batch_dirty(hip):
     want = Pref.eval(Q0, T0)
     assert g1["cost"][0] == want["cost"] and np.array_equal(g1["JtJ"][0], want["JtJ"]) and g1["cost"][0] != g0["cost"][0]
     B.close(); P.close(); Pref.close()
+
+
+def test_resource_cache_hands_blocks_to_the_next_problem_without_changing_results(hip):
+    """ea_problem_destroy / ea_batch_destroy keep their device blocks, pinned blocks and streams for the next owner (what
+    makes a problem per ceres::Solve affordable).  A problem built on recycled blocks -- larger, smaller, another dtype,
+    after a solve whose queued-ahead launches were still draining -- evaluates and solves to the same bits as the first time;
+    ea_release_cached_memory() gives everything back and the next problem still works."""
+    import time
+    L = hip.load()
+    pr_a = synth.make_problem(120, 160, 9000, 40, 1, 130.0, 130.0, 79.5, 59.5, planted_q=synth.quat_from_axis_angle([1, 2, 3], 0.01),
+                              planted_t=(0.01, -0.005, 0.02), normalize=True)
+    pr_b = synth.make_problem(96, 128, 2500, 12, 5, 120.0, 121.0, 63.5, 47.5, planted_q=synth.quat_from_axis_angle([3, 1, 2], 0.008),
+                              planted_t=(0.0, 0.01, 0.005), normalize=True)
+    q0, t0 = np.array([1.0, 0, 0, 0]), np.zeros(3)
+
+    def run(pr, dtype):
+        P = hip.Problem(*pr["K"], dtype=dtype)
+        P.set_points(pr["xyz"]); P.set_dt_grid(pr["grid"]); P.set_loss(hip.LOSS_CAUCHY, 1.0)
+        g = P.eval(q0, t0)
+        q, t, s = P.solve(q0, t0)
+        r, J, bad = P.eval_rows(q, t)
+        P.close()   # (launches queued past the end of the solve may still be draining here)
+        return g["cost"], g["JtJ"].copy(), q.copy(), t.copy(), s["num_iterations"], r.copy()
+
+    assert L.ea_release_cached_memory() == 0
+    first = {(k, d): run(pr, d) for k, pr in (("a", pr_a), ("b", pr_b)) for d in (hip.EA_F64, hip.EA_F32)}
+    t_fresh = time.perf_counter(); run(pr_a, hip.EA_F64); t_fresh = time.perf_counter() - t_fresh
+    order = [("a", hip.EA_F64), ("b", hip.EA_F32), ("b", hip.EA_F64), ("a", hip.EA_F32), ("a", hip.EA_F64), ("b", hip.EA_F64)] * 3
+    for k, d in order:
+        got = run(pr_a if k == "a" else pr_b, d)
+        want = first[(k, d)]
+        assert got[0] == want[0] and np.array_equal(got[1], want[1]), (k, d)
+        assert np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3]) and got[4] == want[4], (k, d)
+        assert np.array_equal(got[5], want[5]), (k, d)
+    assert L.ea_release_cached_memory() == 0
+    got = run(pr_b, hip.EA_F64)
+    assert got[0] == first[("b", hip.EA_F64)][0] and np.array_equal(got[2], first[("b", hip.EA_F64)][2])
