@@ -95,9 +95,11 @@ static int fail(int code, const std::string &msg) {
 
 // scope guards for the temporaries of the measurement / test hooks, so that an early HIPCHK return frees them
 namespace {
+hipError_t cached_malloc(void **out, size_t bytes, int device);  // (the resource cache below)
+void cached_free(void *p);
 struct DevBuf {
   void *p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  ~DevBuf() { if (p) cached_free(p); }  // (blocks that did not come from the cache fall through to hipFree)
   template <typename U> U *as() const { return static_cast<U *>(p); }
 };
 struct EventPair {
@@ -1882,7 +1884,7 @@ extern "C" int ea_problem_pixel_cost(ea_problem *p, const double q[4], const dou
   struct Partial { double sum, max, max_u, max_v; long long max_index, inside, outside, pad_; };
   const int nwg = (int)((p->n + kBlockThreads - 1) / kBlockThreads);
   DevBuf buf;
-  HIPCHK(hipMalloc(&buf.p, (size_t)nwg * sizeof(Partial)));
+  HIPCHK(cached_malloc(&buf.p, (size_t)nwg * sizeof(Partial), p->device));
   HIPCHK(launch_pixel_cost(p->dtype, b->d_probs, 0, (int)p->n, b->d_poses, buf.p, b->stream));
   std::vector<Partial> parts((size_t)nwg);
   HIPCHK(hipMemcpyAsync(parts.data(), buf.p, (size_t)nwg * sizeof(Partial), hipMemcpyDeviceToHost, b->stream));
@@ -1911,8 +1913,8 @@ extern "C" int ea_eval_points(ea_problem *p, const double q[4], const double t[3
   rc = batch_upload_poses(b, q, t);
   if (rc != EA_OK) return rc;
   DevBuf buf_r, buf_J;
-  if (r) HIPCHK(hipMalloc(&buf_r.p, p->n * sizeof(double)));
-  if (J) HIPCHK(hipMalloc(&buf_J.p, p->n * 6 * sizeof(double)));
+  if (r) HIPCHK(cached_malloc(&buf_r.p, p->n * sizeof(double), p->device));
+  if (J) HIPCHK(cached_malloc(&buf_J.p, p->n * 6 * sizeof(double), p->device));
   double *d_r = buf_r.as<double>(), *d_J = buf_J.as<double>();
   hipError_t e = launch_eval_points(p->dtype, b->d_probs, 0, (int)p->n, b->d_poses, d_r, d_J, corrected, b->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
@@ -2685,8 +2687,8 @@ extern "C" int ea_resize_half(int device, int kind, const void *src, int height,
   HIPCHK(hipSetDevice(device));
   const size_t np = (size_t)height * width, es = kind == 0 ? 3 : 4;
   DevBuf a, b;
-  HIPCHK(hipMalloc(&a.p, np * es));
-  HIPCHK(hipMalloc(&b.p, np / 4 * es));
+  HIPCHK(cached_malloc(&a.p, np * es, device));
+  HIPCHK(cached_malloc(&b.p, np / 4 * es, device));
   HIPCHK(hipMemcpy(a.p, src, np * es, hipMemcpyHostToDevice));
   if (kind == 0) HIPCHK(launch_resize_half_bgr8(a.as<uint8_t>(), height, width, b.as<uint8_t>(), nullptr));
   else HIPCHK(launch_resize_half_f32(a.as<float>(), height, width, b.as<float>(), kind == 1 ? 1 : 0, nullptr));
