@@ -206,7 +206,7 @@ def main():
 
     def barrier_sync():
         if node_barrier is not None:
-            node_barrier.wait()
+            node_barrier.wait(timeout_s=3600.0)   # (a missing rank: the watchdog below prints the line, as with a collective barrier)
         elif dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
