@@ -316,7 +316,12 @@ class ProblemAccess {  // keeps Problem's internals private to user code
       Family *f = nullptr;
       for (auto &cand : fams)
         if (SameFamily(*cand.first, b)) { f = &cand; break; }
-      if (!f) { fams.push_back(Family{&b, {}, {}}); f = &fams.back(); }
+      if (!f) {
+        fams.push_back(Family{&b, {}, {}});
+        f = &fams.back();
+        f->xyz.reserve(3 * (blocks.size() - i));  // (usually the one family: no regrowth while 44 457 blocks are gathered)
+        f->idx.reserve(blocks.size() - i);
+      }
       f->xyz.push_back(b.info.X); f->xyz.push_back(b.info.Y); f->xyz.push_back(b.info.Z);
       f->idx.push_back((int)i);
     }
