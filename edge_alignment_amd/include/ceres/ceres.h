@@ -450,9 +450,12 @@ class ProblemAccess {  // keeps Problem's internals private to user code
     if (x.fx != y.fx || x.fy != y.fy || x.cx != y.cx || x.cy != y.cy) return false;
     if (x.z_guard != y.z_guard || x.z_eps != y.z_eps || x.rot_transposed != y.rot_transposed) return false;
     if (x.variant != y.variant) return false;
-    for (int i = 0; i < 5; ++i) if (x.dist[i] != y.dist[i]) return false;
-    for (int i = 0; i < 16; ++i) if (x.T12[i] != y.T12[i] || x.T12inv[i] != y.T12inv[i]) return false;
-    return SameLoss(a.loss, b.loss);
+    // (only what the variant uses: the plain functor's 44 457 blocks are compared once each while they are gathered)
+    if (x.variant & 1)
+      for (int i = 0; i < 5; ++i) if (x.dist[i] != y.dist[i]) return false;
+    if (x.variant & 2)
+      for (int i = 0; i < 16; ++i) if (x.T12[i] != y.T12[i] || x.T12inv[i] != y.T12inv[i]) return false;
+    return a.loss == b.loss || SameLoss(a.loss, b.loss);
   }
   static bool SameLoss(const LossFunction *a, const LossFunction *b) {
     const int ka = a ? a->ea_kind() : EA_LOSS_TRIVIAL, kb = b ? b->ea_kind() : EA_LOSS_TRIVIAL;
