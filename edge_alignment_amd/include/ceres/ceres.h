@@ -16,6 +16,7 @@
 #include <memory>
 #include <sstream>
 #include <string>
+#include <algorithm>
 #include <unordered_set>
 #include <vector>
 
@@ -150,6 +151,9 @@ class Problem {
   Problem() {}
   ~Problem() {
     for (auto *c : costs_) delete c;
+    // a loss object may have been handed to several blocks (Ceres allows it): delete each once
+    if (!std::is_sorted(losses_.begin(), losses_.end())) std::sort(losses_.begin(), losses_.end());
+    losses_.erase(std::unique(losses_.begin(), losses_.end()), losses_.end());
     for (auto *l : losses_) delete l;
     for (auto *p : params_) delete p;
   }
@@ -159,9 +163,25 @@ class Problem {
   // standalone_edge_align.cpp:272  problem.AddResidualBlock(cost, new CauchyLoss(1.), q, t)
   void AddResidualBlock(CostFunction *cost, LossFunction *loss, double *q, double *t) {
     costs_.push_back(cost);
-    if (loss) losses_.insert(loss);  // one `new CauchyLoss(1.)` per block in the reference; shared ones are fine too
+    if (loss && (losses_.empty() || losses_.back() != loss))
+      losses_.push_back(loss);  // one `new CauchyLoss(1.)` per block in the reference; shared ones are fine too (~Problem)
+    // What a block stores is its point and the index of its functor description: the reference adds one block per edge point
+    // (44 457 per frame pair at stride 1), all describing the same functor; 64 bytes per block instead of the 430 of a full
+    // description keep the list in cache while it is built and gathered (see profiles/r02_facade_timing.txt).
+    EABlockInfo info;
     Block b;
-    b.ok = cost->DescribeEdgeAlignmentBlock(&b.info);
+    b.ok = cost->DescribeEdgeAlignmentBlock(&info);
+    b.X = info.X; b.Y = info.Y; b.Z = info.Z;
+    b.fam = -1;
+    if (b.ok) {
+      if (last_fam_ >= 0 && SameFunctor(fams_[(size_t)last_fam_], info)) b.fam = last_fam_;
+      else {
+        for (size_t k = 0; k < fams_.size() && b.fam < 0; ++k)
+          if (SameFunctor(fams_[k], info)) b.fam = (int)k;
+        if (b.fam < 0) { fams_.push_back(info); b.fam = (int)fams_.size() - 1; }
+        last_fam_ = b.fam;
+      }
+    }
     b.loss = loss;
     b.q = q;
     b.t = t;
@@ -192,14 +212,28 @@ class Problem {
 
  private:
   struct Block {
-    EABlockInfo info;
+    double X, Y, Z;
+    int fam;   // index into fams_: everything of the functor's description but the point
     bool ok;
     LossFunction *loss;
     double *q, *t;
   };
+  static bool SameFunctor(const EABlockInfo &x, const EABlockInfo &y) {
+    if (x.grid_data != y.grid_data || x.grid_rows != y.grid_rows || x.grid_cols != y.grid_cols) return false;
+    if (x.fx != y.fx || x.fy != y.fy || x.cx != y.cx || x.cy != y.cy) return false;
+    if (x.z_guard != y.z_guard || x.z_eps != y.z_eps || x.rot_transposed != y.rot_transposed) return false;
+    if (x.variant != y.variant) return false;
+    if (x.variant & 1)
+      for (int i = 0; i < 5; ++i) if (x.dist[i] != y.dist[i]) return false;
+    if (x.variant & 2)
+      for (int i = 0; i < 16; ++i) if (x.T12[i] != y.T12[i] || x.T12inv[i] != y.T12inv[i]) return false;
+    return true;
+  }
   std::vector<Block> blocks_;
+  std::vector<EABlockInfo> fams_;   // distinct functor descriptions (X, Y, Z of the entry unused)
+  int last_fam_ = -1;
   std::vector<CostFunction *> costs_;
-  std::unordered_set<LossFunction *> losses_;
+  std::vector<LossFunction *> losses_;
   std::vector<LocalParameterization *> params_;
   double *quat_param_on_ = nullptr;
   friend class ProblemAccess;
@@ -322,7 +356,7 @@ class ProblemAccess {  // keeps Problem's internals private to user code
         f->xyz.reserve(3 * (blocks.size() - i));  // (usually the one family: no regrowth while 44 457 blocks are gathered)
         f->idx.reserve(blocks.size() - i);
       }
-      f->xyz.push_back(b.info.X); f->xyz.push_back(b.info.Y); f->xyz.push_back(b.info.Z);
+      f->xyz.push_back(b.X); f->xyz.push_back(b.Y); f->xyz.push_back(b.Z);
       f->idx.push_back((int)i);
     }
     if (problem->quat_param_on_ != b0.q) { *err = "the quaternion block needs QuaternionParameterization (problem.SetParameterization)"; return -1000; }
@@ -331,7 +365,7 @@ class ProblemAccess {  // keeps Problem's internals private to user code
     order->clear();
     int rc = EA_OK;
     for (size_t k = 0; k < fams.size() && rc == EA_OK; ++k) {
-      const auto &bi = fams[k].first->info;
+      const EABlockInfo &bi = problem->fams_[(size_t)fams[k].first->fam];
       order->push_back(fams[k].idx);
       ea_camera cam = {bi.fx, bi.fy, bi.cx, bi.cy};
       rc = ea_problem_create(&ps[k], &cam, dtype, device);
@@ -444,18 +478,9 @@ class ProblemAccess {  // keeps Problem's internals private to user code
   }
 
  private:
+  // same functor description (by construction: same index) and an equivalent loss
   static bool SameFamily(const Problem::Block &a, const Problem::Block &b) {
-    const EABlockInfo &x = a.info, &y = b.info;
-    if (x.grid_data != y.grid_data || x.grid_rows != y.grid_rows || x.grid_cols != y.grid_cols) return false;
-    if (x.fx != y.fx || x.fy != y.fy || x.cx != y.cx || x.cy != y.cy) return false;
-    if (x.z_guard != y.z_guard || x.z_eps != y.z_eps || x.rot_transposed != y.rot_transposed) return false;
-    if (x.variant != y.variant) return false;
-    // (only what the variant uses: the plain functor's 44 457 blocks are compared once each while they are gathered)
-    if (x.variant & 1)
-      for (int i = 0; i < 5; ++i) if (x.dist[i] != y.dist[i]) return false;
-    if (x.variant & 2)
-      for (int i = 0; i < 16; ++i) if (x.T12[i] != y.T12[i] || x.T12inv[i] != y.T12inv[i]) return false;
-    return a.loss == b.loss || SameLoss(a.loss, b.loss);
+    return a.fam == b.fam && (a.loss == b.loss || SameLoss(a.loss, b.loss));
   }
   static bool SameLoss(const LossFunction *a, const LossFunction *b) {
     const int ka = a ? a->ea_kind() : EA_LOSS_TRIVIAL, kb = b ? b->ea_kind() : EA_LOSS_TRIVIAL;
