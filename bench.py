@@ -245,6 +245,11 @@ def main():
                 graph = "hipGraph of %d steps (2 kernel nodes per step), one replay" % args.steps
             except capi.EAError as e:
                 graph = "eager launches (graph capture failed: %s)" % e
+    # untimed warm-up of the region itself: the capture above replayed the graph once (that replay uploads it); further
+    # replays settle what the first one leaves cold (EA_BENCH_WARM_REPLAYS, default 2; profiles/r02_bench_warm_replays.txt)
+    warm_replays = int(os.environ.get("EA_BENCH_WARM_REPLAYS", "2")) if graph and graph.startswith("hipGraph") else 0
+    for _ in range(warm_replays):
+        B.bench_steps(args.steps)
     barrier_sync()
     t_start = time.perf_counter()
     B.bench_steps(args.steps)
@@ -352,6 +357,8 @@ def main():
                            "tiles": B.info("num_tiles"), "points_per_thread": B.info("points_per_thread"),
                            "lds_bytes": B.info("lds_bytes"), "point_order_tile_px": P.point_order,
                            "timed_region": graph or "eager launches",
+                           "untimed_warmup": "%d launch-by-launch steps, then %d replays of the timed region's graph" % (max(args.warmup, 1), 1 + warm_replays)
+                                             if warm_replays or (graph and graph.startswith("hipGraph")) else "%d launch-by-launch steps" % max(args.warmup, 1),
                            "closing_barrier_and_sync_ms_on_idle_gpus": bracket_ms,
                            "bracket_barrier": None if dist is None else ("shared-memory epoch barrier (one node)" if node_barrier is not None else "torch.distributed.barrier")},
                 "roofline": roofline, "materialised_mode": mat}

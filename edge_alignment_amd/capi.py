@@ -30,7 +30,7 @@ EXPORTED = [
     "ea_eval", "ea_eval_points", "ea_cost", "ea_problem_pixel_cost", "ea_solve",
     "ea_release_cached_memory", "ea_batch_create", "ea_batch_destroy", "ea_batch_count", "ea_batch_eval", "ea_batch_solve",
     "ea_solve_pyramid", "ea_solve_sharded", "ea_solve_sharded_device", "ea_tracker_create", "ea_tracker_destroy", "ea_tracker_problem", "ea_tracker_push_frame",
-    "ea_batch_bench_eval", "ea_batch_bench_steps", "ea_batch_bench_capture", "ea_batch_bench_capture_pipelined", "ea_batch_bench_result", "ea_batch_bench_result_riding", "ea_batch_bench_kernel", "ea_batch_bench_rows", "ea_batch_row_offsets", "ea_problem_num_rows", "ea_eval_rows", "ea_eval_rows_device", "ea_batch_eval_rows_device", "ea_batch_eval_rows", "ea_batch_bench_fold", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
+    "ea_batch_bench_eval", "ea_batch_bench_steps", "ea_batch_bench_capture", "ea_batch_bench_capture_pipelined", "ea_batch_bench_steps_riding", "ea_batch_bench_result", "ea_batch_bench_result_riding", "ea_batch_bench_kernel", "ea_batch_bench_rows", "ea_batch_row_offsets", "ea_problem_num_rows", "ea_eval_rows", "ea_eval_rows_device", "ea_batch_eval_rows_device", "ea_batch_eval_rows", "ea_batch_bench_fold", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
     "ea_problem_set_ref_frame", "ea_problem_set_ref_frame_masked", "ea_problem_set_now_frame", "ea_problem_debug_now_frame",
     "ea_problem_set_ref_frame_canny", "ea_problem_set_now_frame_canny", "ea_problem_debug_now_frame_canny",
     "ea_problem_set_ref_frame_ros", "ea_problem_set_now_frame_ros", "ea_problem_debug_now_frame_ros",
@@ -131,6 +131,7 @@ def load():
     L.ea_batch_bench_steps.argtypes = [vp, C.c_int, dp]
     L.ea_batch_bench_capture.argtypes = [vp, C.c_int]
     L.ea_batch_bench_capture_pipelined.argtypes = [vp, C.c_int]
+    L.ea_batch_bench_steps_riding.argtypes = [vp, C.c_int, dp]
     L.ea_batch_bench_result.argtypes = [vp, dp, dp, dp, i64p]
     L.ea_batch_bench_result_riding.argtypes = [vp, dp, dp, dp, i64p]
     L.ea_batch_bench_kernel.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp]
@@ -605,13 +606,15 @@ class Batch:
         _check(fn(self._h, _dp(cost), _dp(JtJ), _dp(Jtr), bad.ctypes.data_as(C.POINTER(C.c_int64))))
         return dict(cost=cost, JtJ=JtJ, Jtr=Jtr, n_invalid=bad)
 
-    def bench_steps(self, steps, host_times=False):
-        """`steps` x (fused evaluation + fold) at the poses already on the device, then a stream sync: the timed region"""
+    def bench_steps(self, steps, host_times=False, riding=False):
+        """`steps` x (fused evaluation + fold) at the poses already on the device, then a stream sync: the timed region.
+        riding=True: launch by launch with the fold of step k-1 riding in evaluation k (no graph)"""
+        fn = load().ea_batch_bench_steps_riding if riding else load().ea_batch_bench_steps
         if host_times:
             us = np.zeros(3)
-            _check(load().ea_batch_bench_steps(self._h, int(steps), _dp(us)))
+            _check(fn(self._h, int(steps), _dp(us)))
             return us
-        _check(load().ea_batch_bench_steps(self._h, int(steps), None))
+        _check(fn(self._h, int(steps), None))
 
     def bench_kernel(self, q, t, warmup, launches):
         """mean ms of the per-point kernel over `launches` back-to-back launches (one event pair)"""

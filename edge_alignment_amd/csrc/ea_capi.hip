@@ -378,6 +378,7 @@ struct ea_batch {
   bool built = false;
   hipEvent_t bench_e0 = nullptr, bench_e1 = nullptr;
   hipGraphExec_t bench_graph = nullptr;  // K x (evaluation + fold) captured once (ea_batch_bench_capture), replayed by
+  int bench_riding_steps = 0;            // length of the last riding-fold sequence (captured or run launch by launch)
   int bench_graph_steps = 0;             // ea_batch_bench_steps(K): the timed region then holds no per-launch host work
   // ea_batch_bench_capture_pipelined: the fold of step k-1 rides in the launch of evaluation k; the evaluations alternate
   // between `bench_ring` = 2 row / result arrays
@@ -766,13 +767,13 @@ extern "C" int ea_problem_set_flavour(ea_problem *p, double z_guard, double z_ep
 
 static void bench_ring_free(ea_batch *b) {
   (void)hipFree(b->d_bench_rows); (void)hipFree(b->d_bench_out);
-  b->d_bench_rows = nullptr; b->d_bench_out = nullptr; b->bench_ring = 0;
+  b->d_bench_rows = nullptr; b->d_bench_out = nullptr; b->bench_ring = 0; b->bench_riding_steps = 0;
 }
 
 static void batch_free_device(ea_batch *b) {
   (void)hipFree(b->d_rows_r); (void)hipFree(b->d_rows_J); (void)hipFree(b->d_rows_invalid);
   b->d_rows_r = b->d_rows_J = nullptr; b->d_rows_invalid = nullptr; b->rows_cap = 0;
-  if (b->bench_graph) { (void)hipGraphExecDestroy(b->bench_graph); b->bench_graph = nullptr; b->bench_graph_steps = 0; }
+  if (b->bench_graph) { (void)hipGraphExecDestroy(b->bench_graph); b->bench_graph = nullptr; b->bench_graph_steps = 0; b->bench_riding_steps = 0; }
   bench_ring_free(b);
   if (b->bench_e0) { (void)hipEventDestroy(b->bench_e0); b->bench_e0 = nullptr; }
   if (b->bench_e1) { (void)hipEventDestroy(b->bench_e1); b->bench_e1 = nullptr; }
@@ -913,7 +914,7 @@ static int batch_build(ea_batch *b) {
   (void)sig;
   if (!dirty) return EA_OK;
   b->built = false;  // until the last allocation and upload below has succeeded
-  if (b->bench_graph) { (void)hipGraphExecDestroy(b->bench_graph); b->bench_graph = nullptr; b->bench_graph_steps = 0; }
+  if (b->bench_graph) { (void)hipGraphExecDestroy(b->bench_graph); b->bench_graph = nullptr; b->bench_graph_steps = 0; b->bench_riding_steps = 0; }
   bench_ring_free(b);  // (sized by the row count of the old build)
   // terms of a problem follow it; all share its pose
   std::vector<const ea_problem *> terms;
@@ -1449,7 +1450,7 @@ extern "C" int ea_batch_bench_capture(ea_batch *b, int steps) {
   int rc = batch_build(b);
   if (rc != EA_OK) return rc;
   if (!b->poses_uploaded) return fail(EA_ERR_STATE, "no poses uploaded yet (ea_batch_bench_eval or ea_batch_eval first)");
-  if (b->bench_graph) { (void)hipGraphExecDestroy(b->bench_graph); b->bench_graph = nullptr; b->bench_graph_steps = 0; }
+  if (b->bench_graph) { (void)hipGraphExecDestroy(b->bench_graph); b->bench_graph = nullptr; b->bench_graph_steps = 0; b->bench_riding_steps = 0; }
   const int count = (int)b->probs.size();
   HIPCHK(hipStreamSynchronize(b->stream));
   HIPCHK(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
@@ -1473,38 +1474,28 @@ extern "C" int ea_batch_bench_capture(ea_batch *b, int steps) {
   return EA_OK;
 }
 
-// The same K steps with the fold off the evaluations' critical path.  A step is two dependent launches, and the second
-// one (one workgroup per problem) leaves the chip idle behind a kernel boundary; the next evaluation does not need its
-// result -- the K evaluations of the timed region are independent passes at the resident poses.  Here the fold of step
-// k-1 RIDES in the launch of evaluation k (ea_eval_fold_kernel: one extra workgroup per problem), the evaluations
-// alternating between two row arrays; a stand-alone fold closes the sequence.  K steps = K launches + 1, every step
-// still runs its evaluation and its fold in full, the evaluation kernels still execute one after the other.  The folds
-// sum in the order of a workgroup of the evaluation's size (equal to ea_batch_eval's 1024-thread fold up to rounding).
-// (A two-branch graph with the folds on a side stream was measured first: the cross-branch edges of a replayed graph
-// cost more than the fold -- 9-19 us per step against 5.5 serial, profiles/r02_ab_pipeline.txt.)
-extern "C" int ea_batch_bench_capture_pipelined(ea_batch *b, int steps) {
-  if (!b || steps < 1) return fail(EA_ERR_INVALID_ARG, "bad argument");
-  int rc = batch_build(b);
-  if (rc != EA_OK) return rc;
-  if (!b->poses_uploaded) return fail(EA_ERR_STATE, "no poses uploaded yet (ea_batch_bench_eval or ea_batch_eval first)");
-  if (b->any_variant || !b->terms_are_groups || b->lds_bytes > 0)
-    return fail(EA_ERR_STATE, "the pipelined form covers plain single-family problems on the L2 path");
-  if (b->bench_graph) { (void)hipGraphExecDestroy(b->bench_graph); b->bench_graph = nullptr; b->bench_graph_steps = 0; }
+static int bench_ring_ensure(ea_batch *b) {
   const int count = (int)b->probs.size();
-  HIPCHK(hipStreamSynchronize(b->stream));
   const size_t row_doubles = (size_t)b->tiles_cap * kAccSlots;
-  if (b->bench_ring != 2) {
-    bench_ring_free(b);
-    HIPCHK(hipMalloc(&b->d_bench_rows, row_doubles * sizeof(double) * 2));
-    hipError_t ea = hipMalloc(&b->d_bench_out, sizeof(EvalOut) * (size_t)count * 2);
-    if (ea != hipSuccess) { bench_ring_free(b); return fail(EA_ERR_ALLOC, "bench row buffers: allocation failed"); }
-    b->bench_ring = 2;
-    HIPCHK(hipMemsetAsync(b->d_bench_rows, 0, row_doubles * sizeof(double) * 2, b->stream));
-    HIPCHK(hipMemsetAsync(b->d_bench_out, 0, sizeof(EvalOut) * (size_t)count * 2, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));
-  }
+  if (b->bench_ring == 2) return EA_OK;
+  HIPCHK(hipStreamSynchronize(b->stream));
+  bench_ring_free(b);
+  HIPCHK(hipMalloc(&b->d_bench_rows, row_doubles * sizeof(double) * 2));
+  hipError_t ea = hipMalloc(&b->d_bench_out, sizeof(EvalOut) * (size_t)count * 2);
+  if (ea != hipSuccess) { bench_ring_free(b); return fail(EA_ERR_ALLOC, "bench row buffers: allocation failed"); }
+  b->bench_ring = 2;
+  HIPCHK(hipMemsetAsync(b->d_bench_rows, 0, row_doubles * sizeof(double) * 2, b->stream));
+  HIPCHK(hipMemsetAsync(b->d_bench_out, 0, sizeof(EvalOut) * (size_t)count * 2, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return EA_OK;
+}
+
+// K steps as K launches + 1 on the batch's stream: evaluation k with the fold of step k-1 riding in it, rows alternating
+// between the two arrays of the ring, a stand-alone fold of the last step's rows into the batch's result array.
+static hipError_t enqueue_riding_steps(ea_batch *b, int steps) {
+  const int count = (int)b->probs.size();
+  const size_t row_doubles = (size_t)b->tiles_cap * kAccSlots;
   double *const own_rows = b->d_partials;
-  HIPCHK(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
   hipError_t e = hipSuccess;
   for (int i = 0; i < steps && e == hipSuccess; ++i) {
     double *rows = b->d_bench_rows + row_doubles * (size_t)(i & 1);
@@ -1522,6 +1513,30 @@ extern "C" int ea_batch_bench_capture_pipelined(ea_batch *b, int steps) {
   }
   if (e == hipSuccess)
     e = launch_reduce_nt(b->nt, b->d_groups, count, b->d_bench_rows + row_doubles * (size_t)((steps - 1) & 1), b->d_out, b->stream);
+  return e;
+}
+
+// The same K steps with the fold off the evaluations' critical path.  A step is two dependent launches, and the second
+// one (one workgroup per problem) leaves the chip idle behind a kernel boundary; the next evaluation does not need its
+// result -- the K evaluations of the timed region are independent passes at the resident poses.  Here the fold of step
+// k-1 RIDES in the launch of evaluation k (ea_eval_fold_kernel: one extra workgroup per problem), the evaluations
+// alternating between two row arrays; a stand-alone fold closes the sequence.  K steps = K launches + 1, every step
+// still runs its evaluation and its fold in full, the evaluation kernels still execute one after the other.  The folds
+// sum in the order of a workgroup of the evaluation's size (equal to ea_batch_eval's 1024-thread fold up to rounding).
+// (A two-branch graph with the folds on a side stream was measured first: the cross-branch edges of a replayed graph
+// cost more than the fold -- 9-19 us per step against 5.5 serial, profiles/r02_ab_pipeline.txt.)
+extern "C" int ea_batch_bench_capture_pipelined(ea_batch *b, int steps) {
+  if (!b || steps < 1) return fail(EA_ERR_INVALID_ARG, "bad argument");
+  int rc = batch_build(b);
+  if (rc != EA_OK) return rc;
+  if (!b->poses_uploaded) return fail(EA_ERR_STATE, "no poses uploaded yet (ea_batch_bench_eval or ea_batch_eval first)");
+  if (b->any_variant || !b->terms_are_groups || b->lds_bytes > 0)
+    return fail(EA_ERR_STATE, "the pipelined form covers plain single-family problems on the L2 path");
+  if (b->bench_graph) { (void)hipGraphExecDestroy(b->bench_graph); b->bench_graph = nullptr; b->bench_graph_steps = 0; b->bench_riding_steps = 0; }
+  if ((rc = bench_ring_ensure(b)) != EA_OK) return rc;
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
+  hipError_t e = enqueue_riding_steps(b, steps);
   hipGraph_t graph = nullptr;
   const hipError_t ee = hipStreamEndCapture(b->stream, &graph);
   if (e != hipSuccess || ee != hipSuccess || !graph) {
@@ -1532,8 +1547,42 @@ extern "C" int ea_batch_bench_capture_pipelined(ea_batch *b, int steps) {
   (void)hipGraphDestroy(graph);
   if (e != hipSuccess) { b->bench_graph = nullptr; return fail(EA_ERR_HIP, std::string("graph instantiate: ") + hipGetErrorString(e)); }
   b->bench_graph_steps = steps;
+  b->bench_riding_steps = steps;
   HIPCHK(hipGraphLaunch(b->bench_graph, b->stream));  // one untimed replay: uploads the executable graph
   HIPCHK(hipStreamSynchronize(b->stream));
+  return EA_OK;
+}
+
+// The same K launches + 1 enqueued launch by launch instead of replayed from a graph: the first evaluation starts while
+// the host is still enqueueing the others (a graph replay hands over all K + 1 packets before the first one runs), which
+// is what a short sequence wants -- see profiles/r02_riding_eager_vs_graph.txt.  host_us as in ea_batch_bench_steps.
+extern "C" int ea_batch_bench_steps_riding(ea_batch *b, int steps, double *host_us) {
+  if (!b || steps < 1) return fail(EA_ERR_INVALID_ARG, "bad argument");
+  int rc = batch_build(b);
+  if (rc != EA_OK) return rc;
+  if (!b->poses_uploaded) return fail(EA_ERR_STATE, "no poses uploaded yet (ea_batch_bench_eval or ea_batch_eval first)");
+  if (b->any_variant || !b->terms_are_groups || b->lds_bytes > 0)
+    return fail(EA_ERR_STATE, "the pipelined form covers plain single-family problems on the L2 path");
+  if ((rc = bench_ring_ensure(b)) != EA_OK) return rc;
+  if (host_us && (!b->bench_e0 || !b->bench_e1)) {
+    HIPCHK(hipEventCreate(&b->bench_e0));
+    HIPCHK(hipEventCreate(&b->bench_e1));
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  if (host_us) HIPCHK(hipEventRecord(b->bench_e0, b->stream));
+  const hipError_t e = enqueue_riding_steps(b, steps);
+  if (e != hipSuccess) return fail(EA_ERR_HIP, std::string("riding steps: ") + hipGetErrorString(e));
+  b->bench_riding_steps = steps;
+  if (host_us) HIPCHK(hipEventRecord(b->bench_e1, b->stream));
+  const auto t1 = std::chrono::steady_clock::now();
+  HIPCHK(hipStreamSynchronize(b->stream));
+  if (host_us) {
+    host_us[0] = std::chrono::duration<double, std::micro>(t1 - t0).count();
+    host_us[1] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, b->bench_e0, b->bench_e1));
+    host_us[2] = ms;
+  }
   return EA_OK;
 }
 
@@ -1541,10 +1590,10 @@ extern "C" int ea_batch_bench_capture_pipelined(ea_batch *b, int steps) {
 // covers both a riding fold and the closing stand-alone fold.
 extern "C" int ea_batch_bench_result_riding(ea_batch *b, double *cost, double *JtJ, double *Jtr, int64_t *n_invalid) {
   if (!b) return fail(EA_ERR_INVALID_ARG, "NULL argument");
-  if (!b->built || !b->bench_graph || b->bench_ring != 2 || b->bench_graph_steps < 2)
-    return fail(EA_ERR_STATE, "no pipelined sequence of at least two steps captured");
+  if (!b->built || b->bench_ring != 2 || b->bench_riding_steps < 2)
+    return fail(EA_ERR_STATE, "no pipelined sequence of at least two steps captured or run");
   const int count = (int)b->probs.size();
-  HIPCHK(hipMemcpyAsync(b->h_out, b->d_bench_out + (size_t)count * (size_t)((b->bench_graph_steps - 2) & 1), count * sizeof(EvalOut),
+  HIPCHK(hipMemcpyAsync(b->h_out, b->d_bench_out + (size_t)count * (size_t)((b->bench_riding_steps - 2) & 1), count * sizeof(EvalOut),
                         hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
   unpack_eval_out(b, count, cost, JtJ, Jtr, n_invalid);

@@ -314,6 +314,9 @@ int ea_batch_bench_capture(ea_batch *b, int steps);
  * its fold in full and the evaluation kernels execute one after the other.  The folds sum in the order of a workgroup of
  * the evaluation's size (for 256-thread launches not the order of ea_batch_eval's 1024-thread fold: equal to rounding).  Plain single-family problems on the L2 path; EA_ERR_STATE otherwise. */
 int ea_batch_bench_capture_pipelined(ea_batch *b, int steps);
+/* The same K launches + 1 enqueued launch by launch (no graph) and synchronised: the first evaluation runs while the host
+ * enqueues the others.  host_us as in ea_batch_bench_steps.  Same restrictions as the captured form. */
+int ea_batch_bench_steps_riding(ea_batch *b, int steps, double *host_us /* nullable, 3 doubles */);
 /* cost / JtJ / Jtr / invalid count (layout of ea_batch_eval) that the LAST step of the last ea_batch_bench_steps left in
  * the batch's result array: a check that the timed launches compute what ea_batch_eval computes. */
 int ea_batch_bench_result(ea_batch *b, double *cost, double *JtJ, double *Jtr, int64_t *n_invalid);

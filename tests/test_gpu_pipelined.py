@@ -68,6 +68,11 @@ def test_riding_fold_matches_eval_for_every_shape(hip, oracle, dtype_name, tol):
                                 assert _same(B.bench_result(riding=True), last), where
                             B.bench_steps(steps)   # a replay lands on the same bits
                             assert _same(B.bench_result(), last), where
+                            # the same launches enqueued one by one (ea_batch_bench_steps_riding): the same bits
+                            B.bench_steps(steps, riding=True)
+                            assert _same(B.bench_result(), last), where + ("launch by launch",)
+                            if steps >= 2:
+                                assert _same(B.bench_result(riding=True), last), where + ("launch by launch",)
                         B.bench_capture(3)
                         B.bench_steps(3)
                         assert _same(B.bench_result(), ref), (members, ppt, nt, "serial graph")
@@ -92,6 +97,9 @@ def test_pipelined_form_refuses_what_it_does_not_cover(hip):
         B.set_tuning("use_lds", 1)               # LDS-staged evaluation: not covered
         with pytest.raises(hip.EAError) as ei:
             B.bench_capture_pipelined(4)
+        assert ei.value.code == hip.EA_ERR_STATE
+        with pytest.raises(hip.EAError) as ei:
+            B.bench_steps(4, riding=True)
         assert ei.value.code == hip.EA_ERR_STATE
         B.set_tuning("use_lds", 0)
         B.bench_capture_pipelined(4)
