@@ -27,7 +27,7 @@
 namespace ea {
 hipError_t launch_eval_fused(int dtype, int ppt, int nt, int variant, const ProblemDesc *probs, int nterms, int chunk,
                              int max_chunks, int xcd_remap, const PoseState *poses, double *partials,
-                             int lds_bytes, int terms_are_groups, int buffer_loads, const void *x0, const void *y0,
+                             int lds_bytes, int wide, int terms_are_groups, int buffer_loads, const void *x0, const void *y0,
                              const void *z0, int n0, hipStream_t stream);
 hipError_t launch_pixel_cost(int dtype, const ProblemDesc *probs, int problem, int n, const PoseState *poses, void *partials,
                              hipStream_t stream);
@@ -370,6 +370,7 @@ struct ea_batch {
   int *h_progress = nullptr;            // pinned, device-visible: [running x count | evaluations done x count]
   // tuning (-1 = heuristic)
   int t_lds_bytes = -1, t_ppt = -1, t_use_lds = -1, t_xcd = -1, t_nt = -1, t_streams = -1, t_variant = 0;
+  int t_wide = 0, wide = 0;              // "wide_accumulate": an fp32 kernel sums in fp64 from the lane's sum on (plain functor, L2 path)
   int ppt = 1, nt = 256, lds_bytes = 0, xcd_remap = 1;
   int t_test_fail_build = 0;  // test hook: the next descriptor build fails half-way, as a failed allocation would
   int t_test_stall_ms = 0;  // test hook: hold the stream on a host function for this long at the start of a solve
@@ -1064,6 +1065,7 @@ static int batch_build(ea_batch *b) {
   int lds = b->t_lds_bytes >= 0 ? b->t_lds_bytes : (b->dtype == EA_F32 ? 32768 : 49152);
   if (lds > 61440) lds = 61440;
   b->lds_bytes = (use_lds && !any_variant) ? lds : 0;
+  b->wide = (b->t_wide > 0 && b->dtype == EA_F32 && !any_variant && b->lds_bytes == 0) ? 1 : 0;
   b->xcd_remap = b->t_xcd < 0 ? 1 : (b->t_xcd ? 1 : 0);
   // only now is the batch consistent with its problems: a failure above leaves it dirty, so the next call rebuilds
   // instead of launching on freed or missing buffers
@@ -1083,7 +1085,7 @@ static void host_pose_state(const ea_problem *p, const double *q, const double *
 
 static int batch_launch_eval(ea_batch *b) {
   HIPCHK(launch_eval_fused(b->dtype, b->ppt, b->nt, b->any_variant, b->d_probs, b->nterms, b->chunk, b->max_chunks,
-                           b->xcd_remap, b->d_poses, b->d_partials, b->lds_bytes, b->terms_are_groups, b->buffer_loads,
+                           b->xcd_remap, b->d_poses, b->d_partials, b->lds_bytes, b->wide, b->terms_are_groups, b->buffer_loads,
                            b->x0, b->y0, b->z0, b->n0, b->stream));
   return EA_OK;
 }
@@ -1343,9 +1345,9 @@ extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, 
       ea_batch *c = b->parts[(size_t)k];
       const int use_lds = b->lds_bytes > 0 ? 1 : 0;
       if (c->t_lds_bytes != b->t_lds_bytes || c->t_ppt != b->ppt || c->t_use_lds != use_lds || c->t_xcd != b->xcd_remap ||
-          c->t_nt != b->nt || c->t_variant != b->any_variant || c->t_buf != b->buffer_loads) {
+          c->t_nt != b->nt || c->t_variant != b->any_variant || c->t_buf != b->buffer_loads || c->t_wide != b->t_wide) {
         c->t_lds_bytes = b->t_lds_bytes; c->t_ppt = b->ppt; c->t_use_lds = use_lds; c->t_xcd = b->xcd_remap; c->t_nt = b->nt;
-        c->t_variant = b->any_variant; c->t_buf = b->buffer_loads;
+        c->t_variant = b->any_variant; c->t_buf = b->buffer_loads; c->t_wide = b->t_wide;
         c->built = false;
       }
       runs[(size_t)k].b = c;
@@ -1530,7 +1532,7 @@ extern "C" int ea_batch_bench_capture_pipelined(ea_batch *b, int steps) {
   int rc = batch_build(b);
   if (rc != EA_OK) return rc;
   if (!b->poses_uploaded) return fail(EA_ERR_STATE, "no poses uploaded yet (ea_batch_bench_eval or ea_batch_eval first)");
-  if (b->any_variant || !b->terms_are_groups || b->lds_bytes > 0)
+  if (b->any_variant || !b->terms_are_groups || b->lds_bytes > 0 || b->wide)
     return fail(EA_ERR_STATE, "the pipelined form covers plain single-family problems on the L2 path");
   if (b->bench_graph) { (void)hipGraphExecDestroy(b->bench_graph); b->bench_graph = nullptr; b->bench_graph_steps = 0; b->bench_riding_steps = 0; }
   if ((rc = bench_ring_ensure(b)) != EA_OK) return rc;
@@ -1561,7 +1563,7 @@ extern "C" int ea_batch_bench_steps_riding(ea_batch *b, int steps, double *host_
   int rc = batch_build(b);
   if (rc != EA_OK) return rc;
   if (!b->poses_uploaded) return fail(EA_ERR_STATE, "no poses uploaded yet (ea_batch_bench_eval or ea_batch_eval first)");
-  if (b->any_variant || !b->terms_are_groups || b->lds_bytes > 0)
+  if (b->any_variant || !b->terms_are_groups || b->lds_bytes > 0 || b->wide)
     return fail(EA_ERR_STATE, "the pipelined form covers plain single-family problems on the L2 path");
   if ((rc = bench_ring_ensure(b)) != EA_OK) return rc;
   if (host_us && (!b->bench_e0 || !b->bench_e1)) {
@@ -1831,6 +1833,7 @@ extern "C" int ea_batch_set_tuning(ea_batch *b, const char *key, int value) {
   else if (k == "xcd_remap") b->t_xcd = value;
   else if (k == "threads") b->t_nt = value;
   else if (k == "buffer_loads") b->t_buf = value;
+  else if (k == "wide_accumulate") b->t_wide = value;
   else if (k == "test_stall_ms") { b->t_test_stall_ms = value; return EA_OK; }
   else if (k == "test_fail_build") { b->t_test_fail_build = value; return EA_OK; }
   else if (k == "solve_streams") { b->t_streams = value; return EA_OK; }
@@ -1851,6 +1854,7 @@ extern "C" int ea_batch_get_info(const ea_batch *b, const char *key, int64_t *va
   else if (k == "chunk") *value = b->chunk;
   else if (k == "threads") *value = b->nt;
   else if (k == "buffer_loads") *value = b->buffer_loads;
+  else if (k == "wide_accumulate") *value = b->wide;
   else if (k == "num_points") { int64_t s = 0; for (auto *p : b->probs) s += p->n; *value = s; }
   else if (k == "num_rows") *value = b->total_rows;
   else return fail(EA_ERR_INVALID_ARG, "unknown info key: " + k);

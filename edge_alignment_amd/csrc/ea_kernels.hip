@@ -751,8 +751,10 @@ template <typename T, int PPT, int MODE, int NT, bool VAR, bool BUF, typename PS
 __device__ __forceinline__ double fused_chunk(const ProblemDesc &pd, const PS &ps, const T (&X)[PPT],
                                               const T (&Y)[PPT], const T (&Z)[PPT], int count, double *s_red,
                                               int *s_box, T *s_tile, int lds_texels, int my_slot) {
-  // MODE 0: stencil rows from L2.  1: DT footprint staged in LDS.
+  // MODE 0: stencil rows from L2.  1: DT footprint staged in LDS.  2: as 0, and an fp32 kernel widens a lane's sums to
+  // fp64 before the wavefront butterfly ("wide_accumulate": everything above a lane's <= PPT products is fp64).
   constexpr bool USE_LDS = MODE == 1;
+  constexpr bool WIDE = MODE == 2 && sizeof(T) == 4;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -885,7 +887,13 @@ __device__ __forceinline__ double fused_chunk(const ProblemDesc &pd, const PS &p
 #endif
   EA_STAMP(4);  // sampled + accumulated
   if (USE_LDS) __syncthreads();  // tile readers done before the scratch rows are written
-  if constexpr (sizeof(T) == 4) {
+  if constexpr (WIDE) {
+    double w[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) w[i] = (double)v[i];
+    wave_reduce32_f64(w, lane);
+    if ((lane & 1) == 0) s_red[wave * kAccSlots + swap_slot_f64(lane)] = w[0];
+  } else if constexpr (sizeof(T) == 4) {
     wave_reduce32_f32(v);
     if ((lane & 3) == 0) {
       s_red[wave * kAccSlots + masked_slot(lane, 0)] = (double)v[0];
@@ -1692,7 +1700,7 @@ hipError_t launch_eval_fused_var(int dtype, int ppt, const ProblemDesc *probs, i
 
 hipError_t launch_eval_fused(int dtype, int ppt, int nt, int variant, const ProblemDesc *probs, int nterms, int chunk,
                              int max_chunks, int xcd_remap, const PoseState *poses, double *partials,
-                             int lds_bytes, int terms_are_groups, int buffer_loads, const void *x0, const void *y0,
+                             int lds_bytes, int wide, int terms_are_groups, int buffer_loads, const void *x0, const void *y0,
                              const void *z0, int n0, hipStream_t stream) {
   if (variant)
     return launch_eval_fused_var(dtype, ppt, probs, nterms, chunk, max_chunks, xcd_remap, poses, partials, terms_are_groups,
@@ -1702,7 +1710,15 @@ hipError_t launch_eval_fused(int dtype, int ppt, int nt, int variant, const Prob
   do {                                                                                \
     if (lds_texels > 0) EA_LAUNCH(T, P, 1, N, false); else EA_LAUNCH(T, P, 0, N, false); \
   } while (0)
-  if (dtype == 1) {
+  if (dtype == 1 && wide && lds_texels == 0) {
+    // fp64 sums from the lane's sum on (MODE 2; ea_batch_set_tuning "wide_accumulate")
+#define EA_LAUNCH_W(P, N) do { if (buffer_loads) EA_LAUNCH_B(float, P, 2, N, false, true); else EA_LAUNCH_B(float, P, 2, N, false, false); } while (0)
+    if (nt == 1024) { if (ppt == 1) EA_LAUNCH_W(1, 1024); else if (ppt == 2) EA_LAUNCH_W(2, 1024); else EA_LAUNCH_W(4, 1024); }
+    else if (ppt == 1) EA_LAUNCH_W(1, 256);
+    else if (ppt == 2) EA_LAUNCH_W(2, 256);
+    else EA_LAUNCH_W(4, 256);
+#undef EA_LAUNCH_W
+  } else if (dtype == 1) {
     if (nt == 1024) { if (ppt == 1) EA_LAUNCH_L(float, 1, 1024); else if (ppt == 2) EA_LAUNCH_L(float, 2, 1024); else EA_LAUNCH_L(float, 4, 1024); }
     else if (ppt == 1) EA_LAUNCH_L(float, 1, 256);
     else if (ppt == 2) EA_LAUNCH_L(float, 2, 256);

@@ -333,8 +333,12 @@ int ea_batch_bench_rows(ea_batch *b, const double *q, const double *t, int corre
 /* the same for the fold kernel of ea_batch_eval, over the partial rows the last evaluation left */
 int ea_batch_bench_fold(ea_batch *b, int warmup, int launches, double *ms_per_launch);
 /* tuning knobs: key in {"lds_bytes", "points_per_thread", "use_lds", "xcd_remap", "threads", "buffer_loads",
- * "solve_streams", "rows_staged", "rows_nontemporal"};
- * value < 0 restores the default */
+ * "solve_streams", "rows_staged", "rows_nontemporal", "wide_accumulate"};
+ * value < 0 restores the default.
+ * "wide_accumulate" = 1: an fp32 batch sums in fp64 from a lane's sum of <= points_per_thread products on (default: a
+ * lane's and a wavefront's sums are fp32, everything above fp64).  Plain functor on the L2 path; ignored for fp64
+ * batches, variant functors and the LDS-staged form (ea_batch_get_info "wide_accumulate" reports what is in effect).
+ * Applies to ea_batch_eval and the solves; cost: profiles/r02_ab_wide_accumulate.txt. */
 int ea_batch_set_tuning(ea_batch *b, const char *key, int value);
 int ea_batch_get_info(const ea_batch *b, const char *key, int64_t *value);
 
