@@ -336,6 +336,8 @@ def cases():
         rcs = [c.lib.ea_batch_row_offsets(c.B, None), c.lib.ea_batch_row_offsets(None, off.ctypes.data_as(I64)),
                c.lib.ea_batch_bench_capture_pipelined(c.B, 0), c.lib.ea_batch_bench_capture_pipelined(None, 4),
                c.lib.ea_batch_bench_capture_pipelined(b2, 4),      # no poses uploaded on this batch yet
+               c.lib.ea_batch_bench_steps_riding(c.B, 0, None), c.lib.ea_batch_bench_steps_riding(None, 4, None),
+               c.lib.ea_batch_bench_steps_riding(b2, 4, None),     # no poses uploaded on this batch yet
                c.lib.ea_batch_bench_result(None, None, None, None, None), c.lib.ea_batch_bench_result(b2, None, None, None, None),
                c.lib.ea_batch_bench_result_riding(c.B, None, None, None, None),   # nothing pipelined captured
                c.lib.ea_batch_bench_rows(c.B, dp(c.q), dp(c.t), 1, 0, 1, None, None, 0, 0, 0, C.byref(ms)),   # launches 0
