@@ -56,6 +56,28 @@ int main() {
   }
   bad += check(g_deleted == 2, "borrowed loss destroyed once, by its owner");
 
+  // Problem ownership (Ceres' default): cost functions and losses handed to AddResidualBlock die with the problem, a loss
+  // shared by several blocks -- consecutive or not -- exactly once
+  {
+    g_deleted = 0;
+    double img[16 * 12];
+    for (int i = 0; i < 16 * 12; ++i) img[i] = 0.01 * i;
+    ceres::Grid2D<double, 1> grid(img, 0, 16, 0, 12);
+    ceres::BiCubicInterpolator<ceres::Grid2D<double, 1>> interp(grid);
+    double qq[4] = {1, 0, 0, 0}, tt[3] = {0, 0, 0};
+    {
+      Problem problem;
+      CountedLoss *shared_a = new CountedLoss, *shared_b = new CountedLoss;
+      LossFunction *order[6] = {shared_a, shared_a, shared_b, shared_a, new CountedLoss, shared_b};
+      for (int i = 0; i < 6; ++i)
+        problem.AddResidualBlock(EAResidue::Create(10., 10., 7.5, 5.5, 0.1 * i, 0.05 * i, 1.0 + i, interp), order[i], qq, tt);
+      problem.AddResidualBlock(EAResidue::Create(10., 10., 7.5, 5.5, 0.3, 0.2, 2.0, interp), NULL, qq, tt);
+      problem.SetParameterization(qq, new ceres::QuaternionParameterization);
+      bad += check(problem.NumResidualBlocks() == 7 && g_deleted == 0, "blocks counted, nothing deleted while the problem lives");
+    }
+    bad += check(g_deleted == 3, "three distinct loss objects, each deleted once");
+  }
+
   // the option / summary members the drivers touch
   Solver::Options options;
   options.linear_solver_type = ceres::DENSE_QR;
