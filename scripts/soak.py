@@ -32,6 +32,8 @@ while time.time() < t_end:
     if rng.random() < 0.5:
         B.set_tuning("points_per_thread", int(rng.choice([1, 2, 4]))); B.set_tuning("threads", int(rng.choice([256, 1024])))
         B.set_tuning("buffer_loads", int(rng.integers(0, 2))); B.set_tuning("use_lds", int(rng.integers(0, 2)))
+    if rng.random() < 0.25:
+        B.set_tuning("wide_accumulate", 1)   # (in effect for plain fp32 batches on the L2 path, ignored otherwise)
     Q = np.zeros((m, 4)); T = np.zeros((m, 3))
     for i in range(m):
         q = synth.quat_from_axis_angle(rng.normal(size=3), np.deg2rad(rng.uniform(0, 2.0)))
@@ -83,10 +85,13 @@ while time.time() < t_end:
             rows_checked += 1
     # the riding fold: a pipelined sequence of 2..5 steps ends on ea_batch_eval's sums (1e-13: another summation order),
     # riding and closing folds agree bit for bit
-    if cases % 3 == 0 and B.info("lds_bytes") == 0:
+    if cases % 3 == 0 and B.info("lds_bytes") == 0 and B.info("wide_accumulate") == 0:
         k = int(rng.integers(2, 6))
-        B.bench_capture_pipelined(k)
-        B.bench_steps(k)
+        if cases % 2:
+            B.bench_capture_pipelined(k)
+            B.bench_steps(k)
+        else:
+            B.bench_steps(k, riding=True)   # the same launches without a graph
         last, riding = B.bench_result(), B.bench_result(riding=True)
         for key in ("cost", "JtJ", "Jtr"):
             assert np.array_equal(last[key], riding[key]), (cases, "riding != closing", key)
