@@ -458,13 +458,14 @@ constexpr int kDppRowMirror = 0x140, kDppRowHalfMirror = 0x141, kDppQuadXor2 = 0
 
 template <int CTRL>
 __device__ __forceinline__ float lane_xchg(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+  // (bound_ctrl: every lane of these patterns has a source lane, so no "old" value is needed -- and none is materialised)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
 }
 template <int CTRL>
 __device__ __forceinline__ double lane_xchg(double x) {
   const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, false);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
   return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 __device__ __forceinline__ int wave_min_i32(int x) {
