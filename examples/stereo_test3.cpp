@@ -1,10 +1,12 @@
 // examples/stereo_test3.cpp — the solve block of the reference's stereo tests
 // (ref: standalone/standalone_edge_align.cpp:778-815 for EAResidue + EAResidueSecondCam,
-//  :3195-3233 for EAResidueEx + EAResidueSecondCamEx with TrivialLoss and 100 iterations)
+//  :3195-3233 for EAResidueEx + EAResidueSecondCamEx with TrivialLoss and 100 iterations,
+//  :2590-2626 (tests 7-8) for EAResidue + EAResidueSecondCam with TrivialLoss, 100 iterations and every iterStep-th point,
+//  iterStep = N / minNumOfPointsPerimage)
 // compiled against the drop-in headers.  Input (binary, written by the Python tests):
 //   int32 n1, n2, rows(H), cols(W); double K1[4], K2[4], Kc[5], trans_1to2[16], trans_1to2_inv[16];
 //   double a_X[4*n1], a_X2[4*n2] (column-major 4xN); double e_disTrans[H*W], e_disTrans2[H*W] (column-major)
-// argv[2] = "ex" selects the distortion flavour.  Output: "q0 q1 q2 q3 t0 t1 t2 iterations termination".
+// argv[2] = "ex" selects the distortion flavour, "test7" the subsampled TrivialLoss flavour of tests 7-8.  Output: "q0 q1 q2 q3 t0 t1 t2 iterations termination".
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -18,6 +20,7 @@ using namespace ceres;
 int main(int argc, char **argv) {
   if (argc < 2) return 2;
   const bool ex = argc > 2 && std::strcmp(argv[2], "ex") == 0;
+  const bool test7 = argc > 2 && std::strcmp(argv[2], "test7") == 0;
   std::FILE *f = std::fopen(argv[1], "rb");
   if (!f) return 2;
   int32_t hdr[4];
@@ -43,21 +46,25 @@ int main(int argc, char **argv) {
   double b_quat_a[10] = {1, 0, 0, 0}, b_t_a[10] = {0, 0, 0};
   ceres::Problem problem;
   int count = 0;
-  for (int i = 0; i < n1; i += 1) {
+  const int minNumOfPointsPerimage = 1000;   // (:2590-2595)
+  int iterStep = 1;
+  if (test7 && n1 > minNumOfPointsPerimage) iterStep = n1 / minNumOfPointsPerimage;
+  const bool trivial = ex || test7;
+  for (int i = 0; i < n1; i += iterStep) {
     const double X = a_X[4 * (size_t)i], Y = a_X[4 * (size_t)i + 1], Z = a_X[4 * (size_t)i + 2];
     ceres::CostFunction *cost_function =
         ex ? EAResidueEx::Create(fx, fy, cx, cy, Kc[0], Kc[1], Kc[2], Kc[3], Kc[4], X, Y, Z, interpolated_imb_disTrans)
            : EAResidue::Create(fx, fy, cx, cy, X, Y, Z, interpolated_imb_disTrans);
-    problem.AddResidualBlock(cost_function, ex ? (LossFunction *)new TrivialLoss() : (LossFunction *)new CauchyLoss(1.), b_quat_a, b_t_a);
+    problem.AddResidualBlock(cost_function, trivial ? (LossFunction *)new TrivialLoss() : (LossFunction *)new CauchyLoss(1.), b_quat_a, b_t_a);
     count++;
   }
-  for (int i = 0; i < n2; i += 1) {
+  for (int i = 0; i < n2; i += iterStep) {
     const double X = a_X2[4 * (size_t)i], Y = a_X2[4 * (size_t)i + 1], Z = a_X2[4 * (size_t)i + 2];
     ceres::CostFunction *cost_function =
         ex ? EAResidueSecondCamEx::Create(fx2, fy2, cx2, cy2, Kc[0], Kc[1], Kc[2], Kc[3], Kc[4], X, Y, Z, trans_1to2,
                                           trans_1to2_inv, interpolated_imb_disTrans2)
            : EAResidueSecondCam::Create(fx2, fy2, cx2, cy2, X, Y, Z, trans_1to2, trans_1to2_inv, interpolated_imb_disTrans2);
-    problem.AddResidualBlock(cost_function, ex ? (LossFunction *)new TrivialLoss() : (LossFunction *)new CauchyLoss(1.), b_quat_a, b_t_a);
+    problem.AddResidualBlock(cost_function, trivial ? (LossFunction *)new TrivialLoss() : (LossFunction *)new CauchyLoss(1.), b_quat_a, b_t_a);
     count++;
   }
   std::cerr << "-----> Use Point count = " << count << "\n";
@@ -65,7 +72,7 @@ int main(int argc, char **argv) {
   problem.SetParameterization(b_quat_a, quaternion_parameterization);
   ceres::Solver::Options options;
   options.linear_solver_type = ceres::DENSE_QR;
-  if (ex) options.max_num_iterations = 100;
+  if (trivial) options.max_num_iterations = 100;
   Solver::Summary summary;
   ceres::Solve(options, &problem, &summary);
   std::cerr << summary.BriefReport() << "\n";

@@ -132,10 +132,12 @@ def test_ros_frames_full_resolution_resized_on_device(binaries, oracle, tmp_path
     assert int(v[7]) == so["termination"]
 
 
-@pytest.mark.parametrize("ex", [False, True])
+@pytest.mark.parametrize("ex", [False, True, "test7"])
 def test_stereo_call_sequence(binaries, oracle, tmp_path, ex):
-    """standalone_edge_align.cpp:778-815 (EAResidue + EAResidueSecondCam, CauchyLoss) and :3195-3233
-    (EAResidueEx + EAResidueSecondCamEx, TrivialLoss, 100 iterations) through the drop-in headers"""
+    """standalone_edge_align.cpp:778-815 (EAResidue + EAResidueSecondCam, CauchyLoss), :3195-3233
+    (EAResidueEx + EAResidueSecondCamEx, TrivialLoss, 100 iterations) and :2590-2626 (tests 7-8: the plain functors,
+    TrivialLoss, 100 iterations, every iterStep-th point with iterStep = N / 1000) through the drop-in headers"""
+    test7, ex = ex == "test7", ex is True
     K1 = (130.0, 132.0, 79.5, 59.5)
     K2 = (128.0, 129.0, 81.0, 58.0)
     dist = (0.2624, -0.9531, -0.0054, 0.0026, 1.1633)
@@ -154,18 +156,20 @@ def test_stereo_call_sequence(binaries, oracle, tmp_path, ex):
             f.write(np.ascontiguousarray(aX, dtype=np.float64).tobytes())
         for fam in fams:
             f.write(np.ascontiguousarray(fam["grid"], dtype=np.float64).tobytes())
-    out = subprocess.run([os.path.join(binaries, "stereo_test3"), p] + (["ex"] if ex else []), capture_output=True, text=True)
+    out = subprocess.run([os.path.join(binaries, "stereo_test3"), p] + (["ex"] if ex else ["test7"] if test7 else []),
+                         capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     v = [float(x) for x in out.stdout.split()]
     q, t = np.array(v[:4]), np.array(v[4:7])
-    loss = oracle.LOSS_TRIVIAL if ex else oracle.LOSS_CAUCHY
+    loss = oracle.LOSS_TRIVIAL if (ex or test7) else oracle.LOSS_CAUCHY
+    step = 3000 // 1000 if test7 else 1   # (iterStep comes from the first family's count for both loops, :2590-2611)
     O1 = oracle.OracleProblem(fams[0]["grid"], *K1, loss=loss, distortion=dist if ex else None)
     O2 = oracle.OracleProblem(fams[1]["grid"], *K2, loss=loss, distortion=dist if ex else None, T12=T12)
-    qo, to, so = oracle.solve_terms([O1, O2], [fams[0]["xyz"], fams[1]["xyz"]], [1, 0, 0, 0], [0, 0, 0],
-                                    max_num_iterations=100 if ex else 50)
+    qo, to, so = oracle.solve_terms([O1, O2], [fams[0]["xyz"][::step].copy(), fams[1]["xyz"][::step].copy()], [1, 0, 0, 0], [0, 0, 0],
+                                    max_num_iterations=100 if (ex or test7) else 50)
     assert synth.rotation_angle_between(q, qo) < 1e-7 and np.linalg.norm(t - to) < 1e-7
     assert int(v[8]) == so["termination"]
-    assert "Use Point count = 5000" in out.stderr
+    assert "Use Point count = %d" % (len(range(0, 3000, step)) + len(range(0, 2000, step))) in out.stderr
 
 
 def test_c_abi_from_plain_c(binaries, hip, bundled_pair, tmp_path):
