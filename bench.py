@@ -650,9 +650,10 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             leg[0] = "cpu baseline"
-            extras["cpu_baseline"] = cpu_baseline(cfg, loss)
+            scale = float(os.environ.get("EA_BENCH_CPU_SAMPLE_SCALE", "1"))   # (tests/test_gpu_bench_line.py shortens the sample)
+            extras["cpu_baseline"] = cpu_baseline(cfg, loss, budget_s=12.0 * scale)
             try:
-                extras["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cfg, loss)
+                extras["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cfg, loss, budget_s=6.0 * scale)
             except Exception as e:  # a reported extra, never a reason to lose the line
                 extras["cpu_baseline_all_cores"] = {"error": repr(e)}
         out = compose()
