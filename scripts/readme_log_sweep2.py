@@ -1,0 +1,78 @@
+"""Second sweep for the reference's recorded solve (standalone/README.md:26-71, initial cost 8.743202): the knobs the comment
+block of get_distance_transform names (utils.cpp:40-44) that scripts/readme_log_sweep.py had not varied -- Gaussian kernel
+size (none / 3 / 5 / 7), Laplacian aperture (1 / 3), median window (none / 3 / 5), distance-transform mask (3x3 chamfer, 5x5
+chamfer, exact), threshold, channel order -- for B = 2..5: 4584 combinations.  CPU only, test tooling (oracle/preprocess_np.py +
+scipy; the variants outside the shipped producer are plain floating-point restatements, good to ~1e-4 in the cost, which is
+enough to see whether a combination comes close).  The initial cost needs no solve: at the identity pose every sampled point
+projects onto its own pixel, where the bicubic interpolant returns the texel, so cost0 = 1/2 sum log(1 + DT[v,u]^2).
+Output: the 40 closest combinations -> profiles/r02_readme_log_sweep.txt (second part)."""
+import os, sys, itertools, numpy as np, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import preprocess_np as pp, ea_oracle as eo
+from scipy import ndimage as ndi
+G=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),'tests','golden','rgbd'); K=(525.0,525.0,319.5,239.5)
+imgs={b: pp.load_rgb_as_bgr(os.path.join(G,'rgb_%d.png'%b)) for b in range(1,6)}
+deps={b: pp.load_depth_u16(os.path.join(G,'depth_%d.png'%b)) for b in range(1,6)}
+aX,_=pp.get_aX(imgs[1],deps[1],*K)
+N=aX.shape[1]
+# pixel positions of the sampled A points: identity pose -> u = fx X/Z + cx
+Xs=aX[:3,::30]
+u=np.rint(K[0]*Xs[0]/Xs[2]+K[2]).astype(int); v=np.rint(K[1]*Xs[1]/Xs[2]+K[3]).astype(int)
+print('N',N,'blocks',len(u))
+def cost0(dt):  # 0.5 sum log(1+d^2) at integer pixels (bicubic returns the texel there)
+    d=dt[v,u].astype(np.float64); return 0.5*np.log1p(d*d).sum()
+def gauss_u8(img,k):
+    if k==0: return img
+    if k==3: return pp.gaussian_blur3_u8(img)
+    w={5:np.array([1,4,6,4,1],float)/16, 7:np.array([0.03125,0.109375,0.21875,0.28125,0.21875,0.109375,0.03125])}[k]
+    a=img.astype(np.float64)
+    a=ndi.correlate1d(a,w,axis=0,mode='mirror'); a=ndi.correlate1d(a,w,axis=1,mode='mirror')
+    return np.clip(np.rint(a),0,255).astype(np.uint8)
+def lap_u8(gray,ks):
+    g=gray.astype(np.int32)
+    if ks==3: return pp.laplacian3_abs_u8(gray)
+    kern=np.array([[0,1,0],[1,-4,1],[0,1,0]])
+    l=ndi.correlate(g,kern,mode='mirror')
+    return np.clip(np.abs(l),0,255).astype(np.uint8)
+A5,B5,C5=1.0,1.4,2.1969
+def chamfer5(zero):
+    H,W=zero.shape; BIG=1e9
+    t=np.full((H+4,W+4),BIG); 
+    for i in range(2,H+2):
+        up=t[i-1]; up2=t[i-2]
+        c=np.minimum.reduce([up[1:-3]+B5, up[2:-2]+A5, up[3:-1]+B5, up[0:-4]+C5, up[4:]+C5, up2[1:-3]+C5, up2[3:-1]+C5])
+        c=np.where(zero[i-2],0,c)
+        k=np.arange(W)*A5
+        row=np.minimum.accumulate(c-k)+k
+        t[i,2:-2]=np.minimum(row,BIG)
+    for i in range(H+1,1,-1):
+        dn=t[i+1]; dn2=t[i+2]
+        c=np.minimum.reduce([dn[1:-3]+B5, dn[2:-2]+A5, dn[3:-1]+B5, dn[0:-4]+C5, dn[4:]+C5, dn2[1:-3]+C5, dn2[3:-1]+C5, t[i,2:-2]])
+        k=np.arange(W)*A5
+        cr=c[::-1]; row=(np.minimum.accumulate(cr-k)+k)[::-1]
+        t[i,2:-2]=np.minimum(row,BIG)
+    return t[2:-2,2:-2].astype(np.float32)
+def norm(d):
+    return (d-d.min())/(d.max()-d.min())
+res=[]
+for b in (5,4,3,2):
+  img=imgs[b]
+  for gk, order in itertools.product((3,5,0,7),('bgr','rgb')):
+    im = img if order=='bgr' else img[:,:,::-1].copy()
+    gray=pp.rgb2gray_u8(gauss_u8(im,gk))
+    for lk in (3,1):
+      es=lap_u8(gray,lk)
+      for thr in ((20,25,30,35,40,45,50,60) if lk==3 else (5,8,10,12,15,20,25,35)):
+        Bm0=np.where(es>thr,0,255).astype(np.uint8)
+        for med in (0,3,5):
+            Bm = Bm0 if med==0 else (pp.median_blur3_u8(Bm0) if med==3 else ndi.median_filter(Bm0,size=5,mode='nearest'))
+            if not (Bm==0).any(): continue
+            for kind in ('l2_3','l2_5','precise'):
+                if kind=='l2_3': d=pp.distance_transform_l2_3(Bm)
+                elif kind=='l2_5': d=chamfer5(Bm==0)
+                else: d=ndi.distance_transform_edt(Bm!=0).astype(np.float32)
+                c=cost0(norm(d.astype(np.float64)))
+                res.append((abs(c-8.743202),c,b,gk,order,lk,thr,med,kind))
+    print('B',b,'gk',gk,order,'done',len(res),flush=True)
+res.sort()
+for r in res[:40]: print('%.6f  cost %.6f  B%d gauss %d %s lap_k %d thr %d med %d %s'%r)
