@@ -139,6 +139,92 @@ def cpu_baseline_all_cores(cfg, loss, budget_s=6.0):
             "sample": "analytic-Jacobian oracle, %d threads x shards of the first %d points, fp64, %.1f s" % (cores, n, el)}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n):
+    """`python3 bench.py --gpus N` with no launcher in the environment: THIS process becomes the parent of N fresh rank
+    processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one per GPU) and never touches the GPU itself -- no torch
+    import, no HIP call, nothing re-executed in a process that has initialised a device.  Rank 0's stdout (the ONE JSON
+    line) is relayed; every rank's stderr is inherited; the exit code is non-zero if any rank fails, and the others are
+    terminated once one has failed (they would wait for it in a collective)."""
+    import signal
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("MASTER_PORT", str(_free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(n)
+    env["EA_BENCH_GPUS_ON_BOX"] = env.get("EA_BENCH_GPUS_ON_BOX", str(n))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, cwd=ROOT))
+    line = []
+
+    def relay():
+        for raw in procs[0].stdout:
+            line.append(raw)
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    rc, failed_at = 0, None
+    try:
+        while any(p.poll() is None for p in procs):
+            for r, p in enumerate(procs):
+                c = p.poll()
+                if c not in (None, 0) and rc == 0:
+                    rc, failed_at = c, time.perf_counter()
+                    sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, c))
+            if failed_at is not None and time.perf_counter() - failed_at > 10.0:
+                for p in procs:
+                    if p.poll() is None:
+                        p.send_signal(signal.SIGTERM)
+                failed_at = time.perf_counter() + 1e9
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        rc = 130
+    for r, p in enumerate(procs):
+        c = p.wait()
+        if c != 0 and rc == 0:
+            rc = c
+    th.join(timeout=5.0)
+    # the contract is ONE JSON line on stdout: anything else rank 0 (or a library under it: gloo announces its peers on
+    # stdout) printed goes to stderr
+    for raw in line:
+        txt = raw.decode(errors="replace")
+        (sys.stdout if txt.lstrip().startswith("{") else sys.stderr).write(txt)
+    sys.stdout.flush()
+    return rc if rc >= 0 else 128 - rc
+
+
+def launcher_selftest(rank, world, args):
+    """tests/test_bench_launcher.py (CPU): what a rank does with the environment launch_ranks() gave it, minus the GPU --
+    rendezvous over gloo, one all-reduce, rank 0 prints a line carrying the world size every rank saw."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1), 1.0], dtype=torch.float64)
+    dist.all_reduce(t)
+    fail_rank = os.environ.get("EA_BENCH_LAUNCHER_SELFTEST_FAIL")
+    if fail_rank is not None and int(fail_rank) == rank:
+        os._exit(7)   # (a rank that dies: the parent must report it and stop the others)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": int(t[1].item()), "rank_sum": t[0].item(), "steps": args.steps,
+                          "master": os.environ.get("MASTER_ADDR") + ":" + os.environ.get("MASTER_PORT")}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,11 +249,18 @@ def main():
                     help="world size 1: create the process group anyway and take the N>1 branches (RCCL on a one-rank group)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no torch.distributed.run around us: start the N ranks ourselves (nothing below runs in this process)
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if os.environ.get("EA_BENCH_LAUNCHER_SELFTEST"):
+        return launcher_selftest(rank, world, args)
 
     import torch  # plumbing only: process group (RCCL), barriers, device sync
     dist = None
@@ -378,12 +471,21 @@ def main():
         if rank == 0:
             sys.stdout.write(json.dumps(compose("timed out after %.0f s in: %s" % (args.extras_timeout, leg[0]))) + "\n")
             sys.stdout.flush()
+        # a leg that hangs is a finding, not an "ok": the line above keeps the mandatory part of the record, the exit
+        # code and stderr say what stalled so that it can be fixed once
+        try:
+            last = capi.load().ea_last_error().decode()
+        except Exception:
+            last = "?"
+        sys.stderr.write("bench.py: rank %d: extras watchdog fired after %.0f s in leg %r; last library error: %r\n"
+                         % (rank, args.extras_timeout, leg[0], last))
+        sys.stderr.flush()
         try:
             if node_barrier is not None:
                 node_barrier.close()
         except Exception:
             pass
-        os._exit(0)
+        os._exit(3)
     watchdog = threading.Timer(args.extras_timeout, on_timeout)
     watchdog.daemon = True
     if not args.no_extras:
