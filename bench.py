@@ -6,12 +6,15 @@
 
 A "step" is one pass of the hot path over one frame pair's edge cloud with the inputs already
 resident in HBM: the fused per-point kernel (SE(3) warp, pinhole, bicubic DT sample, analytic 1x6
-row, IRLS weight, JtJ/Jtr/cost partials) plus the fixed-order fold of the partials — exactly what
-one evaluation inside the trust-region loop costs.  The K timed steps are K independent evaluations at
-the resident pose, replayed from one hipGraph in which the fold of step k-1 rides in the launch of
-evaluation k (one extra workgroup per problem; K launches + one closing fold, every step still runs
-both parts in full; --serial-steps gives the two-dependent-launches form, whose per-step time the
-line also carries as roofline.step_ms_events_serial_graph).  Default workload = BASELINE.json configs[1]
+row, IRLS weight, JtJ/Jtr/cost partials) plus the fixed-order fold of the partials.  The K timed steps
+are ONE call of the product API ea_batch_eval_resident_poses (include/ea_hip.h): K INDEPENDENT
+evaluations at K DIFFERENT poses -- the throughput a caller gets who asks for many evaluations at
+once (cost-surface probes, a line search, its own optimiser) -- in which the fold of step k-1 rides
+in the launch of step k.  It is NOT the cost of an evaluation inside the trust-region loop, where
+step k+1 depends on the fold and the LM step of k: that dependent form (evaluation -> fold, two
+launches per step) is carried beside the headline as `value_serial_dependent_steps` /
+roofline.step_ms_events_serial_dependent, and --serial-steps makes it the timed region; the loop
+itself is measured by lm_iters_per_s_at_1e5_pts.  Default workload = BASELINE.json configs[1]
 (C2): single 640x480 frame pair, 5e4 edge points, fp64.  With N GPUs every rank evaluates its own
 independent frame pair (weak scaling, no data-path collective); the one collective is the pose
 all-gather (RCCL) after the per-rank LM solves, reported separately.
@@ -74,6 +77,32 @@ def valu_issue(workload_key, kernel_ms):
     return {"bound": "valu_issue", "achieved": achieved, "peak": VALU_PEAK_IPS, "unit": "wave64 instr/s",
             "frac": achieved / VALU_PEAK_IPS, "measured_ceiling": ceiling, "frac_of_measured_ceiling": achieved / ceiling,
             "sq_insts_valu_per_launch": n, "source": "profiles/pmc_valu.json (rocprofv3 --pmc SQ_INSTS_VALU) / live kernel time"}
+
+
+def step_poses(K, seed):
+    """K different poses for the K timed steps: seeded perturbations of the identity (rotation <= 0.2 deg about a random
+    axis, translation <= 5 mm per axis) -- every step samples other stencil fractions, no two steps repeat a launch"""
+    from edge_alignment_amd import synth
+    rng = np.random.default_rng(seed)
+    Q, T = np.zeros((K, 1, 4)), np.zeros((K, 1, 3))
+    for k in range(K):
+        Q[k, 0] = synth.quat_from_axis_angle(rng.normal(size=3), np.deg2rad(rng.uniform(0.0, 0.2)))
+        T[k, 0] = rng.uniform(-0.005, 0.005, size=3)
+    return Q, T
+
+
+def counter_busy(workload_key, kernel_ms):
+    """A kernel duration that is neither this script's hipEvent clock nor the tracer's bracket: GPU-busy cycles per launch
+    from a committed PMC pass (profiles/pmc_busy.json: rocprofv3 --pmc GRBM_GUI_ACTIVE / SQ_BUSY_CYCLES on this command) over
+    the shader clock.  Reported beside the live figure with their ratio."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_busy.json")))[workload_key]
+    except Exception:
+        return None
+    out = dict(d)
+    if d.get("kernel_ms_from_counters"):
+        out["live_over_counters"] = kernel_ms / d["kernel_ms_from_counters"]
+    return out
 
 
 def algorithmic_bytes(n_points, H, W, esize):
@@ -316,36 +345,42 @@ def main():
     q0, t0 = np.array([1.0, 0, 0, 0]), np.zeros(3)
 
     # Untimed: descriptors + pose upload + W warm-up steps (ea_batch_bench_eval builds the batch, uploads the poses and
-    # creates its events).  Timed: EXACTLY K steps between barrier+sync brackets -- ea_batch_bench_steps only enqueues
-    # K x (fused eval + fold) at the resident poses and synchronises the stream, no setup inside the bracket.
+    # creates its events), then the K poses of the timed region go up (inputs resident in HBM when the clock starts) and
+    # their sequence is run once (captures the graph) plus EA_BENCH_WARM_REPLAYS times more.
+    # Timed: EXACTLY K steps between barrier+sync brackets = ONE call of the product API ea_batch_eval_resident_poses --
+    # K evaluations at K DIFFERENT poses (no two steps read the same stencils), each its per-point kernel and its fold in
+    # full, the fold of step k-1 riding in the launch of step k, one synchronisation, the K results unpacked into the
+    # caller's arrays.  --serial-steps: the LM loop's dependency instead (evaluation -> fold, two dependent launches per
+    # step, at the resident pose; a measurement hook).
     B.bench_eval(q0, t0, 0, max(args.warmup, 1), kernel_pass=False)
-    graph, pipelined = None, False
-    if not args.no_graph:
-        # untimed: the K steps as one hipGraph (launch-bound inner loop).  Default: the fold of step k-1 rides in the launch
-        # of evaluation k (ea_batch_bench_capture_pipelined: K launches + one closing fold; the K passes are independent
-        # evaluations at the resident poses, every step still runs its evaluation and its fold in full).  --serial-steps:
-        # evaluation -> fold -> evaluation ..., two dependent launches per step.
-        if not args.serial_steps:
-            try:
-                B.bench_capture_pipelined(args.steps)
-                graph = "hipGraph of %d steps (evaluation k + riding fold k-1 per kernel node, one closing fold), one replay" % args.steps
-                pipelined = True
-            except capi.EAError as e:
-                graph = None
-        if graph is None:
-            try:
-                B.bench_capture(args.steps)
-                graph = "hipGraph of %d steps (2 kernel nodes per step), one replay" % args.steps
-            except capi.EAError as e:
-                graph = "eager launches (graph capture failed: %s)" % e
-    # untimed warm-up of the region itself: the capture above replayed the graph once (that replay uploads it); further
-    # replays settle what the first one leaves cold (EA_BENCH_WARM_REPLAYS, default 2; profiles/r02_bench_warm_replays.txt)
-    warm_replays = int(os.environ.get("EA_BENCH_WARM_REPLAYS", "2")) if graph and graph.startswith("hipGraph") else 0
-    for _ in range(warm_replays):
-        B.bench_steps(args.steps)
+    Qk, Tk = step_poses(args.steps, 1000 + rank)
+    mode = "serial" if (args.serial_steps or args.no_graph) else "poses"
+    graph, pipelined, out_k, warm_replays = None, False, None, 0
+    if mode == "poses":
+        B.set_poses(Qk, Tk)
+        out_k = B.eval_resident_poses()
+        pipelined = bool(B.info("poses_ride"))   # (plain single-family batch on the L2 path: the riding form)
+        graph = ("ea_batch_eval_resident_poses: %d evaluations at %d different poses (rotations <= 0.2 deg, translations <= 5 mm "
+                 "around the identity), one call; K launches (evaluation k + riding fold k-1) + one closing fold replayed from "
+                 "one hipGraph, one synchronisation, results unpacked" % (args.steps, args.steps))
+        warm_replays = int(os.environ.get("EA_BENCH_WARM_REPLAYS", "2"))
+        for _ in range(warm_replays):
+            B.eval_resident_poses(out=out_k)
+    elif not args.no_graph:
+        try:
+            B.bench_capture(args.steps)
+            graph = "hipGraph of %d dependent steps at one pose (evaluation -> fold, 2 kernel nodes per step), one replay" % args.steps
+            warm_replays = int(os.environ.get("EA_BENCH_WARM_REPLAYS", "2"))
+            for _ in range(warm_replays):
+                B.bench_steps(args.steps)
+        except capi.EAError as e:
+            graph = "eager launches (graph capture failed: %s)" % e
     barrier_sync()
     t_start = time.perf_counter()
-    B.bench_steps(args.steps)
+    if mode == "poses":
+        B.eval_resident_poses(out=out_k)
+    else:
+        B.bench_steps(args.steps)
     barrier_sync()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
@@ -363,44 +398,75 @@ def main():
             barrier_sync()
             costs.append(time.perf_counter() - tb)
         bracket_ms = min(costs) * 1e3
-    # the timed launches computed what ea_batch_eval computes (the riding folds sum in another order: equal to rounding)
-    got, want = B.bench_result(), B.eval(q0, t0)
+    # the timed steps computed what ea_batch_eval computes at their poses (first, middle and last step checked; the riding
+    # folds sum in another order: equal to rounding)
+    if mode == "poses":
+        for k in sorted({0, args.steps // 2, args.steps - 1}):
+            want = B.eval(Qk[k], Tk[k])
+            if not (np.allclose(out_k["cost"][k], want["cost"], rtol=1e-12, atol=0) and np.allclose(out_k["JtJ"][k], want["JtJ"], rtol=1e-11, atol=1e-300)
+                    and np.allclose(out_k["Jtr"][k], want["Jtr"], rtol=1e-10, atol=1e-300) and np.array_equal(out_k["n_invalid"][k], want["n_invalid"])):
+                raise SystemExit("bench.py: timed step %d differs from ea_batch_eval at its pose" % k)
+        if args.steps > 1 and np.array_equal(out_k["cost"][0], out_k["cost"][-1]):
+            raise SystemExit("bench.py: the timed steps were not evaluated at different poses")
+    else:
+        got, want = B.bench_result(), B.eval(q0, t0)
+        if not (np.allclose(got["cost"], want["cost"], rtol=1e-12, atol=0) and np.allclose(got["JtJ"], want["JtJ"], rtol=1e-12, atol=1e-300)
+                and np.allclose(got["Jtr"], want["Jtr"], rtol=1e-11, atol=1e-300) and np.array_equal(got["n_invalid"], want["n_invalid"])):
+            raise SystemExit("bench.py: the timed steps' result differs from ea_batch_eval's")
+    # the product calls by the wall clock, beside the headline: one ea_batch_eval (launch pair + synchronisation), and
+    # ea_batch_eval_poses all in one (pose upload and device-side pose constants inside)
+    B.eval(q0, t0)
+    tl = time.perf_counter()
+    for _ in range(50):
+        B.eval(q0, t0)
+    single_eval_ms = (time.perf_counter() - tl) / 50 * 1e3
+    eval_poses_call_ms = None
+    if mode == "poses":
+        B.eval_poses(Qk, Tk)
+        tl = time.perf_counter()
+        for _ in range(5):
+            B.eval_poses(Qk, Tk)
+        eval_poses_call_ms = (time.perf_counter() - tl) / 5 * 1e3
     B.bench_eval(q0, t0, 0, 1, kernel_pass=False)  # (poses resident again for the measurements below)
-    if not (np.allclose(got["cost"], want["cost"], rtol=1e-12, atol=0) and np.allclose(got["JtJ"], want["JtJ"], rtol=1e-12, atol=1e-300)
-            and np.allclose(got["Jtr"], want["Jtr"], rtol=1e-11, atol=1e-300) and np.array_equal(got["n_invalid"], want["n_invalid"])):
-        raise SystemExit("bench.py: the timed steps' result differs from ea_batch_eval's")
 
     # Duration of the dominant kernel, HIP events on the library's stream.
-    #   kernel_ms               pipelined region: (event pair around nk >= 100 replayed steps) / nk -- a step IS one launch of
-    #                           the evaluation kernel (with the previous step's fold riding in it), the figure rocprofv3
-    #                           --kernel-trace reports per launch for this command (profiles/); serial region: the
-    #                           evaluation's share of a step = that quotient minus the fold kernel's own time.  Never below
-    #                           kernel_ms_back_to_back.  `achieved` / `frac` are computed from it;
+    #   kernel_ms               (event pair around replays of nk >= 100 steps at nk different poses) / nk -- a step IS one
+    #                           launch of the evaluation kernel (with the previous step's fold riding in it), the figure
+    #                           rocprofv3 --kernel-trace reports per launch for this command (profiles/); serial region:
+    #                           the evaluation's share of a step = that quotient minus the fold kernel's own time.  Never
+    #                           below kernel_ms_back_to_back.  `achieved` / `frac` are computed from it;
     #   kernel_ms_back_to_back  one event pair around a run of plain evaluation launches executing from the queue, / their
     #                           number: the kernel's execution window with the next dispatch already decoded;
     #   kernel_ms_isolated      an event pair around every single launch of the serial pattern, which also contains the
-    #                           command processor's dispatch (~2.6 us) because nothing is in flight to hide it.
+    #                           command processor's dispatch (~2.6 us) because nothing is in flight to hide it;
+    #   launch_floor_ms         an EMPTY kernel of the same grid in a replayed graph of nk nodes: what the launch mechanism
+    #                           costs per node whatever the kernel does -- frac_ceiling_at_floor = algorithmic bytes /
+    #                           launch_floor_ms / peak is the most this workload's ONE launch per step could reach.
     nk = min(max(args.steps, 100), 1000)
     ms_steps, ms_kernel_isolated = B.bench_eval(q0, t0, 2, min(args.steps, 64))
     ms_steps, _ = B.bench_eval(q0, t0, 20, nk, kernel_pass=False)       # launch by launch (host-bound: ~3.1 us per launch)
     step_ms_eager = ms_steps / nk
     step_ms_serial = step_ms_pipelined = None
-    if graph and graph.startswith("hipGraph"):
-        # the launch patterns as hipGraphs of nk steps between an event pair on the library's stream; nk >= 100 so that a
-        # short --steps run does not measure the first nodes' ramp instead of the kernel
+    try:
         B.bench_capture(nk)
         step_ms_serial = min(B.bench_steps(nk, host_times=True)[2] for _ in range(3)) / nk
-        if pipelined:
-            B.bench_capture_pipelined(nk)
-            step_ms_pipelined = min(B.bench_steps(nk, host_times=True)[2] for _ in range(3)) / nk
-    else:
+    except capi.EAError:
         step_ms_serial = step_ms_eager
+    if pipelined:
+        Qn, Tn = step_poses(nk, 2000 + rank)
+        B.set_poses(Qn, Tn)
+        step_ms_pipelined = min(B.bench_resident_poses(3) for _ in range(3)) / nk
+        B.bench_eval(q0, t0, 0, 1, kernel_pass=False)
     ms_fold = B.bench_fold(10, nk)
     ms_kernel_b2b = B.bench_kernel(q0, t0, 10, nk)
     step_ms = step_ms_pipelined if pipelined else step_ms_serial
     ms_kernel = max(step_ms if pipelined else step_ms - ms_fold, ms_kernel_b2b)
     bytes_launch = algorithmic_bytes(n_pts, H, W, esize)
     achieved = bytes_launch / (ms_kernel * 1e-3) / 1e9
+    try:
+        floor_ms = capi.graph_floor_ms(local_rank, nodes=nk, grid=max(1, int(B.info("num_tiles"))), block=int(B.info("threads")))
+    except capi.EAError:
+        floor_ms = None
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
@@ -415,9 +481,14 @@ def main():
                 "kernel": "%s<%s>" % ("ea_eval_fold_kernel" if pipelined else "ea_eval_fused_kernel", "double" if esize == 8 else "float"),
                 "kernel_ms": ms_kernel, "kernel_ms_back_to_back": ms_kernel_b2b,
                 "frac_back_to_back": bytes_launch / (ms_kernel_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "fold_kernel_ms": ms_fold, "step_ms_events": step_ms, "step_ms_events_serial_graph": step_ms_serial,
+                "launch_floor_ms": floor_ms,
+                "frac_ceiling_at_floor": (bytes_launch / (floor_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if floor_ms else None,
+                "frac_of_ceiling_at_floor": (floor_ms / ms_kernel) if floor_ms else None,
+                "fold_kernel_ms": ms_fold, "step_ms_events": step_ms,
+                "step_ms_events_serial_dependent": step_ms_serial,
                 "step_ms_events_eager_launches": step_ms_eager, "kernel_ms_isolated": ms_kernel_isolated,
                 "algorithmic_bytes_per_launch": bytes_launch,
+                "counter_busy": counter_busy(args.workload, ms_kernel),
                 "secondary": valu_issue(args.workload, ms_kernel_b2b)}
 
     # Materialised mode of the same workload ("report both numbers"): r and the 1x6 row of every point written
@@ -450,10 +521,17 @@ def main():
                            "tiles": B.info("num_tiles"), "points_per_thread": B.info("points_per_thread"),
                            "lds_bytes": B.info("lds_bytes"), "point_order_tile_px": P.point_order,
                            "timed_region": graph or "eager launches",
-                           "untimed_warmup": "%d launch-by-launch steps, then %d replays of the timed region's graph" % (max(args.warmup, 1), 1 + warm_replays)
-                                             if warm_replays or (graph and graph.startswith("hipGraph")) else "%d launch-by-launch steps" % max(args.warmup, 1),
+                           "untimed_warmup": "%d launch-by-launch steps at one pose, the upload of the K poses, then %d runs of the timed call" % (max(args.warmup, 1), 1 + warm_replays)
+                                             if mode == "poses" else "%d launch-by-launch steps, then %d replays of the timed region" % (max(args.warmup, 1), warm_replays),
                            "closing_barrier_and_sync_ms_on_idle_gpus": bracket_ms,
                            "bracket_barrier": None if dist is None else ("shared-memory epoch barrier (one node)" if node_barrier is not None else "torch.distributed.barrier")},
+                # the same workload with the trust-region loop's dependency (evaluation -> fold, two dependent launches per
+                # step, replayed from a graph): what ONE evaluation costs when the next one needs its result
+                "value_serial_dependent_steps": world * n_pts / (step_ms_serial * 1e-3) if step_ms_serial else None,
+                "single_eval_call_ms": single_eval_ms, "eval_poses_call_ms": eval_poses_call_ms,
+                "calls": {"timed": "ea_batch_eval_resident_poses (K poses resident)" if mode == "poses" else "ea_batch_bench_steps (hook)",
+                          "single_eval_call_ms": "ea_batch_eval: pose upload, evaluation, fold, synchronisation -- wall clock",
+                          "eval_poses_call_ms": "ea_batch_eval_poses(K = steps): pose upload + device-side pose constants + the K evaluations -- wall clock"},
                 "roofline": roofline, "materialised_mode": mat}
     extras, others, leg = {}, {}, ["start"]
 

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # strategy (a wave of occupancy in fp64) and keep the default one.
 SOURCES = [("csrc/ea_kernels.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]), ("csrc/ea_kernels_var.hip", []),
            ("csrc/ea_preprocess.hip", []), ("csrc/ea_capi.hip", [])]
-HEADERS = ["csrc/ea_types.h", "csrc/ea_lm.h", "csrc/ea_spin.h", "../include/ea_hip.h"]
+HEADERS = ["csrc/ea_types.h", "csrc/ea_lm.h", "csrc/ea_spin.h", "csrc/ea_hip_dev.h", "../include/ea_hip.h"]
 LIB = os.path.join(_HERE, "lib", "libea_hip.so")
 # -amdgpu-kernarg-preload-count: the command processor hands the first 16 dwords of the kernel-argument segment to
 # every wave in SGPRs, so a kernel does not start with a scalar load of its own pointers and a wait (gfx950; kernels

@@ -29,14 +29,24 @@ EXPORTED = [
     "ea_problem_set_loss", "ea_problem_set_flavour", "ea_problem_num_points",
     "ea_eval", "ea_eval_points", "ea_cost", "ea_problem_pixel_cost", "ea_solve",
     "ea_release_cached_memory", "ea_batch_create", "ea_batch_destroy", "ea_batch_count", "ea_batch_eval", "ea_batch_solve",
+    "ea_batch_eval_poses", "ea_batch_set_poses", "ea_batch_eval_resident_poses",
     "ea_solve_pyramid", "ea_solve_sharded", "ea_solve_sharded_device", "ea_tracker_create", "ea_tracker_destroy", "ea_tracker_problem", "ea_tracker_push_frame",
-    "ea_batch_bench_eval", "ea_batch_bench_steps", "ea_batch_bench_capture", "ea_batch_bench_capture_pipelined", "ea_batch_bench_steps_riding", "ea_batch_bench_result", "ea_batch_bench_result_riding", "ea_batch_bench_kernel", "ea_batch_bench_rows", "ea_batch_row_offsets", "ea_problem_num_rows", "ea_eval_rows", "ea_eval_rows_device", "ea_batch_eval_rows_device", "ea_batch_eval_rows", "ea_batch_bench_fold", "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
+    "ea_batch_row_offsets", "ea_problem_num_rows", "ea_eval_rows", "ea_eval_rows_device", "ea_batch_eval_rows_device", "ea_batch_eval_rows",
+    "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
     "ea_problem_set_ref_frame", "ea_problem_set_ref_frame_masked", "ea_problem_set_now_frame", "ea_problem_debug_now_frame",
     "ea_problem_set_ref_frame_canny", "ea_problem_set_now_frame_canny", "ea_problem_debug_now_frame_canny",
     "ea_problem_set_ref_frame_ros", "ea_problem_set_now_frame_ros", "ea_problem_debug_now_frame_ros",
     "ea_problem_set_ref_frame_ros_scaled", "ea_problem_set_now_frame_ros_scaled", "ea_resize_half",
     "ea_problem_get_points", "ea_problem_get_dt",
     "ea_problem_set_distortion", "ea_problem_set_second_camera", "ea_problem_add_term", "ea_problem_clear_terms",
+]
+
+# measurement hooks (edge_alignment_amd/csrc/ea_hip_dev.h): bound by bench.py, the A/B scripts and the tests that pin the
+# launch patterns; not part of the drop-in boundary
+EXPORTED_DEV = [
+    "ea_batch_bench_eval", "ea_batch_bench_steps", "ea_batch_bench_capture", "ea_batch_bench_capture_pipelined", "ea_batch_bench_steps_riding",
+    "ea_batch_bench_result", "ea_batch_bench_result_riding", "ea_batch_bench_kernel", "ea_batch_bench_rows", "ea_batch_bench_fold",
+    "ea_batch_bench_resident_poses", "ea_bench_graph_floor",
 ]
 
 
@@ -127,6 +137,9 @@ def load():
     L.ea_batch_count.argtypes = [vp]
     L.ea_batch_eval.argtypes = [vp, dp, dp, dp, dp, dp, i64p]
     L.ea_batch_solve.argtypes = [vp, C.POINTER(Options), dp, dp, C.POINTER(Summary)]
+    L.ea_batch_eval_poses.argtypes = [vp, C.c_int, dp, dp, dp, dp, dp, i64p]
+    L.ea_batch_set_poses.argtypes = [vp, C.c_int, dp, dp]
+    L.ea_batch_eval_resident_poses.argtypes = [vp, dp, dp, dp, i64p]
     L.ea_batch_bench_eval.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp, dp]
     L.ea_batch_bench_steps.argtypes = [vp, C.c_int, dp]
     L.ea_batch_bench_capture.argtypes = [vp, C.c_int]
@@ -136,6 +149,8 @@ def load():
     L.ea_batch_bench_result_riding.argtypes = [vp, dp, dp, dp, i64p]
     L.ea_batch_bench_kernel.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp]
     L.ea_batch_bench_fold.argtypes = [vp, C.c_int, C.c_int, dp]
+    L.ea_batch_bench_resident_poses.argtypes = [vp, C.c_int, dp]
+    L.ea_bench_graph_floor.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, dp]
     L.ea_batch_row_offsets.argtypes = [vp, i64p]
     L.ea_problem_num_rows.argtypes = [vp, i64p]
     L.ea_eval_rows.argtypes = [vp, dp, dp, C.c_int, C.c_int, vp, vp, C.c_int64, i64p]
@@ -447,6 +462,10 @@ class Problem:
         self._keep.append(term)
         _check(load().ea_problem_add_term(self._h, term.handle))
 
+    def clear_terms(self):
+        _check(load().ea_problem_clear_terms(self._h))
+        self._keep = []
+
     def set_loss(self, kind, a=1.0):
         _check(load().ea_problem_set_loss(self._h, kind, a))
 
@@ -539,6 +558,13 @@ def solve_pyramid(levels, q, t, **opts):
     return q, t, [summary_to_dict(x) for x in s]
 
 
+def graph_floor_ms(device=0, nodes=200, grid=196, block=256):
+    """ms per kernel node of a replayed hipGraph of EMPTY kernels (ea_bench_graph_floor): the launch mechanism's floor"""
+    ms = C.c_double()
+    _check(load().ea_bench_graph_floor(int(device), int(nodes), int(grid), int(block), C.byref(ms)))
+    return ms.value
+
+
 class Batch:
     """Several independent frame pairs evaluated / solved by the same launch sequence."""
 
@@ -571,6 +597,53 @@ class Batch:
         _check(load().ea_batch_eval(self._h, _dp(q), _dp(t), _dp(cost), _dp(JtJ), _dp(Jtr),
                                     bad.ctypes.data_as(C.POINTER(C.c_int64))))
         return dict(cost=cost, JtJ=JtJ, Jtr=Jtr, n_invalid=bad)
+
+    def _pose_outputs(self, K):
+        n = len(self)
+        return (np.zeros((K, n)), np.zeros((K, n, 6, 6)), np.zeros((K, n, 6)), np.zeros((K, n), dtype=np.int64))
+
+    def eval_poses(self, q, t):
+        """K evaluations of every problem at K different poses in one call (ea_batch_eval_poses): q (K, n, 4), t (K, n, 3)
+        -> dict of cost (K, n), JtJ (K, n, 6, 6), Jtr (K, n, 6), n_invalid (K, n)"""
+        n = len(self)
+        q, t = _f64(q).reshape(-1, n, 4), _f64(t).reshape(-1, n, 3)
+        K = q.shape[0]
+        assert t.shape[0] == K
+        cost, JtJ, Jtr, bad = self._pose_outputs(K)
+        _check(load().ea_batch_eval_poses(self._h, K, _dp(q), _dp(t), _dp(cost), _dp(JtJ), _dp(Jtr),
+                                          bad.ctypes.data_as(C.POINTER(C.c_int64))))
+        self._resident_K = K
+        return dict(cost=cost, JtJ=JtJ, Jtr=Jtr, n_invalid=bad)
+
+    def set_poses(self, q, t):
+        """make K poses per problem resident in HBM (ea_batch_set_poses); returns K"""
+        n = len(self)
+        q, t = _f64(q).reshape(-1, n, 4), _f64(t).reshape(-1, n, 3)
+        assert q.shape[0] == t.shape[0]
+        _check(load().ea_batch_set_poses(self._h, q.shape[0], _dp(q), _dp(t)))
+        self._resident_K = q.shape[0]
+        return q.shape[0]
+
+    def eval_resident_poses(self, out=None, fetch=True):
+        """the K evaluations of the resident poses (ea_batch_eval_resident_poses); `out`: arrays of a previous call to fill
+        again (no allocation inside a timed region); fetch=False: run and synchronise, hand nothing back"""
+        if not fetch:
+            _check(load().ea_batch_eval_resident_poses(self._h, None, None, None, None))
+            return None
+        if out is None:
+            cost, JtJ, Jtr, bad = self._pose_outputs(self._resident_K)
+            out = dict(cost=cost, JtJ=JtJ, Jtr=Jtr, n_invalid=bad)
+        ptrs = out.get("_ptrs")
+        if ptrs is None:   # (the ctypes pointer objects of the four arrays, built once: ~2 us each -- as much as two 5e4-point evaluations)
+            ptrs = out["_ptrs"] = (_dp(out["cost"]), _dp(out["JtJ"]), _dp(out["Jtr"]), out["n_invalid"].ctypes.data_as(C.POINTER(C.c_int64)))
+        _check(load().ea_batch_eval_resident_poses(self._h, *ptrs))
+        return out
+
+    def bench_resident_poses(self, reps):
+        """ms per replay of the resident poses' graph (event pair on the batch's stream around `reps` replays)"""
+        ms = C.c_double()
+        _check(load().ea_batch_bench_resident_poses(self._h, int(reps), C.byref(ms)))
+        return ms.value
 
     def solve(self, q, t, **opts):
         q = _f64(q).reshape(-1, 4).copy()

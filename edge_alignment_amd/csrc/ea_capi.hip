@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/ea_hip.h"
+#include "ea_hip_dev.h"
 #include "ea_lm.h"
 #include "ea_spin.h"
 #include "ea_types.h"
@@ -48,6 +49,8 @@ hipError_t launch_lm_step(const GroupDesc *groups, int count, const double *part
                           LMState *states, LMCold *cold, LMTrace *traces, const LMOptions &opt, int *running_flags,
                           LMState *host_states, LMTrace *host_traces, const GroupDesc &first, hipStream_t stream);
 hipError_t launch_pad_image(int dtype, const void *src, int H, int W, void *dst, int pitch, hipStream_t stream);
+hipError_t launch_make_poses(const double *qt, int n, int count, const ProblemDesc *probs, const GroupDesc *groups,
+                             PoseState *out, hipStream_t stream);
 hipError_t launch_grid_to_image(int dtype, const double *grid, int W, int H, void *dst, int pitch, hipStream_t stream);
 hipError_t launch_aos_to_soa(int dtype, const double *src, long long n, int stride, void *x, void *y, void *z, hipStream_t stream);
 hipError_t launch_selftest_reduce(const float *in, float *a, float *b, float *c, float *d, double *o32, double *o64,
@@ -386,6 +389,15 @@ struct ea_batch {
   int bench_ring = 0;
   double *d_bench_rows = nullptr;   // bench_ring x tiles_cap x kAccSlots
   EvalOut *d_bench_out = nullptr;   // bench_ring x count
+  // ea_batch_set_poses / ea_batch_eval_resident_poses: K different poses per problem resident on the device, their K
+  // evaluations + folds as one replayed hipGraph (the fold of evaluation k-1 rides in the launch of evaluation k), the K
+  // results folded straight into pinned host memory
+  int kp_K = 0, kp_cap = 0;                       // poses per problem resident / allocated
+  double *h_kqt = nullptr, *d_kqt = nullptr;      // q, t staging: cap x count x 7 doubles (pinned / device)
+  PoseState *d_kposes = nullptr;                  // cap x count
+  EvalOut *h_kout = nullptr, *dv_kout = nullptr;  // cap x count, pinned + the device's view of it
+  hipGraphExec_t kp_graph = nullptr;
+  int kp_graph_K = 0;
   bool needs_drain = false;     // a solve gave up on its deadline with launches still queued: synchronise before reuse
   const void *x0 = nullptr, *y0 = nullptr, *z0 = nullptr;  // problem 0's point arrays and count, handed to the evaluation
   int n0 = 0;                                              // kernel in its preloaded arguments
@@ -771,7 +783,21 @@ static void bench_ring_free(ea_batch *b) {
   b->d_bench_rows = nullptr; b->d_bench_out = nullptr; b->bench_ring = 0; b->bench_riding_steps = 0;
 }
 
+static void kposes_drop_graph(ea_batch *b) {
+  if (b->kp_graph) { (void)hipGraphExecDestroy(b->kp_graph); b->kp_graph = nullptr; }
+  b->kp_graph_K = 0;
+}
+
+static void kposes_free(ea_batch *b) {
+  kposes_drop_graph(b);
+  cached_free(b->d_kqt); cached_free(b->d_kposes);
+  cached_host_free(b->h_kqt); cached_host_free(b->h_kout);
+  b->d_kqt = nullptr; b->d_kposes = nullptr; b->h_kqt = nullptr; b->h_kout = nullptr; b->dv_kout = nullptr;
+  b->kp_K = b->kp_cap = 0;
+}
+
 static void batch_free_device(ea_batch *b) {
+  kposes_free(b);
   (void)hipFree(b->d_rows_r); (void)hipFree(b->d_rows_J); (void)hipFree(b->d_rows_invalid);
   b->d_rows_r = b->d_rows_J = nullptr; b->d_rows_invalid = nullptr; b->rows_cap = 0;
   if (b->bench_graph) { (void)hipGraphExecDestroy(b->bench_graph); b->bench_graph = nullptr; b->bench_graph_steps = 0; b->bench_riding_steps = 0; }
@@ -917,6 +943,8 @@ static int batch_build(ea_batch *b) {
   b->built = false;  // until the last allocation and upload below has succeeded
   if (b->bench_graph) { (void)hipGraphExecDestroy(b->bench_graph); b->bench_graph = nullptr; b->bench_graph_steps = 0; b->bench_riding_steps = 0; }
   bench_ring_free(b);  // (sized by the row count of the old build)
+  kposes_drop_graph(b);
+  b->kp_K = 0;         // (resident pose states were built for the old descriptors' flavour)
   // terms of a problem follow it; all share its pose
   std::vector<const ea_problem *> terms;
   std::vector<int> term_group;
@@ -1099,9 +1127,9 @@ static int batch_upload_poses(ea_batch *b, const double *q, const double *t) {
 }
 
 // the 32 accumulator slots of every problem (pinned host copy) -> the caller's cost / 6x6 JtJ / Jtr / invalid count
-static void unpack_eval_out(const ea_batch *b, int count, double *cost, double *JtJ, double *Jtr, int64_t *n_invalid) {
+static void unpack_eval_out(const EvalOut *src, int count, double *cost, double *JtJ, double *Jtr, int64_t *n_invalid) {
   for (int i = 0; i < count; ++i) {
-    const double *acc = b->h_out[i].acc;
+    const double *acc = src[i].acc;
     if (cost) cost[i] = acc[kAccCost];
     if (JtJ) {
       int k = 0;
@@ -1115,6 +1143,9 @@ static void unpack_eval_out(const ea_batch *b, int count, double *cost, double *
     if (Jtr) for (int a = 0; a < 6; ++a) Jtr[6 * i + a] = acc[kAccJtr + a];
     if (n_invalid) n_invalid[i] = (int64_t)llround(acc[kAccInvalid]);
   }
+}
+static void unpack_eval_out(const ea_batch *b, int count, double *cost, double *JtJ, double *Jtr, int64_t *n_invalid) {
+  unpack_eval_out(b->h_out, count, cost, JtJ, Jtr, n_invalid);
 }
 
 extern "C" int ea_batch_eval(ea_batch *b, const double *q, const double *t, double *cost, double *JtJ,
@@ -1133,6 +1164,201 @@ extern "C" int ea_batch_eval(ea_batch *b, const double *q, const double *t, doub
   HIPCHK(hipStreamSynchronize(b->stream));
   unpack_eval_out(b, count, cost, JtJ, Jtr, n_invalid);
   return EA_OK;
+}
+
+// ---- K evaluations at K different poses (ea_batch_set_poses / ea_batch_eval_resident_poses / ea_batch_eval_poses) ------
+// What a caller that drives its own optimiser -- or probes a cost surface, or runs a line search -- asks of the evaluator:
+// ceres::Problem::Evaluate once per pose (src/SolveEA.cpp:241 is the reference's one call of it).  One evaluation through
+// ea_batch_eval is a launch pair and a synchronisation (~30 us on a 5e4-point pair, 3 us of which are the kernel); K of
+// them here are K launches + 1 replayed from one hipGraph, the fold of evaluation k-1 riding in the launch of evaluation k
+// (ea_eval_fold_kernel) where the batch allows it, the K results folded straight into pinned host memory, ONE
+// synchronisation.  Every evaluation runs its per-point kernel and its fold in full, at its own pose.
+
+static bool kposes_can_ride(const ea_batch *b) { return !b->any_variant && b->terms_are_groups && b->lds_bytes == 0 && !b->wide; }
+
+static int kposes_reserve(ea_batch *b, int K) {
+  const size_t count = b->probs.size();
+  if (K <= b->kp_cap) return EA_OK;
+  HIPCHK(hipStreamSynchronize(b->stream));  // (launches still reading the old arrays)
+  kposes_free(b);
+  const int cap = std::max(K, 8);
+  const size_t n = (size_t)cap * count;
+  HIPCHK(cached_malloc(reinterpret_cast<void **>(&b->d_kqt), n * 7 * sizeof(double), b->device));
+  HIPCHK(cached_malloc(reinterpret_cast<void **>(&b->d_kposes), n * sizeof(PoseState), b->device));
+  HIPCHK(cached_host_malloc(reinterpret_cast<void **>(&b->h_kqt), n * 7 * sizeof(double), hipHostMallocDefault, b->device));
+  HIPCHK(cached_host_malloc(reinterpret_cast<void **>(&b->h_kout), n * sizeof(EvalOut), hipHostMallocMapped, b->device));
+  HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&b->dv_kout), b->h_kout, 0));
+  b->kp_cap = cap;
+  return EA_OK;
+}
+
+extern "C" int ea_batch_set_poses(ea_batch *b, int K, const double *q, const double *t) {
+  if (!b || !q || !t) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  if (K < 1 || K > (1 << 20)) return fail(EA_ERR_INVALID_ARG, "K out of range");
+  int rc = batch_build(b);
+  if (rc != EA_OK) return rc;
+  b->kp_K = 0;
+  if ((rc = kposes_reserve(b, K)) != EA_OK) return rc;
+  const size_t n = (size_t)K * b->probs.size();
+  // (the previous upload out of the same staging block has been consumed: every call below ends with its pose kernel
+  // enqueued behind the copy, and the evaluations that follow are synchronised before they return)
+  HIPCHK(hipStreamSynchronize(b->stream));
+  for (size_t i = 0; i < n; ++i) {
+    double *d = b->h_kqt + 7 * i;
+    d[0] = q[4 * i]; d[1] = q[4 * i + 1]; d[2] = q[4 * i + 2]; d[3] = q[4 * i + 3];
+    d[4] = t[3 * i]; d[5] = t[3 * i + 1]; d[6] = t[3 * i + 2];
+  }
+  HIPCHK(hipMemcpyAsync(b->d_kqt, b->h_kqt, n * 7 * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(launch_make_poses(b->d_kqt, (int)n, (int)b->probs.size(), b->d_probs, b->d_groups, b->d_kposes, b->stream));
+  b->kp_K = K;
+  return EA_OK;
+}
+
+static int launch_eval_at(ea_batch *b, const PoseState *poses, double *rows) {
+  HIPCHK(launch_eval_fused(b->dtype, b->ppt, b->nt, b->any_variant, b->d_probs, b->nterms, b->chunk, b->max_chunks,
+                           b->xcd_remap, poses, rows, b->lds_bytes, b->wide, b->terms_are_groups, b->buffer_loads,
+                           b->x0, b->y0, b->z0, b->n0, b->stream));
+  return EA_OK;
+}
+
+// the K evaluations of the resident poses on the batch's stream, results into dv_kout[k * count + i]
+static hipError_t enqueue_resident_poses(ea_batch *b, int K) {
+  const size_t count = b->probs.size();
+  if (!kposes_can_ride(b) || K == 1) {
+    // evaluation -> fold, one pair per pose, in the summation order of ea_batch_eval
+    for (int k = 0; k < K; ++k) {
+      if (launch_eval_at(b, b->d_kposes + (size_t)k * count, b->d_partials) != EA_OK) return hipErrorUnknown;
+      const hipError_t e = launch_reduce(b->d_groups, (int)count, b->d_partials, b->dv_kout + (size_t)k * count, b->stream);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }
+  const size_t row_doubles = (size_t)b->tiles_cap * kAccSlots;
+  for (int k = 0; k < K; ++k) {
+    double *rows = b->d_bench_rows + row_doubles * (size_t)(k & 1);
+    const PoseState *poses = b->d_kposes + (size_t)k * count;
+    if (k == 0) {
+      if (launch_eval_at(b, poses, rows) != EA_OK) return hipErrorUnknown;
+    } else {
+      const hipError_t e = launch_eval_fold(b->dtype, b->ppt, b->nt, b->d_probs, b->nterms, b->chunk, b->max_chunks, b->xcd_remap, poses,
+                                            rows, b->buffer_loads, b->x0, b->y0, b->z0, b->n0, b->d_groups,
+                                            b->d_bench_rows + row_doubles * (size_t)((k - 1) & 1),
+                                            b->dv_kout + (size_t)(k - 1) * count, b->stream);
+      if (e != hipSuccess) return e;
+    }
+  }
+  return launch_reduce_nt(b->nt, b->d_groups, (int)count, b->d_bench_rows + row_doubles * (size_t)((K - 1) & 1),
+                          b->dv_kout + (size_t)(K - 1) * count, b->stream);
+}
+
+static int bench_ring_ensure(ea_batch *b);
+
+extern "C" int ea_batch_eval_resident_poses(ea_batch *b, double *cost, double *JtJ, double *Jtr, int64_t *n_invalid) {
+  if (!b) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  int rc = batch_build(b);
+  if (rc != EA_OK) return rc;
+  const int K = b->kp_K;
+  if (K < 1) return fail(EA_ERR_STATE, "no poses resident (ea_batch_set_poses first; a change of the batch's problems drops them)");
+  const int count = (int)b->probs.size();
+  const bool ride = kposes_can_ride(b) && K > 1;
+  if (ride && (rc = bench_ring_ensure(b)) != EA_OK) return rc;
+  // K <= 2: the launches go out as they are; longer sequences are captured once per K and replayed -- a replay costs the
+  // host one call, the launches then execute back to back from the queue (enqueued one by one the host needs ~4 us per
+  // launch, more than a 5e4-point evaluation runs)
+  if (K > 2 && b->kp_graph_K != K) {
+    kposes_drop_graph(b);
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
+    const hipError_t e = enqueue_resident_poses(b, K);
+    hipGraph_t graph = nullptr;
+    const hipError_t ee = hipStreamEndCapture(b->stream, &graph);
+    if (e != hipSuccess || ee != hipSuccess || !graph) {
+      if (graph) (void)hipGraphDestroy(graph);
+      return fail(EA_ERR_HIP, std::string("graph capture (resident poses): ") + hipGetErrorString(e != hipSuccess ? e : ee));
+    }
+    const hipError_t ei = hipGraphInstantiate(&b->kp_graph, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) { b->kp_graph = nullptr; return fail(EA_ERR_HIP, std::string("graph instantiate: ") + hipGetErrorString(ei)); }
+    b->kp_graph_K = K;
+  }
+  if (K > 2) {
+    HIPCHK(hipGraphLaunch(b->kp_graph, b->stream));
+  } else {
+    const hipError_t e = enqueue_resident_poses(b, K);
+    if (e != hipSuccess) return fail(EA_ERR_HIP, std::string("resident poses: ") + hipGetErrorString(e));
+  }
+  HIPCHK(hipStreamSynchronize(b->stream));
+  const size_t n = (size_t)K * (size_t)count;
+  if (cost || JtJ || Jtr || n_invalid) unpack_eval_out(b->h_kout, (int)n, cost, JtJ, Jtr, n_invalid);
+  return EA_OK;
+}
+
+// (ea_hip_dev.h) `reps` replays of the resident poses' graph between one event pair on the batch's stream: milliseconds
+// per replay, the device's own view of the K evaluations (what bench.py divides by K for the kernel's duration)
+extern "C" int ea_batch_bench_resident_poses(ea_batch *b, int reps, double *ms_per_replay) {
+  if (!b || !ms_per_replay || reps < 1) return fail(EA_ERR_INVALID_ARG, "bad argument");
+  int rc = ea_batch_eval_resident_poses(b, nullptr, nullptr, nullptr, nullptr);  // (captures on first use)
+  if (rc != EA_OK) return rc;
+  if (!b->kp_graph) return fail(EA_ERR_STATE, "sequences of fewer than three poses are not replayed from a graph");
+  EventPair evp;
+  HIPCHK(hipEventCreate(&evp.e0));
+  HIPCHK(hipEventCreate(&evp.e1));
+  HIPCHK(hipEventRecord(evp.e0, b->stream));
+  for (int i = 0; i < reps; ++i) HIPCHK(hipGraphLaunch(b->kp_graph, b->stream));
+  HIPCHK(hipEventRecord(evp.e1, b->stream));
+  HIPCHK(hipEventSynchronize(evp.e1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, evp.e0, evp.e1));
+  *ms_per_replay = (double)ms / reps;
+  return EA_OK;
+}
+
+// (ea_hip_dev.h) The floor of the launch mechanism the sequences above run on: a hipGraph of `nodes` kernel nodes, each an
+// EMPTY kernel of grid x block threads, replayed between one event pair -- milliseconds per node.  What a launch of any
+// size costs when it does nothing; a kernel's duration cannot go below it, so (algorithmic bytes / floor) bounds the
+// roofline fraction a small launch can reach.
+namespace ea { hipError_t launch_empty(int grid, int block, hipStream_t stream); }
+extern "C" int ea_bench_graph_floor(int device, int nodes, int grid, int block, double *ms_per_node) {
+  if (!ms_per_node || nodes < 1 || grid < 1 || block < 1 || block > 1024) return fail(EA_ERR_INVALID_ARG, "bad argument");
+  int rc = check_device(device);
+  if (rc != EA_OK) return rc;
+  HIPCHK(hipSetDevice(device));
+  hipStream_t st = nullptr;
+  HIPCHK(cached_stream_create(&st, device));
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  EventPair evp;
+  hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+  for (int i = 0; i < nodes && e == hipSuccess; ++i) e = launch_empty(grid, block, st);
+  const hipError_t ee = hipStreamEndCapture(st, &graph);
+  if (e == hipSuccess) e = ee;
+  if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  if (graph) (void)hipGraphDestroy(graph);
+  double best = 1e30;
+  if (e == hipSuccess) e = hipEventCreate(&evp.e0);
+  if (e == hipSuccess) e = hipEventCreate(&evp.e1);
+  for (int r = 0; r < 5 && e == hipSuccess; ++r) {  // (first replay uploads the graph; best of the rest)
+    e = hipEventRecord(evp.e0, st);
+    if (e == hipSuccess) e = hipGraphLaunch(exec, st);
+    if (e == hipSuccess) e = hipEventRecord(evp.e1, st);
+    if (e == hipSuccess) e = hipEventSynchronize(evp.e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, evp.e0, evp.e1);
+    if (r > 0 && e == hipSuccess) best = std::min(best, (double)ms / nodes);
+  }
+  if (exec) (void)hipGraphExecDestroy(exec);
+  (void)hipStreamSynchronize(st);
+  cached_stream_destroy(st, device);
+  if (e != hipSuccess) return fail(EA_ERR_HIP, std::string("graph floor: ") + hipGetErrorString(e));
+  *ms_per_node = best;
+  return EA_OK;
+}
+
+extern "C" int ea_batch_eval_poses(ea_batch *b, int K, const double *q, const double *t, double *cost, double *JtJ, double *Jtr,
+                                   int64_t *n_invalid) {
+  int rc = ea_batch_set_poses(b, K, q, t);
+  if (rc != EA_OK) return rc;
+  return ea_batch_eval_resident_poses(b, cost, JtJ, Jtr, n_invalid);
 }
 
 static void fill_summary(const LMState &s, const LMTrace &tr, int64_t npts, double ms, ea_summary *out) {
@@ -1857,6 +2083,7 @@ extern "C" int ea_batch_get_info(const ea_batch *b, const char *key, int64_t *va
   else if (k == "wide_accumulate") *value = b->wide;
   else if (k == "num_points") { int64_t s = 0; for (auto *p : b->probs) s += p->n; *value = s; }
   else if (k == "num_rows") *value = b->total_rows;
+  else if (k == "poses_ride") *value = kposes_can_ride(b) ? 1 : 0;  // ea_batch_eval_poses takes the riding-fold form
   else return fail(EA_ERR_INVALID_ARG, "unknown info key: " + k);
   return EA_OK;
 }

@@ -1610,6 +1610,23 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_step_kernel(
   EA_LM_STAMP(5, ev_);
 }
 
+// q (w, x, y, z) and t of n = K x count poses, 7 doubles each -> the PoseState the evaluation kernels read, built on the
+// device (ea_batch_set_poses: K different poses per problem go up as 56 bytes each instead of a 600-byte PoseState the
+// host would have to compute).  Pose i belongs to problem i % count; its rotation is applied transposed for the ROS
+// flavour (the problem's first term says so).
+__global__ __launch_bounds__(64) void ea_make_poses_kernel(const double *__restrict__ qt, int n, int count,
+                                                           const ProblemDesc *__restrict__ probs,
+                                                           const GroupDesc *__restrict__ groups, PoseState *__restrict__ out) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  double x[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) x[k] = qt[(size_t)i * 7 + k];
+  PoseState *ps = out + i;
+  make_pose_state(x, probs[groups[i % count].term_begin].rot_transposed, 1, ps);
+  ps->pad_[0] = 0; ps->pad_[1] = 0;
+}
+
 // pad + convert a row-major [H][W] device image into the replicated-border layout
 template <typename T>
 __global__ void ea_pad_image_kernel(const T *__restrict__ src, int H, int W, T *__restrict__ dst, int pitch) {
@@ -1856,6 +1873,19 @@ hipError_t set_lm_stamp_buffer(unsigned long long *buf) { return hipMemcpyToSymb
 hipError_t launch_selftest_reduce(const float *in, float *a, float *b, float *c, float *d, double *o32, double *o64,
                                   hipStream_t stream) {
   hipLaunchKernelGGL(ea_selftest_reduce_kernel, dim3(1), dim3(64), 0, stream, in, a, b, c, d, o32, o64);
+  return hipGetLastError();
+}
+
+__global__ void ea_empty_kernel() {}
+hipError_t launch_empty(int grid, int block, hipStream_t stream) {
+  hipLaunchKernelGGL(ea_empty_kernel, dim3(grid), dim3(block), 0, stream);
+  return hipGetLastError();
+}
+
+hipError_t launch_make_poses(const double *qt, int n, int count, const ProblemDesc *probs, const GroupDesc *groups,
+                             PoseState *out, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(ea_make_poses_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, qt, n, count, probs, groups, out);
   return hipGetLastError();
 }
 

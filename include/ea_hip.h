@@ -264,6 +264,25 @@ int ea_batch_eval(ea_batch *b, const double *q, const double *t, double *cost, d
 int ea_batch_solve(ea_batch *b, const ea_options *opt, double *q, double *t,
                    ea_summary *summaries);
 
+/* K evaluations of every problem of the batch at K DIFFERENT poses, one call -- what a caller that runs its own optimiser,
+ * a line search or a cost-surface probe asks of the evaluator: ceres::Problem::Evaluate once per pose (the reference's own
+ * call of it: src/SolveEA.cpp:241).  q: K x count x 4, t: K x count x 3 (pose k of problem i at [k * count + i]); outputs in
+ * the layout of ea_batch_eval with the same leading index: cost K x count, JtJ K x count x 36, Jtr K x count x 6, n_invalid
+ * K x count; any of them may be NULL.  The K evaluations are K launches + 1 replayed from one hipGraph (captured once per K
+ * and batch), the fold of evaluation k-1 riding in the launch of evaluation k, the results folded straight into pinned
+ * host memory, ONE synchronisation: 3-5 us per evaluation of a 5e4-point pair against ~30 us through ea_batch_eval.
+ * Every evaluation runs its per-point kernel and its fold in full.  The folds of 256-thread launches sum in another
+ * order than ea_batch_eval's (equal to rounding); batches with variant functors, shared-pose terms, LDS staging or
+ * "wide_accumulate" take the plain evaluation + fold pair per pose (ea_batch_eval's summation order). */
+int ea_batch_eval_poses(ea_batch *b, int K, const double *q, const double *t, double *cost, double *JtJ, double *Jtr,
+                        int64_t *n_invalid);
+/* The same in two halves, for a caller that evaluates the same poses again (or wants the upload off its critical path):
+ * ea_batch_set_poses makes K poses per problem resident in HBM (56 bytes per pose go up; the pose-dependent constants
+ * the kernels read are built by a device kernel); ea_batch_eval_resident_poses runs their K evaluations.  A change of
+ * the batch's problems (points, DT image, loss, tuning) drops the resident poses: EA_ERR_STATE until they are set again. */
+int ea_batch_set_poses(ea_batch *b, int K, const double *q, const double *t);
+int ea_batch_eval_resident_poses(ea_batch *b, double *cost, double *JtJ, double *Jtr, int64_t *n_invalid);
+
 /* ---- materialised mode: the "EAResidue batch Evaluate" view -------------------------------------------------------
  * Replaces N calls of ceres::AutoDiffCostFunction<EAResidue,1,4,3>::Evaluate followed by the parameterisation's 4x3
  * plus-Jacobian (standalone/utils.h:48-92, standalone_edge_align.cpp:261-278): residual r and the effective 1x6 row
@@ -290,48 +309,7 @@ int ea_eval_rows(ea_problem *p, const double q[4], const double t[3], int correc
 int ea_eval_rows_device(ea_problem *p, const double q[4], const double t[3], int corrected, int layout, void *r_dev, void *J_dev,
                         int64_t capacity_rows, int64_t *n_invalid);
 
-/* ---- measurement hooks (used by bench.py; timing is done with HIP events on the stream the
- * kernels are launched on) ------------------------------------------------------------- */
-/* Upload the poses once, run `warmup` untimed then `steps` timed fused evaluations
- * (residual + Jacobian + JtJ/Jtr/cost reduction) back to back with the inputs resident in HBM.
- * ms_total: event time over the timed region; ms_eval_kernel: average duration of the
- * dominant per-point kernel alone (events around each launch in a second pass). */
-int ea_batch_bench_eval(ea_batch *b, const double *q, const double *t, int warmup, int steps,
-                        double *ms_total, double *ms_eval_kernel);
-/* The timed region of bench.py and nothing else: `steps` x (fused evaluation + fold) enqueued on the batch's stream at the
- * poses the last ea_batch_bench_eval / ea_batch_eval uploaded, then a stream synchronisation.  No pose upload, no event
- * creation, no allocation inside: whoever brackets this call with a wall clock times exactly K steps (round 1's bracket
- * contained ~70 us of setup, a third of a 20-step run).  EA_ERR_STATE when no poses have been uploaded yet. */
-int ea_batch_bench_steps(ea_batch *b, int steps, double *host_us /* nullable, 3 doubles: [0] enqueue and [1] wait in
-                         microseconds of host time, [2] milliseconds between a HIP event pair around the region on the stream */);
-/* Untimed set-up for it: capture `steps` x (evaluation + fold) into a hipGraph once; ea_batch_bench_steps with the same
- * `steps` then replays the graph (one host call, the launches execute back to back from the queue) instead of enqueueing
- * 2 x steps launches at ~3 us of host time each.  Dropped when the batch's problems or tuning change. */
-int ea_batch_bench_capture(ea_batch *b, int steps);
-/* The same K steps with the fold of step k-1 riding in the launch of evaluation k (one extra workgroup per problem; the K
- * passes of the timed region are independent evaluations at the resident poses, the fold's result is not an input of the
- * next one): K launches + one closing fold instead of 2 K dependent launches.  Every step still runs its evaluation and
- * its fold in full and the evaluation kernels execute one after the other.  The folds sum in the order of a workgroup of
- * the evaluation's size (for 256-thread launches not the order of ea_batch_eval's 1024-thread fold: equal to rounding).  Plain single-family problems on the L2 path; EA_ERR_STATE otherwise. */
-int ea_batch_bench_capture_pipelined(ea_batch *b, int steps);
-/* The same K launches + 1 enqueued launch by launch (no graph) and synchronised: the first evaluation runs while the host
- * enqueues the others.  host_us as in ea_batch_bench_steps.  Same restrictions as the captured form. */
-int ea_batch_bench_steps_riding(ea_batch *b, int steps, double *host_us /* nullable, 3 doubles */);
-/* cost / JtJ / Jtr / invalid count (layout of ea_batch_eval) that the LAST step of the last ea_batch_bench_steps left in
- * the batch's result array: a check that the timed launches compute what ea_batch_eval computes. */
-int ea_batch_bench_result(ea_batch *b, double *cost, double *JtJ, double *Jtr, int64_t *n_invalid);
-/* the last-but-one step's result of a pipelined sequence (a riding fold; ea_batch_bench_result reads the closing one) */
-int ea_batch_bench_result_riding(ea_batch *b, double *cost, double *JtJ, double *Jtr, int64_t *n_invalid);
-/* `launches` of the per-point kernel queued back to back between ONE event pair: average execution window per
- * launch (dispatch of the next launch overlaps the running one) -- the figure rocprofv3 --kernel-trace reports. */
-int ea_batch_bench_kernel(ea_batch *b, const double *q, const double *t, int warmup, int launches,
-                          double *ms_per_launch);
-/* the same for the materialised-mode kernel; mode bit 0: LDS-staged row-major stores, bit 1: non-temporal stores;
- * r_dev / J_dev NULL: the library's own arrays */
-int ea_batch_bench_rows(ea_batch *b, const double *q, const double *t, int corrected, int layout, int mode, void *r_dev,
-                        void *J_dev, int64_t capacity_rows, int warmup, int launches, double *ms_per_launch);
-/* the same for the fold kernel of ea_batch_eval, over the partial rows the last evaluation left */
-int ea_batch_bench_fold(ea_batch *b, int warmup, int launches, double *ms_per_launch);
+/* ---- tuning ---------------------------------------------------------------------------- */
 /* tuning knobs: key in {"lds_bytes", "points_per_thread", "use_lds", "xcd_remap", "threads", "buffer_loads",
  * "solve_streams", "rows_staged", "rows_nontemporal", "wide_accumulate"};
  * value < 0 restores the default.

@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "ea_hip.h")).read()
+def _declared_symbols(header=os.path.join("include", "ea_hip.h")):
+    text = open(os.path.join(ROOT, header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(ea_[a-z0-9_]+)\s*\(", text)))
 
@@ -29,6 +29,16 @@ def test_header_and_stub_agree():
 
 def test_every_declared_symbol_is_exported(lib):
     for name in _declared_symbols():
+        assert hasattr(lib, name), name
+
+
+def test_measurement_hooks_live_in_their_own_header(lib):
+    """the public header declares no ea_*bench* entry point; the internal one declares exactly the hooks the stub binds"""
+    from edge_alignment_amd import capi
+    assert not [n for n in _declared_symbols() if "bench" in n]
+    dev = _declared_symbols(os.path.join("edge_alignment_amd", "csrc", "ea_hip_dev.h"))
+    assert dev == sorted(capi.EXPORTED_DEV)
+    for name in dev:
         assert hasattr(lib, name), name
 
 

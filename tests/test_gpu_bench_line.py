@@ -40,6 +40,15 @@ def test_driver_command_prints_one_valid_line(hip):
     assert 1e-3 < r["kernel_ms"] < 1e-2 and "ea_eval" in r["kernel"]
     assert r["traffic"] is None or 0.5 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 2.0
     assert r["secondary"]["bound"].startswith("valu")
+    # the ceiling this workload's one launch per step can reach, from the launch mechanism's own floor (an empty kernel
+    # of the same grid in a replayed graph), and the dependent two-launch step beside the headline
+    assert 5e-4 < r["launch_floor_ms"] < r["kernel_ms"]
+    assert abs(r["frac_ceiling_at_floor"] - r["algorithmic_bytes_per_launch"] / (r["launch_floor_ms"] * 1e-3) / 1e9 / r["peak"]) <= 1e-9
+    assert r["frac"] < r["frac_ceiling_at_floor"] < 1.0
+    assert r["step_ms_events_serial_dependent"] > r["step_ms_events"]
+    assert 0 < d["value_serial_dependent_steps"] < d["value"] * 1.05
+    assert "ea_batch_eval_resident_poses" in cfg["timed_region"] and "different poses" in cfg["timed_region"]
+    assert d["single_eval_call_ms"] > d["ms_per_step"] and d["eval_poses_call_ms"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "evals/s" and c["cores"] == 1 and c["value"] > 1e5 and "passes over" in c["sample"]
     m = d["materialised_mode"]
