@@ -314,6 +314,20 @@ def main():
     from edge_alignment_amd import dist as ead
     if capi.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X (gfx950): " + capi.load().ea_last_error().decode())
+    # The collectives of the measured modes are the library's own (include/ea_hip.h ea_comm_*: ncclAllGather /
+    # ncclAllReduce from librccl on the library's stream); torch.distributed carries the rendezvous (the 128-byte id), the
+    # max-over-ranks of the timed region and -- in a gloo rehearsal, where RCCL cannot hold two ranks on one GPU -- the
+    # exchanges themselves.  One rank: a one-rank communicator (created with the extras, not before the headline).
+    comm, comm_error = None, None
+    if multi and args.dist_backend == "nccl":
+        try:
+            comm = capi.Comm.from_process_group(device=local_rank)
+        except Exception as e:   # (the torch.distributed forms of the same exchanges take over; the line says so)
+            comm_error = repr(e)
+        ok = torch.tensor([0 if comm is None else 1], dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and comm is not None:   # every rank or none
+            comm.close(); comm = None
 
     # The barrier of the timed bracket.  Ranks of one node: an epoch barrier through shared memory (a few microseconds;
     # edge_alignment_amd/dist.py NodeBarrier) -- the closing barrier sits INSIDE the timed region, and a collective-based one
@@ -589,7 +603,14 @@ def main():
         # language -- sees; the Python wrapper adds ~8 us per solve of ctypes marshalling, reported beside it
         lm_local = its / (lib_ms * 1e-3)
         # the one collective: all-gather of the solved poses (7 doubles + status per problem)
-        pg1 = ead.PoseGather(1, world, device=coll_dev if multi else "cpu", force_collective=multi)  # tensors allocated once, outside the clock
+        if comm is None and not multi:
+            try:
+                comm = capi.Comm(capi.comm_unique_id(), 1, 0, device=local_rank)   # (N = 1: the same calls on a one-rank communicator)
+            except Exception as e:
+                comm_error = repr(e)
+        if comm_error:
+            extras["comm_error"] = comm_error
+        pg1 = ead.PoseGather(1, world, device=coll_dev if multi else "cpu", force_collective=multi, comm=comm)  # buffers allocated once, outside the clock
         pg1.gather([q], [t], [s["termination"]])
         tg = time.perf_counter()
         qa, ta, st = pg1.gather([q], [t], [s["termination"]])
@@ -627,30 +648,6 @@ def main():
                 P2f.close()
             except Exception as e:
                 extras["lm_fp32_at_1e5_pts"] = {"error": repr(e)}
-        # the other way to use N GPUs on this path: ONE 1e5-point problem sharded by points, an
-        # all-reduce of the 32 accumulator slots per iteration (RCCL when world > 1), the step replicated on every rank
-        leg[0] = "point-sharded LM, all-reduce through the host"
-        try:
-            sl = ead.shard_slice(cfg2["xyz"].shape[0], rank, world)
-            P3 = capi.Problem(*cfg2["K"], dtype=dt2, device=local_rank)
-            P3.set_points(cfg2["xyz"][sl]); P3.set_dt_grid(cfg2["grid"]); P3.set_loss(*loss2)
-            ar = ead.make_allreduce(world, device=coll_dev if multi else "cpu", force_collective=multi)
-            P3.solve_sharded(q0, t0, ar)
-            barrier_sync()
-            ts = time.perf_counter()
-            reps3, its3 = 10, 0
-            for _ in range(reps3):
-                q3, t3, s3 = P3.solve_sharded(q0, t0, ar)
-                its3 += s3["num_iterations"]
-            barrier_sync()
-            el3 = time.perf_counter() - ts
-            extras["lm_point_sharded_1e5_pts"] = {"iters_per_s": its3 / el3, "solve_ms": el3 / reps3 * 1e3,
-                                                  "points_per_gpu": int(sl.stop - sl.start),
-                                                  "pose_err_vs_planted": {"rad": synth.rotation_angle_between(q3, cfg2["q_true"]),
-                                                                          "m": float(np.linalg.norm(t3 - cfg2["t_true"]))}}
-            P3.close()
-        except Exception as e:  # never let the secondary measurement take the headline line down
-            extras["lm_point_sharded_1e5_pts"] = {"error": repr(e)}
         P2.close()
 
     # BASELINE config C4 as a run shape (every rank, collective): 32 frame pairs per GPU built on the device from the
@@ -687,7 +684,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MIN)
             ok = int(tt.item())
         if ok:
-            c4, _ = ead.run_c4(rank, world, build_and_solve, per_gpu=32, device=coll_dev if multi else "cpu", repeats=3, force_collective=multi)
+            c4, _ = ead.run_c4(rank, world, build_and_solve, per_gpu=32, device=coll_dev if multi else "cpu", repeats=3, force_collective=multi, comm=comm)
             if dist is not None:
                 tt = torch.tensor([c4["lm_iters_per_s_per_gpu"], c4["evals_per_s_per_gpu"]], dtype=torch.float64, device=coll_dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.SUM)
@@ -797,9 +794,10 @@ def main():
         others["batch256_c2_fp32_tile16_beyond_infinity_cache"] = measure(batch * 8, capi.EA_F32, 4, (capi.LOSS_CAUCHY, 1.0), tile=16,
                                                                           traffic_key="batch256_c2_fp32_tile16")
 
-    # Last, because it is the one measurement whose collective pattern (RCCL calls enqueued on the library's stream from a
-    # callback, four per round) has only met a one-rank group so far: the point-sharded solve with the exchange kept on
-    # the stream (ea_solve_sharded_device).  On one rank there is nothing to enqueue: the path without the host hop.
+    # Last, because it is the one measurement whose collective pattern (one ncclAllReduce per iteration enqueued on the
+    # solve's stream) has only met a one-rank communicator so far: the point-sharded solve with the exchange issued by the
+    # library (ea_solve_sharded_comm; look-ahead rule of ea_solve_sharded_device).  gloo rehearsal: the same protocol with
+    # the exchange staged through torch.distributed.
     if not args.no_extras and not (world > 1 and args.no_device_allreduce):
         leg[0] = "point-sharded LM, all-reduce enqueued on the stream"
         try:
@@ -808,17 +806,25 @@ def main():
             sl = ead.shard_slice(cfg2["xyz"].shape[0], rank, world)
             P3 = capi.Problem(*cfg2["K"], dtype=dt2, device=local_rank)
             P3.set_points(cfg2["xyz"][sl]); P3.set_dt_grid(cfg2["grid"]); P3.set_loss(*loss2)
-            sums, enqueue = ead.make_device_allreduce(world, torch.device("cuda", local_rank), force_collective=multi)
-            P3.solve_sharded_device(q0, t0, enqueue, sums.data_ptr())
+            if comm is not None:
+                solve4 = lambda: P3.solve_sharded_comm(q0, t0, comm)
+                exchange = "ncclAllReduce of 32 doubles per iteration, enqueued by the library (ea_solve_sharded_comm), %d-rank communicator" % world
+            else:
+                sums, enqueue = ead.make_device_allreduce(world, torch.device("cuda", local_rank), force_collective=multi)
+                solve4 = lambda: P3.solve_sharded_device(q0, t0, enqueue, sums.data_ptr())
+                exchange = "torch.distributed (%s) under the library's stream, through a Python callback" % args.dist_backend
+            solve4()
             barrier_sync()
             ts = time.perf_counter()
-            reps4, its4 = 10, 0
+            reps4, its4, lib4 = 10, 0, 0.0
             for _ in range(reps4):
-                q4, t4, s4 = P3.solve_sharded_device(q0, t0, enqueue, sums.data_ptr())
+                q4, t4, s4 = solve4()
                 its4 += s4["num_iterations"]
+                lib4 += s4["total_time_ms"]
             barrier_sync()
             el4 = time.perf_counter() - ts
-            extras["lm_point_sharded_device_1e5_pts"] = {"iters_per_s": its4 / el4, "solve_ms": el4 / reps4 * 1e3,
+            extras["lm_point_sharded_device_1e5_pts"] = {"iters_per_s": its4 / (lib4 * 1e-3), "iters_per_s_through_ctypes": its4 / el4,
+                                                         "solve_ms": lib4 / reps4, "exchange": exchange,
                                                          "points_per_gpu": int(sl.stop - sl.start),
                                                          "pose_err_vs_planted": {"rad": synth.rotation_angle_between(q4, cfg2["q_true"]),
                                                                                  "m": float(np.linalg.norm(t4 - cfg2["t_true"]))}}
@@ -840,6 +846,8 @@ def main():
     leg[0] = "teardown"
     B.close()
     P.close()
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.barrier()
         if node_barrier is not None:

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # The variant functors' instantiations (ea_kernels_var.hip = the same file under -DEA_TU_VARIANT) lose 4-7 % under that
 # strategy (a wave of occupancy in fp64) and keep the default one.
 SOURCES = [("csrc/ea_kernels.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]), ("csrc/ea_kernels_var.hip", []),
-           ("csrc/ea_preprocess.hip", []), ("csrc/ea_capi.hip", [])]
+           ("csrc/ea_preprocess.hip", []), ("csrc/ea_capi.hip", []), ("csrc/ea_comm.hip", [])]
 HEADERS = ["csrc/ea_types.h", "csrc/ea_lm.h", "csrc/ea_spin.h", "csrc/ea_hip_dev.h", "../include/ea_hip.h"]
 LIB = os.path.join(_HERE, "lib", "libea_hip.so")
 # -amdgpu-kernarg-preload-count: the command processor hands the first 16 dwords of the kernel-argument segment to
@@ -51,7 +51,7 @@ def build_library(force=False, verbose=False, out=None, defines=()):
     for cmd, pr in procs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
-    link = [cc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", lib] + objs
+    link = [cc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", lib] + objs + ["-ldl"]  # (librccl itself is opened lazily: ea_comm.hip)
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link, cwd=_HERE)

@@ -30,7 +30,9 @@ EXPORTED = [
     "ea_eval", "ea_eval_points", "ea_cost", "ea_problem_pixel_cost", "ea_solve",
     "ea_release_cached_memory", "ea_batch_create", "ea_batch_destroy", "ea_batch_count", "ea_batch_eval", "ea_batch_solve",
     "ea_batch_eval_poses", "ea_batch_set_poses", "ea_batch_eval_resident_poses",
-    "ea_solve_pyramid", "ea_solve_sharded", "ea_solve_sharded_device", "ea_tracker_create", "ea_tracker_destroy", "ea_tracker_problem", "ea_tracker_push_frame",
+    "ea_solve_pyramid", "ea_solve_sharded", "ea_solve_sharded_device",
+    "ea_comm_get_unique_id", "ea_comm_create", "ea_comm_create_all", "ea_comm_destroy", "ea_comm_rank", "ea_comm_size",
+    "ea_comm_gather_poses", "ea_solve_sharded_comm", "ea_comm_get_info", "ea_hip_runtime_copies", "ea_tracker_create", "ea_tracker_destroy", "ea_tracker_problem", "ea_tracker_push_frame",
     "ea_batch_row_offsets", "ea_problem_num_rows", "ea_eval_rows", "ea_eval_rows_device", "ea_batch_eval_rows_device", "ea_batch_eval_rows",
     "ea_batch_set_tuning", "ea_batch_get_info", "ea_selftest_wave_reduce",
     "ea_problem_set_ref_frame", "ea_problem_set_ref_frame_masked", "ea_problem_set_now_frame", "ea_problem_debug_now_frame",
@@ -162,6 +164,16 @@ def load():
     L.ea_solve_sharded.argtypes = [vp, C.POINTER(Options), ALLREDUCE_FN, vp, dp, dp, C.POINTER(Summary)]
     L.ea_solve_sharded_device.argtypes = [vp, C.POINTER(Options), DEVICE_ALLREDUCE_FN, vp, vp, dp, dp, C.POINTER(Summary)]
     L.ea_solve_pyramid.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Options), dp, dp, C.POINTER(Summary)]
+    L.ea_comm_get_unique_id.argtypes = [C.c_char_p]
+    L.ea_comm_create.argtypes = [C.POINTER(vp), C.c_char_p, C.c_int, C.c_int, C.c_int]
+    L.ea_comm_create_all.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]
+    L.ea_comm_destroy.argtypes = [vp]
+    L.ea_comm_destroy.restype = None
+    L.ea_comm_rank.argtypes = [vp]
+    L.ea_comm_size.argtypes = [vp]
+    L.ea_comm_gather_poses.argtypes = [vp, vp, dp, dp, C.POINTER(C.c_int), C.c_int, dp, dp, C.POINTER(C.c_int)]
+    L.ea_solve_sharded_comm.argtypes = [vp, C.POINTER(Options), vp, dp, dp, C.POINTER(Summary)]
+    L.ea_comm_get_info.argtypes = [vp, C.c_char_p, i64p]
     L.ea_batch_set_tuning.argtypes = [vp, C.c_char_p, C.c_int]
     L.ea_batch_get_info.argtypes = [vp, C.c_char_p, i64p]
     L.ea_selftest_wave_reduce.argtypes = [C.c_int, C.POINTER(C.c_float), dp, dp, C.POINTER(C.c_float)]
@@ -429,6 +441,15 @@ class Problem:
                                               C.byref(s)))
         return q, t, summary_to_dict(s)
 
+    def solve_sharded_comm(self, q, t, comm, **opts):
+        """ea_solve_sharded_comm: the point-sharded solve with ncclAllReduce enqueued by the library itself (no callback)"""
+        q = _f64(q).reshape(4).copy()
+        t = _f64(t).reshape(3).copy()
+        o = default_options(**opts)
+        s = Summary()
+        _check(load().ea_solve_sharded_comm(self._h, C.byref(o), comm._h, _dp(q), _dp(t), C.byref(s)))
+        return q, t, summary_to_dict(s)
+
     def pixel_cost(self, q, t):
         """the reference's integer-pixel cost report (standalone_edge_align.cpp:2494-2567) at pose (q, t)"""
         q, t = _f64(q).reshape(4), _f64(t).reshape(3)
@@ -556,6 +577,68 @@ def solve_pyramid(levels, q, t, **opts):
     s = (Summary * len(levels))()
     _check(load().ea_solve_pyramid(hs, len(levels), C.byref(o), _dp(q), _dp(t), s))
     return q, t, [summary_to_dict(x) for x in s]
+
+
+def runtime_copies():
+    """number of HIP runtimes mapped in this process (ea_hip_runtime_copies): 1 when torch was imported before this library"""
+    return load().ea_hip_runtime_copies()
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """the 128 bytes rank 0 hands to the other ranks (ncclGetUniqueId)"""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(load().ea_comm_get_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """One RCCL communicator rank (ea_comm): the pose gather of the batch mode and the all-reduce of the point-sharded solve,
+    issued by the library from librccl directly."""
+
+    def __init__(self, unique_id, nranks, rank, device=0):
+        self._h = C.c_void_p()
+        assert len(unique_id) == COMM_ID_BYTES
+        _check(load().ea_comm_create(C.byref(self._h), unique_id, int(nranks), int(rank), int(device)))
+        self.nranks, self.rank = int(nranks), int(rank)
+
+    @classmethod
+    def from_process_group(cls, device=0):
+        """inside an initialised torch.distributed group (any backend): rank 0's id broadcast as an object"""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls(box[0], world, rank, device)
+
+    def close(self):
+        if self._h:
+            load().ea_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def gather_poses(self, q, t, status=None, after=None):
+        """-> (q (nranks * m, 4), t (nranks * m, 3), status (nranks * m,)) in rank order; `after`: the Batch that solved them"""
+        q, t = _f64(q).reshape(-1, 4), _f64(t).reshape(-1, 3)
+        m = q.shape[0]
+        st = np.ascontiguousarray(status if status is not None else np.zeros(m), dtype=np.int32)
+        qa, ta, sa = np.zeros((self.nranks * m, 4)), np.zeros((self.nranks * m, 3)), np.zeros(self.nranks * m, dtype=np.int32)
+        ip = C.POINTER(C.c_int)
+        _check(load().ea_comm_gather_poses(self._h, after._h if after is not None else None, _dp(q), _dp(t), st.ctypes.data_as(ip), m,
+                                           _dp(qa), _dp(ta), sa.ctypes.data_as(ip)))
+        return qa, ta, sa
+
+    def info(self, key):
+        v = C.c_int64()
+        _check(load().ea_comm_get_info(self._h, key.encode(), C.byref(v)))
+        return v.value
 
 
 def graph_floor_ms(device=0, nodes=200, grid=196, block=256):

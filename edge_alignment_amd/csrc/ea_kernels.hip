@@ -1490,7 +1490,8 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_step_kernel(
     LMTrace *__restrict__ traces, LMOptions opt_arg,
     int *__restrict__ progress /* pinned host: [running x n | evals x n] */,
     LMState *__restrict__ host_states, LMTrace *__restrict__ host_traces /* pinned host, nullable: final delivery */,
-    GroupDesc first /* = groups[0], by value: problem 0's row range needs no dependent load */) {
+    GroupDesc first /* = groups[0], by value: problem 0's row range needs no dependent load */,
+    int post_done /* also post "this step is complete" (progress[2 n + p]): the point-sharded solve's look-ahead rule */) {
   __shared__ __align__(16) double s_part[reduce_tiles_lds<kLmThreads>()];
   __shared__ double s_acc[kAccSlots];
   __shared__ LMState s_st;
@@ -1604,6 +1605,9 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_step_kernel(
     __syncthreads();
     if (tid == 0) __hip_atomic_store(progress + p, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  // behind the flag (same lane, release order): a host that has seen "step k complete" sees the flag as step k left it
+  if (post_done && tid == 0)
+    __hip_atomic_store(progress + 2 * gridDim.x + p, evals_before + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 #ifdef EA_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -1854,14 +1858,14 @@ hipError_t launch_reduce(const GroupDesc *groups, int count, const double *parti
 
 hipError_t launch_lm_step(const GroupDesc *groups, int count, const double *partials, PoseState *poses,
                           LMState *states, LMCold *cold, LMTrace *traces, const LMOptions &opt, int *progress,
-                          LMState *host_states, LMTrace *host_traces, const GroupDesc &first, hipStream_t stream) {
+                          LMState *host_states, LMTrace *host_traces, const GroupDesc &first, int post_done, hipStream_t stream) {
   if (count <= 0) return hipSuccess;
   if (opt.strategy == 0)
     hipLaunchKernelGGL(ea_lm_step_kernel<0>, dim3(count), dim3(kLmThreads), 0, stream, groups, partials, poses,
-                       states, cold, traces, opt, progress, host_states, host_traces, first);
+                       states, cold, traces, opt, progress, host_states, host_traces, first, post_done);
   else
     hipLaunchKernelGGL(ea_lm_step_kernel<1>, dim3(count), dim3(kLmThreads), 0, stream, groups, partials, poses,
-                       states, cold, traces, opt, progress, host_states, host_traces, first);
+                       states, cold, traces, opt, progress, host_states, host_traces, first, post_done);
   return hipGetLastError();
 }
 

@@ -1,7 +1,14 @@
-"""Multi-GPU layer: one process per GPU, independent frame-pair problems sharded round-robin,
-ONE collective — an all-gather of the solved poses (RCCL over xGMI when the backend is "nccl").
-A single large problem can instead be sharded by points (`shard_slice`, `make_allreduce`, `Problem.solve_sharded`):
-one all-reduce of 32 doubles per trust-region iteration, the step itself replicated on every rank.
+"""Multi-GPU layer of the Python harness: one process per GPU, independent frame-pair problems sharded in blocks,
+ONE collective — an all-gather of the solved poses (RCCL over xGMI).  A single large problem can instead be sharded by
+points (`shard_slice`): one all-reduce of 32 doubles per trust-region iteration, the step itself replicated on every rank.
+
+The collectives themselves live BELOW Python, in the C-ABI (include/ea_hip.h, ea_comm_*: ncclAllGather / ncclAllReduce
+called from librccl on the library's stream): `capi.Comm.gather_poses` and `Problem.solve_sharded_comm` are what a GPU
+run uses, and what a C++ caller of the library uses without any of this file (examples/node_batch_demo.cpp).  What is
+left here: the sharding arithmetic, the run shape of BASELINE config C4, the shared-memory barrier of bench.py's timed
+bracket, and -- for rehearsals on one GPU or on the CPU, where RCCL cannot hold two ranks -- the torch.distributed forms
+of the same exchanges (`make_allreduce`: host-staged, any backend; `make_device_allreduce`: enqueued on the library's
+stream through torch's ExternalStream).
 
 The reference is single-process and has no communication at all; frame pairs are
 independent units, so no data-path collective exists.  The gather moves 8 doubles per problem
@@ -43,6 +50,13 @@ def make_device_allreduce(world_size, device, force_collective=False):
     gloo rehearsal on one GPU checks)."""
     import torch
     import torch.distributed as dist
+    from . import capi
+    # The library's stream handle is handed to torch below.  That is only meaningful when both sit on ONE HIP runtime:
+    # PyTorch-ROCm ships its own libamdhip64 under the SONAME this library links, so importing torch first gives one copy
+    # (checked here); the other load order maps two, and a stream of one is not an object of the other.
+    if capi.runtime_copies() != 1:
+        raise RuntimeError("%d HIP runtimes are mapped in this process: import torch before edge_alignment_amd.capi loads libea_hip.so "
+                           "(or use Problem.solve_sharded, whose exchange is staged through the host)" % capi.runtime_copies())
     sums = torch.zeros(32, dtype=torch.float64, device=device)
     if world_size == 1 and not force_collective:   # (force_collective: rehearse the RCCL call on a one-rank group)
         return sums, (lambda stream_ptr: None)
@@ -107,9 +121,10 @@ class PoseGather:
     allocated ONCE; gather() is one host-to-device copy of m x 8 doubles, ONE all_gather_into_tensor (RCCL over xGMI
     when the backend is "nccl") and one copy back.  Blocks of `m` problems per rank, global order = rank-major."""
 
-    def __init__(self, m, world_size, device="cpu", force_collective=False):
+    def __init__(self, m, world_size, device="cpu", force_collective=False, comm=None):
         import torch
         self.m, self.world, self.device = int(m), int(world_size), device
+        self.comm = comm   # capi.Comm: the gather is then ea_comm_gather_poses (ncclAllGather issued by the library)
         self.collective = self.world > 1 or force_collective
         self.host = torch.zeros((self.m, 8), dtype=torch.float64)
         if str(device) != "cpu":
@@ -117,8 +132,11 @@ class PoseGather:
         self.send = torch.zeros((self.m, 8), dtype=torch.float64, device=device)
         self.recv = torch.zeros((self.world * self.m, 8), dtype=torch.float64, device=device)
 
-    def gather(self, q_local, t_local, status_local):
-        """-> (q (W m, 4), t (W m, 3), status (W m,)) on every rank"""
+    def gather(self, q_local, t_local, status_local, after=None):
+        """-> (q (W m, 4), t (W m, 3), status (W m,)) on every rank; `after`: the capi.Batch whose solve produced the poses"""
+        if self.comm is not None:
+            qa, ta, sa = self.comm.gather_poses(q_local, t_local, status_local, after=after)
+            return qa, ta, sa.astype(np.float64)
         import torch
         import torch.distributed as dist
         h = self.host.numpy()
@@ -134,11 +152,12 @@ class PoseGather:
         return out[:, 0:4].copy(), out[:, 4:7].copy(), out[:, 7].copy()
 
 
-def run_c4(rank, world_size, build_and_solve, per_gpu=32, device="cpu", total=None, repeats=1, force_collective=False):
+def run_c4(rank, world_size, build_and_solve, per_gpu=32, device="cpu", total=None, repeats=1, force_collective=False, comm=None):
     """BASELINE config C4 as a run shape: every rank takes its block of `per_gpu` frame-pair problems
     (synth.config_c4_specs), solves them with ONE batched solve (`build_and_solve(specs) -> (solve_fn, info)`,
     solve_fn() -> (q, t, summaries) -- ea_batch_solve on the GPU, a CPU stand-in in the gloo test), then ONE
-    all-gather of the per_gpu x 8 doubles.  Returns a dict of timings and the gathered poses (global order)."""
+    all-gather of the per_gpu x 8 doubles (`comm`: through the C-ABI's RCCL communicator; otherwise torch.distributed on
+    `device`).  Returns a dict of timings and the gathered poses (global order)."""
     import time
     from . import synth
     total = total if total is not None else per_gpu * world_size
@@ -146,7 +165,7 @@ def run_c4(rank, world_size, build_and_solve, per_gpu=32, device="cpu", total=No
     mine = shard_block(total, rank, world_size)
     assert len(mine) == per_gpu, "C4 shards evenly: %d problems over %d ranks" % (total, world_size)
     solve_fn, info = build_and_solve([specs_all[i] for i in mine])
-    pg = PoseGather(per_gpu, world_size, device=device, force_collective=force_collective)
+    pg = PoseGather(per_gpu, world_size, device=device, force_collective=force_collective, comm=comm)
     q, t, ss = solve_fn()  # warm-up (descriptor upload, first-touch)
     pg.gather(q, t, [s["termination"] for s in ss])
     t0 = time.perf_counter()
@@ -159,7 +178,8 @@ def run_c4(rank, world_size, build_and_solve, per_gpu=32, device="cpu", total=No
     its = sum(s["num_iterations"] for s in ss)
     evals = sum(s.get("num_point_evals", 0) for s in ss)
     out = dict(info)
-    out.update({"pairs_per_gpu": per_gpu, "pairs_total": total, "solve_ms": solve_s * 1e3,
+    out.update({"pose_gather": "ea_comm_gather_poses (ncclAllGather from librccl)" if comm is not None else "torch.distributed all_gather_into_tensor",
+                "pairs_per_gpu": per_gpu, "pairs_total": total, "solve_ms": solve_s * 1e3,
                 "lm_iters_per_s_per_gpu": its / solve_s, "evals_per_s_per_gpu": evals / solve_s,
                 "iterations_mean": its / per_gpu, "pose_gather_ms": gather_s * 1e3,
                 "converged": int(sum(1 for s in ss if s["termination"] == 0))})

@@ -236,6 +236,40 @@ typedef int (*ea_device_allreduce_fn)(void *device_buf, int count, void *hip_str
 int ea_solve_sharded_device(ea_problem *p, const ea_options *opt, ea_device_allreduce_fn allreduce, void *user,
                             double *device_sums, double q[4], double t[3], ea_summary *summary);
 
+/* ---- several GPUs: one communicator rank per GPU, RCCL over xGMI, called from librccl directly -------------------------
+ * The path shards by INDEPENDENT frame pairs -- the unit is one ceres::Solve per pair (standalone_edge_align.cpp:286,
+ * src/SolveEA.cpp:198): every GPU solves its own ea_batch, no data-path collective -- and the one exchange step is the
+ * all-gather of the solved poses.  librccl is opened on first use (dlopen): callers that stay on one GPU never load it.
+ * One rank per GPU, either as one process per GPU (ea_comm_get_unique_id on rank 0, the 128 bytes handed to the others
+ * by whatever launched them, ea_comm_create on every rank) or as host threads of one process (ea_comm_create_all, one
+ * communicator per device, each used by the thread that drives that device). */
+typedef struct ea_comm ea_comm;
+#define EA_COMM_ID_BYTES 128
+int ea_comm_get_unique_id(unsigned char id[EA_COMM_ID_BYTES]);
+int ea_comm_create(ea_comm **out, const unsigned char id[EA_COMM_ID_BYTES], int nranks, int rank, int device);
+int ea_comm_create_all(ea_comm **out /* ndev entries */, const int *devices /* NULL = 0 .. ndev-1 */, int ndev);
+void ea_comm_destroy(ea_comm *c);
+int ea_comm_rank(const ea_comm *c);
+int ea_comm_size(const ea_comm *c);
+/* THE collective of the batch mode: every rank hands in the `count` poses it solved (q: count x 4, t: count x 3, status:
+ * count ints such as ea_summary.termination, NULL = zeros) and receives all nranks x count of them in rank order (any of
+ * the three outputs may be NULL).  ONE ncclAllGather of count x 8 doubles, enqueued on the stream of `after` -- the batch
+ * whose ea_batch_solve produced the poses; NULL = the communicator's own stream -- one synchronisation.  `count` must be
+ * the same on every rank (BASELINE config C4: 32). */
+int ea_comm_gather_poses(ea_comm *c, ea_batch *after, const double *q, const double *t, const int *status, int count,
+                         double *all_q, double *all_t, int *all_status);
+/* ea_solve_sharded_device with the exchange issued by the library itself: per iteration evaluation -> fold ->
+ * ncclAllReduce(32 doubles, sum) -> step kernel on one stream, no callback, nothing leaves the device.  Every rank calls
+ * it with its shard of the points (and the whole DT image), the same options and the same start pose. */
+int ea_solve_sharded_comm(ea_problem *p, const ea_options *opt, ea_comm *c, double q[4], double t[3], ea_summary *summary);
+/* key in {"allreduces", "allgathers", "device"}: collectives enqueued so far (tests: equal on every rank) */
+int ea_comm_get_info(const ea_comm *c, const char *key, int64_t *value);
+/* number of HIP runtimes (libamdhip64) mapped in this process.  1 is the only healthy answer: PyTorch-ROCm ships its own
+ * copy under the same SONAME, so a process that imports torch FIRST shares one runtime with this library, while loading
+ * this library first maps two -- streams and device pointers of one are then not objects of the other (ea_comm_* and the
+ * on-stream collectives refuse to run). */
+int ea_hip_runtime_copies(void);
+
 /* Coarse-to-fine driver (BASELINE config C3; the reference has no pyramid): levels[0] = finest.
  * Solves levels[nlevels-1] first and carries q, t down level by level; every level is a complete problem with its own
  * points, DT image and (caller-scaled) intrinsics.  summaries: nlevels entries or NULL. */
