@@ -236,7 +236,7 @@ def launch_ranks(n):
     return rc if rc >= 0 else 128 - rc
 
 
-def launcher_selftest(rank, world, args):
+def launcher_selftest(rank, world, args, line_out):
     """tests/test_bench_launcher.py (CPU): what a rank does with the environment launch_ranks() gave it, minus the GPU --
     rendezvous over gloo, one all-reduce, rank 0 prints a line carrying the world size every rank saw."""
     import torch
@@ -250,8 +250,9 @@ def launcher_selftest(rank, world, args):
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"selftest": True, "n_gpus": int(t[1].item()), "rank_sum": t[0].item(), "steps": args.steps,
-                          "master": os.environ.get("MASTER_ADDR") + ":" + os.environ.get("MASTER_PORT")}))
+        line_out.write(json.dumps({"selftest": True, "n_gpus": int(t[1].item()), "rank_sum": t[0].item(), "steps": args.steps,
+                                   "master": os.environ.get("MASTER_ADDR") + ":" + os.environ.get("MASTER_PORT")}) + "\n")
+        line_out.flush()
 
 
 def main():
@@ -283,13 +284,19 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no torch.distributed.run around us: start the N ranks ourselves (nothing below runs in this process)
         sys.exit(launch_ranks(args.gpus))
+    # stdout carries ONE JSON line.  Libraries under this process talk on stdout too (RCCL's version banner at communicator
+    # creation, gloo's peer report): file descriptor 1 points at stderr from here on, the line goes to the saved descriptor.
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
+    line_out = os.fdopen(line_fd, "w")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if os.environ.get("EA_BENCH_LAUNCHER_SELFTEST"):
-        return launcher_selftest(rank, world, args)
+        return launcher_selftest(rank, world, args, line_out)
 
     import torch  # plumbing only: process group (RCCL), barriers, device sync
     dist = None
@@ -561,8 +568,8 @@ def main():
 
     def on_timeout():
         if rank == 0:
-            sys.stdout.write(json.dumps(compose("timed out after %.0f s in: %s" % (args.extras_timeout, leg[0]))) + "\n")
-            sys.stdout.flush()
+            line_out.write(json.dumps(compose("timed out after %.0f s in: %s" % (args.extras_timeout, leg[0]))) + "\n")
+            line_out.flush()
         # a leg that hangs is a finding, not an "ok": the line above keeps the mandatory part of the record, the exit
         # code and stderr say what stalled so that it can be fixed once
         try:
@@ -855,7 +862,8 @@ def main():
         dist.destroy_process_group()
     watchdog.cancel()
     if rank == 0:
-        print(json.dumps(out))
+        line_out.write(json.dumps(out) + "\n")
+        line_out.flush()
 
 
 if __name__ == "__main__":

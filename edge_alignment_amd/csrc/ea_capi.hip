@@ -28,11 +28,11 @@
 namespace ea {
 hipError_t launch_eval_fused(int dtype, int ppt, int nt, int variant, const ProblemDesc *probs, int nterms, int chunk,
                              int max_chunks, int xcd_remap, const PoseState *poses, double *partials,
-                             int lds_bytes, int wide, int terms_are_groups, int buffer_loads, const void *x0, const void *y0,
+                             int lds_bytes, int wide, int terms_are_groups, int buffer_loads, int img32, const void *x0, const void *y0,
                              const void *z0, int n0, hipStream_t stream);
 hipError_t launch_pixel_cost(int dtype, const ProblemDesc *probs, int problem, int n, const PoseState *poses, void *partials,
                              hipStream_t stream);
-hipError_t launch_eval_rows(int dtype, int variant, int buffer_loads, int layout, int staged, const ProblemDesc *probs, int nterms,
+hipError_t launch_eval_rows(int dtype, int variant, int buffer_loads, int img32, int layout, int staged, const ProblemDesc *probs, int nterms,
                             long long max_n, const PoseState *poses, int corrected, int nontemporal, long long total_rows,
                             void *r_out, void *J_out, unsigned int *n_invalid, hipStream_t stream);
 hipError_t launch_eval_points(int dtype, const ProblemDesc *probs, int problem, int n, const PoseState *poses,
@@ -40,7 +40,7 @@ hipError_t launch_eval_points(int dtype, const ProblemDesc *probs, int problem, 
 hipError_t launch_reduce(const GroupDesc *groups, int count, const double *partials, EvalOut *out,
                          hipStream_t stream);
 hipError_t launch_eval_fold(int dtype, int ppt, int nt, const ProblemDesc *probs, int nterms, int chunk, int max_chunks,
-                            int xcd_remap, const PoseState *poses, double *partials, int buffer_loads, const void *x0,
+                            int xcd_remap, const PoseState *poses, double *partials, int buffer_loads, int img32, const void *x0,
                             const void *y0, const void *z0, int n0, const GroupDesc *groups, const double *prev_rows,
                             EvalOut *prev_out, hipStream_t stream);
 hipError_t launch_reduce_nt(int nt, const GroupDesc *groups, int count, const double *partials, EvalOut *out,
@@ -48,10 +48,12 @@ hipError_t launch_reduce_nt(int nt, const GroupDesc *groups, int count, const do
 hipError_t launch_lm_step(const GroupDesc *groups, int count, const double *partials, PoseState *poses,
                           LMState *states, LMCold *cold, LMTrace *traces, const LMOptions &opt, int *running_flags,
                           LMState *host_states, LMTrace *host_traces, const GroupDesc &first, int post_done, hipStream_t stream);
-hipError_t launch_pad_image(int dtype, const void *src, int H, int W, void *dst, int pitch, hipStream_t stream);
+hipError_t launch_pad_image(int dtype, const void *src, int H, int W, void *dst, int pitch, float *dst32, int *inexact,
+                            hipStream_t stream);
 hipError_t launch_make_poses(const double *qt, int n, int count, const ProblemDesc *probs, const GroupDesc *groups,
                              PoseState *out, hipStream_t stream);
-hipError_t launch_grid_to_image(int dtype, const double *grid, int W, int H, void *dst, int pitch, hipStream_t stream);
+hipError_t launch_grid_to_image(int dtype, const double *grid, int W, int H, void *dst, int pitch, float *dst32, int *inexact,
+                                hipStream_t stream);
 hipError_t launch_aos_to_soa(int dtype, const double *src, long long n, int stride, void *x, void *y, void *z, hipStream_t stream);
 hipError_t launch_selftest_reduce(const float *in, float *a, float *b, float *c, float *d, double *o32, double *o64,
                                   hipStream_t stream);
@@ -70,7 +72,7 @@ hipError_t launch_edge_scatter_ros(int dtype, const uint8_t *edges, const float 
                                    double fx, double fy, double cx, double cy, void *X, void *Y, void *Z, int capacity,
                                    hipStream_t s);
 hipError_t launch_dt_store(int dtype, const int *dist_fix, const float *dist_f32, int H, int W, const unsigned int *minmax,
-                           int normalize, double lo, double hi, void *dst, int pitch, float *plain, hipStream_t s);
+                           int normalize, double lo, double hi, void *dst, int pitch, float *plain, float *dst32, hipStream_t s);
 hipError_t launch_gate_by_mask(uint8_t *grad, const uint8_t *mask, int H, int W, hipStream_t s);
 hipError_t launch_edge_count_scan(const uint8_t *lap, const uint16_t *depth, int H, int W, int thr, int *block_counts,
                                   int *total, hipStream_t s);
@@ -316,6 +318,11 @@ struct ea_problem {
   std::vector<int32_t> order;
   void *d_dt = nullptr;
   size_t dt_cap = 0;   // bytes allocated behind d_dt: a frame of the same size reuses the allocation
+  // fp64 problems: the float32 mirror of the image (same padded layout and pitch in texels) and whether it holds every
+  // value exactly -- then the plain fp64 kernels read it instead (ProblemDesc::dt32): one 16-byte load per stencil row
+  float *d_dt32 = nullptr;
+  size_t dt32_cap = 0;
+  bool dt32_exact = false;
   size_t pts_cap = 0;  // bytes allocated behind each of d_x, d_y, d_z when own_points (hipFree / hipMalloc per frame
                        // cost more than the whole pre-processing of a 640x480 frame)
   int W = 0, H = 0, pitch = 0;
@@ -381,6 +388,8 @@ struct ea_batch {
   int t_test_fail_build = 0;  // test hook: the next descriptor build fails half-way, as a failed allocation would
   int t_test_stall_ms = 0;  // test hook: hold the stream on a host function for this long at the start of a solve
   int t_buf = -1, buffer_loads = 0;  // raw-buffer addressing of the DT image and the points (needs a < 2 GiB image)
+  int t_img32 = -1, img32 = 0;       // fp64 batch whose kernels read the float32 mirror of the DT images ("dt_f32": -1 = when every
+                                     // term has an exact mirror, 0 = never)
   std::vector<ea_batch *> parts;  // sub-batches of the concurrent solve (ea_batch_solve)
   bool built = false;
   hipEvent_t bench_e0 = nullptr, bench_e1 = nullptr;
@@ -576,6 +585,7 @@ extern "C" void ea_problem_destroy(ea_problem *p) {
   if (p->self) ea_batch_destroy(p->self);
   free_points(p);
   if (p->d_dt) cached_free(p->d_dt);
+  if (p->d_dt32) cached_free(p->d_dt32);
   if (p->ws) cached_free(p->ws);
   if (p->stage) cached_free(p->stage);
   delete p;
@@ -716,10 +726,28 @@ static int alloc_dt(ea_problem *p, int W, int H) {
   p->pitch = (W + 2 * kImagePad + 3) & ~3;
   const size_t esz = p->dtype == EA_F32 ? 4 : 8;
   const size_t need = (size_t)p->pitch * (size_t)(H + 2 * kImagePad) * esz;
+  p->dt32_exact = false;  // (until the call that fills the image says otherwise)
+  if (p->dtype == EA_F64) {
+    const size_t need32 = need / 2;
+    if (!(p->d_dt32 && p->dt32_cap >= need32 && p->dt32_cap <= 4 * need32)) {
+      if (p->d_dt32) { cached_free(p->d_dt32); p->d_dt32 = nullptr; p->dt32_cap = 0; }
+      HIPCHK(cached_malloc(reinterpret_cast<void **>(&p->d_dt32), need32, p->device));
+      p->dt32_cap = need32;
+    }
+  }
   if (p->d_dt && p->dt_cap >= need && p->dt_cap <= 4 * need) return EA_OK;  // same-size frame: keep the allocation
   if (p->d_dt) { cached_free(p->d_dt); p->d_dt = nullptr; p->dt_cap = 0; }
   HIPCHK(cached_malloc(&p->d_dt, need, p->device));
   p->dt_cap = need;
+  return EA_OK;
+}
+
+// a device word for the "mirror is not exact" flag of the two upload paths, zeroed; freed by the caller
+static int inexact_flag(ea_problem *p, int **flag) {
+  *flag = nullptr;
+  if (p->dtype != EA_F64) return EA_OK;
+  HIPCHK(cached_malloc(reinterpret_cast<void **>(flag), sizeof(int), p->device));
+  HIPCHK(hipMemsetAsync(*flag, 0, sizeof(int), nullptr));
   return EA_OK;
 }
 
@@ -736,12 +764,20 @@ extern "C" int ea_problem_set_dt(ea_problem *p, const double *data, int grid_row
   // this replaces read the caller's array with a stride of one grid row per element (0.28 -> 0.1x ms per 640 x 480 frame).
   const size_t raw = (size_t)W * (size_t)H * sizeof(double);
   void *d_raw = nullptr;
-  HIPCHK(cached_malloc(&d_raw, raw, p->device));
-  hipError_t e = hipMemcpy(d_raw, data, raw, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = launch_grid_to_image(p->dtype, static_cast<const double *>(d_raw), W, H, p->d_dt, p->pitch, nullptr);
+  int *d_inexact = nullptr;
+  if ((rc = inexact_flag(p, &d_inexact)) != EA_OK) return rc;
+  hipError_t e = cached_malloc(&d_raw, raw, p->device);
+  if (e == hipSuccess) e = hipMemcpy(d_raw, data, raw, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = launch_grid_to_image(p->dtype, static_cast<const double *>(d_raw), W, H, p->d_dt, p->pitch, p->d_dt32, d_inexact, nullptr);
+  int inexact = 1;
+  if (e == hipSuccess && d_inexact) e = hipMemcpy(&inexact, d_inexact, sizeof(int), hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipDeviceSynchronize();
   cached_free(d_raw);
+  cached_free(d_inexact);
   if (e != hipSuccess) return fail(EA_ERR_HIP, std::string("ea_problem_set_dt: ") + hipGetErrorString(e));
+  // every grid the reference builds comes out of a CV_32F distance transform (utils.cpp:79-82, cv2eigen at
+  // standalone_edge_align.cpp:205-206): its doubles are floats, and the fp64 kernels may read the float mirror
+  p->dt32_exact = d_inexact != nullptr && inexact == 0;
   p->version++;
   return EA_OK;
 }
@@ -753,8 +789,15 @@ extern "C" int ea_problem_set_dt_image_device(ea_problem *p, const void *image, 
   HIPCHK(hipSetDevice(p->device));
   int rc = alloc_dt(p, width, height);
   if (rc != EA_OK) return rc;
-  HIPCHK(launch_pad_image(p->dtype, image, height, width, p->d_dt, p->pitch, nullptr));
-  HIPCHK(hipDeviceSynchronize());
+  int *d_inexact = nullptr;
+  if ((rc = inexact_flag(p, &d_inexact)) != EA_OK) return rc;
+  hipError_t e = launch_pad_image(p->dtype, image, height, width, p->d_dt, p->pitch, p->d_dt32, d_inexact, nullptr);
+  int inexact = 1;
+  if (e == hipSuccess && d_inexact) e = hipMemcpy(&inexact, d_inexact, sizeof(int), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  cached_free(d_inexact);
+  if (e != hipSuccess) return fail(EA_ERR_HIP, std::string("ea_problem_set_dt_image_device: ") + hipGetErrorString(e));
+  p->dt32_exact = d_inexact != nullptr && inexact == 0;
   p->version++;
   return EA_OK;
 }
@@ -907,6 +950,7 @@ extern "C" void *ea_internal_batch_stream(ea_batch *b, int *device) {
 static void fill_desc(const ea_problem *p, ProblemDesc &d) {
   std::memset(&d, 0, sizeof(d));
   d.x = p->d_x; d.y = p->d_y; d.z = p->d_z; d.dt = p->d_dt;
+  d.dt32 = (p->dtype == EA_F64 && p->dt32_exact) ? p->d_dt32 : nullptr;
   d.n = (int32_t)p->n; d.W = p->W; d.H = p->H; d.pitch = p->pitch;
   d.fx = p->cam.fx; d.fy = p->cam.fy; d.cx = p->cam.cx; d.cy = p->cam.cy;
   d.loss_a = p->loss_a; d.z_guard = p->z_guard; d.z_eps = p->z_eps;
@@ -1099,6 +1143,11 @@ static int batch_build(ea_batch *b) {
   if (lds > 61440) lds = 61440;
   b->lds_bytes = (use_lds && !any_variant) ? lds : 0;
   b->wide = (b->t_wide > 0 && b->dtype == EA_F32 && !any_variant && b->lds_bytes == 0) ? 1 : 0;
+  {
+    bool all32 = b->dtype == EA_F64 && !any_variant && b->lds_bytes == 0 && b->t_img32 != 0 && !terms.empty();
+    for (const ea_problem *p : terms) all32 = all32 && p->dt32_exact && p->d_dt32;
+    b->img32 = all32 ? 1 : 0;
+  }
   b->xcd_remap = b->t_xcd < 0 ? 1 : (b->t_xcd ? 1 : 0);
   // only now is the batch consistent with its problems: a failure above leaves it dirty, so the next call rebuilds
   // instead of launching on freed or missing buffers
@@ -1118,7 +1167,7 @@ static void host_pose_state(const ea_problem *p, const double *q, const double *
 
 static int batch_launch_eval(ea_batch *b) {
   HIPCHK(launch_eval_fused(b->dtype, b->ppt, b->nt, b->any_variant, b->d_probs, b->nterms, b->chunk, b->max_chunks,
-                           b->xcd_remap, b->d_poses, b->d_partials, b->lds_bytes, b->wide, b->terms_are_groups, b->buffer_loads,
+                           b->xcd_remap, b->d_poses, b->d_partials, b->lds_bytes, b->wide, b->terms_are_groups, b->buffer_loads, b->img32,
                            b->x0, b->y0, b->z0, b->n0, b->stream));
   return EA_OK;
 }
@@ -1221,7 +1270,7 @@ extern "C" int ea_batch_set_poses(ea_batch *b, int K, const double *q, const dou
 
 static int launch_eval_at(ea_batch *b, const PoseState *poses, double *rows) {
   HIPCHK(launch_eval_fused(b->dtype, b->ppt, b->nt, b->any_variant, b->d_probs, b->nterms, b->chunk, b->max_chunks,
-                           b->xcd_remap, poses, rows, b->lds_bytes, b->wide, b->terms_are_groups, b->buffer_loads,
+                           b->xcd_remap, poses, rows, b->lds_bytes, b->wide, b->terms_are_groups, b->buffer_loads, b->img32,
                            b->x0, b->y0, b->z0, b->n0, b->stream));
   return EA_OK;
 }
@@ -1246,7 +1295,7 @@ static hipError_t enqueue_resident_poses(ea_batch *b, int K) {
       if (launch_eval_at(b, poses, rows) != EA_OK) return hipErrorUnknown;
     } else {
       const hipError_t e = launch_eval_fold(b->dtype, b->ppt, b->nt, b->d_probs, b->nterms, b->chunk, b->max_chunks, b->xcd_remap, poses,
-                                            rows, b->buffer_loads, b->x0, b->y0, b->z0, b->n0, b->d_groups,
+                                            rows, b->buffer_loads, b->img32, b->x0, b->y0, b->z0, b->n0, b->d_groups,
                                             b->d_bench_rows + row_doubles * (size_t)((k - 1) & 1),
                                             b->dv_kout + (size_t)(k - 1) * count, b->stream);
       if (e != hipSuccess) return e;
@@ -1577,9 +1626,10 @@ extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, 
       ea_batch *c = b->parts[(size_t)k];
       const int use_lds = b->lds_bytes > 0 ? 1 : 0;
       if (c->t_lds_bytes != b->t_lds_bytes || c->t_ppt != b->ppt || c->t_use_lds != use_lds || c->t_xcd != b->xcd_remap ||
-          c->t_nt != b->nt || c->t_variant != b->any_variant || c->t_buf != b->buffer_loads || c->t_wide != b->t_wide) {
+          c->t_nt != b->nt || c->t_variant != b->any_variant || c->t_buf != b->buffer_loads || c->t_wide != b->t_wide ||
+          c->t_img32 != (b->img32 ? -1 : 0)) {
         c->t_lds_bytes = b->t_lds_bytes; c->t_ppt = b->ppt; c->t_use_lds = use_lds; c->t_xcd = b->xcd_remap; c->t_nt = b->nt;
-        c->t_variant = b->any_variant; c->t_buf = b->buffer_loads; c->t_wide = b->t_wide;
+        c->t_variant = b->any_variant; c->t_buf = b->buffer_loads; c->t_wide = b->t_wide; c->t_img32 = b->img32 ? -1 : 0;
         c->built = false;
       }
       runs[(size_t)k].b = c;
@@ -1741,7 +1791,7 @@ static hipError_t enqueue_riding_steps(ea_batch *b, int steps) {
     } else {
       const int prev = (i - 1) & 1;
       e = launch_eval_fold(b->dtype, b->ppt, b->nt, b->d_probs, b->nterms, b->chunk, b->max_chunks, b->xcd_remap, b->d_poses,
-                           rows, b->buffer_loads, b->x0, b->y0, b->z0, b->n0, b->d_groups,
+                           rows, b->buffer_loads, b->img32, b->x0, b->y0, b->z0, b->n0, b->d_groups,
                            b->d_bench_rows + row_doubles * (size_t)prev, b->d_bench_out + (size_t)count * (size_t)prev, b->stream);
     }
   }
@@ -1967,7 +2017,7 @@ static int check_device_pointer(const ea_batch *b, const void *ptr, const char *
 }
 
 static int rows_launch(ea_batch *b, int corrected, int layout, int staged, int nontemporal, void *r_dev, void *J_dev) {
-  HIPCHK(launch_eval_rows(b->dtype, b->any_variant, b->buffer_loads, layout, staged, b->d_probs, b->nterms, b->max_n, b->d_poses,
+  HIPCHK(launch_eval_rows(b->dtype, b->any_variant, b->buffer_loads, b->img32, layout, staged, b->d_probs, b->nterms, b->max_n, b->d_poses,
                           corrected ? 1 : 0, nontemporal, b->total_rows, r_dev, J_dev, b->d_rows_invalid, b->stream));
   return EA_OK;
 }
@@ -2066,6 +2116,7 @@ extern "C" int ea_batch_set_tuning(ea_batch *b, const char *key, int value) {
   else if (k == "threads") b->t_nt = value;
   else if (k == "buffer_loads") b->t_buf = value;
   else if (k == "wide_accumulate") b->t_wide = value;
+  else if (k == "dt_f32") b->t_img32 = value;
   else if (k == "test_stall_ms") { b->t_test_stall_ms = value; return EA_OK; }
   else if (k == "test_fail_build") { b->t_test_fail_build = value; return EA_OK; }
   else if (k == "solve_streams") { b->t_streams = value; return EA_OK; }
@@ -2087,6 +2138,7 @@ extern "C" int ea_batch_get_info(const ea_batch *b, const char *key, int64_t *va
   else if (k == "threads") *value = b->nt;
   else if (k == "buffer_loads") *value = b->buffer_loads;
   else if (k == "wide_accumulate") *value = b->wide;
+  else if (k == "dt_f32") *value = b->img32;
   else if (k == "num_points") { int64_t s = 0; for (auto *p : b->probs) s += p->n; *value = s; }
   else if (k == "num_rows") *value = b->total_rows;
   else if (k == "poses_ride") *value = kposes_can_ride(b) ? 1 : 0;  // ea_batch_eval_poses takes the riding-fold form
@@ -2675,8 +2727,9 @@ static int dt_from_mask(ea_problem *p, WsCarver &ws, const uint8_t *d_mask, int 
     if (rc != EA_OK) return rc;
   }
   HIPCHK(launch_dt_store(p->dtype, d_dist, d_dist_f32, height, width, d_minmax, normalize, lo, hi, p->d_dt, p->pitch, d_plain,
-                         nullptr));
+                         p->d_dt32, nullptr));
   HIPCHK(hipDeviceSynchronize());
+  p->dt32_exact = p->d_dt32 != nullptr;  // the producers compute the distance transform in float32, as OpenCV does
   p->version++;
   if (dist_out) *dist_out = d_dist;
   if (plain_out) *plain_out = d_plain;

@@ -17,6 +17,7 @@
 
 #include <dlfcn.h>
 #include <link.h>
+#include <unistd.h>
 
 #include <cstdint>
 #include <cstdio>
@@ -93,6 +94,24 @@ int rccl_ready() {
   return EA_OK;
 }
 
+// RCCL announces itself on STDOUT when a communicator is created ("RCCL version : ..." and four more lines on rank 0).
+// The stdout of a process that uses this library belongs to its caller (bench.py's contract is ONE JSON line there):
+// while a communicator is being created, file descriptor 1 points at stderr.
+struct StdoutToStderr {
+  int saved = -1;
+  StdoutToStderr() {
+    std::fflush(stdout);
+    saved = dup(1);
+    if (saved >= 0 && dup2(2, 1) < 0) { close(saved); saved = -1; }
+  }
+  ~StdoutToStderr() {
+    if (saved < 0) return;
+    std::fflush(stdout);
+    (void)dup2(saved, 1);
+    close(saved);
+  }
+};
+
 #define NCCLCHK(expr)                                                                                         \
   do {                                                                                                        \
     const ncclResult_t r_ = (expr);                                                                           \
@@ -125,7 +144,10 @@ extern "C" int ea_comm_get_unique_id(unsigned char id[EA_COMM_ID_BYTES]) {
   int rc = rccl_ready();
   if (rc != EA_OK) return rc;
   ncclUniqueId u;
-  NCCLCHK(rccl().GetUniqueId(&u));
+  {
+    StdoutToStderr quiet;
+    NCCLCHK(rccl().GetUniqueId(&u));
+  }
   std::memcpy(id, u.internal, EA_COMM_ID_BYTES);
   return EA_OK;
 }
@@ -164,7 +186,11 @@ extern "C" int ea_comm_create(ea_comm **out, const unsigned char id[EA_COMM_ID_B
   if (e != hipSuccess) { delete c; return fail(EA_ERR_HIP, hipGetErrorString(e)); }
   ncclUniqueId u;
   std::memcpy(u.internal, id, EA_COMM_ID_BYTES);
-  const ncclResult_t r = rccl().CommInitRank(&c->comm, nranks, u, rank);
+  ncclResult_t r;
+  {
+    StdoutToStderr quiet;
+    r = rccl().CommInitRank(&c->comm, nranks, u, rank);
+  }
   if (r != ncclSuccess) { c->comm = nullptr; ea_comm_destroy(c); return fail(EA_ERR_HIP, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r)); }
   rc = comm_finish(c);
   if (rc != EA_OK) { ea_comm_destroy(c); return rc; }
@@ -187,7 +213,11 @@ extern "C" int ea_comm_create_all(ea_comm **out, const int *devices, int ndev) {
       if (devs[(size_t)j] == devs[(size_t)i]) return fail(EA_ERR_INVALID_ARG, "a device may appear once");
   }
   std::vector<ncclComm_t> comms((size_t)ndev, nullptr);
-  NCCLCHK(rccl().CommInitAll(comms.data(), ndev, devs.data()));
+  {
+    StdoutToStderr quiet;
+    const ncclResult_t r = rccl().CommInitAll(comms.data(), ndev, devs.data());
+    if (r != ncclSuccess) return fail(EA_ERR_HIP, std::string("ncclCommInitAll: ") + rccl().GetErrorString(r));
+  }
   for (int i = 0; i < ndev; ++i) out[i] = nullptr;
   for (int i = 0; i < ndev; ++i) {
     ea_comm *c = new (std::nothrow) ea_comm;

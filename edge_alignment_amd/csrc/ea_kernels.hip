@@ -734,6 +734,29 @@ template <> __device__ __forceinline__ Row4<double> buf_load_row4<double>(__amdg
   return o;
 }
 
+// A stencil row of a T-typed kernel out of an image stored as IT (IT = T, or float under a double kernel: the fp32-stored
+// distance transform of an fp64 problem -- ONE 16-byte load per row and four exact conversions instead of two loads).
+template <typename T, typename IT> struct RowLoad {
+  static __device__ __forceinline__ Row4<T> buf(__amdgpu_buffer_rsrc_t r, int voff, int soff) { return buf_load_row4<T>(r, voff, soff); }
+  static __device__ __forceinline__ Row4<T> flat(GPtr<IT> p) { return load_row4<T>(p); }
+};
+template <> struct RowLoad<double, float> {
+  static __device__ __forceinline__ Row4<double> buf(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const Row4<float> f = buf_load_row4<float>(r, voff, soff);
+    Row4<double> o;
+    o.p0 = (double)f.p0; o.p1 = (double)f.p1; o.p2 = (double)f.p2; o.p3 = (double)f.p3;
+    return o;
+  }
+  static __device__ __forceinline__ Row4<double> flat(GPtr<float> p) {
+    const Row4<float> f = load_row4<float>(p);
+    Row4<double> o;
+    o.p0 = (double)f.p0; o.p1 = (double)f.p1; o.p2 = (double)f.p2; o.p3 = (double)f.p3;
+    return o;
+  }
+};
+template <typename T, bool IMG32> struct ImgOf { typedef T type; };
+template <> struct ImgOf<double, true> { typedef float type; };
+
 // ------------------------------------------------------------------------------------------------
 // fused evaluation kernel: residual + Jacobian + loss + JtJ/Jtr/cost partials, one row per workgroup
 //
@@ -748,7 +771,7 @@ constexpr int kHdrBytes = kRedBytes + kMaxWaves * 16;  // + bbox words, keeps th
 // One workgroup's share of an evaluation: NT lanes x PPT points -> the workgroup's partial row.
 // X/Y/Z hold the lane's points (lanes past `count` carry a copy of the chunk's last point); the return value is
 // slot `my_slot` of the row (0 when my_slot < 0).  `ps` may live in global memory (scalar loads) or LDS.
-template <typename T, int PPT, int MODE, int NT, bool VAR, bool BUF, typename PS>
+template <typename T, int PPT, int MODE, int NT, bool VAR, bool BUF, bool IMG32, typename PS>
 __device__ __forceinline__ double fused_chunk(const ProblemDesc &pd, const PS &ps, const T (&X)[PPT],
                                               const T (&Y)[PPT], const T (&Z)[PPT], int count, double *s_red,
                                               int *s_box, T *s_tile, int lds_texels, int my_slot) {
@@ -756,13 +779,16 @@ __device__ __forceinline__ double fused_chunk(const ProblemDesc &pd, const PS &p
   // fp64 before the wavefront butterfly ("wide_accumulate": everything above a lane's <= PPT products is fp64).
   constexpr bool USE_LDS = MODE == 1;
   constexpr bool WIDE = MODE == 2 && sizeof(T) == 4;
+  static_assert(!IMG32 || (std::is_same<T, double>::value && MODE == 0 && !VAR), "fp32-stored image: plain fp64 kernels on the L2 path");
+  typedef typename ImgOf<T, IMG32>::type IT;  // element type of the image in HBM
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int pitch = pd.pitch;
-  const GPtr<T> gimg = (GPtr<T>)(static_cast<const T *>(pd.dt) + (size_t)kImagePad * (size_t)pitch + kImagePad);
+  const void *img_base = IMG32 ? pd.dt32 : pd.dt;
+  const GPtr<IT> gimg = (GPtr<IT>)(static_cast<const IT *>(img_base) + (size_t)kImagePad * (size_t)pitch + kImagePad);
   const __amdgpu_buffer_rsrc_t rimg =
-      make_raw_buffer(pd.dt, BUF ? (unsigned)pitch * (unsigned)(pd.H + 2 * kImagePad) * (unsigned)sizeof(T) : 0u);
+      make_raw_buffer(img_base, BUF ? (unsigned)pitch * (unsigned)(pd.H + 2 * kImagePad) * (unsigned)sizeof(IT) : 0u);
   const int loss_kind = pd.loss_kind;
   const T loss_a = Uni<T>::loss_a(pd), loss_inv_b = Uni<T>::loss_inv_b(pd);
 
@@ -823,7 +849,7 @@ __device__ __forceinline__ double fused_chunk(const ProblemDesc &pd, const PS &p
       const long long area = (long long)tw * (long long)th;
       if (area <= (long long)lds_texels) {
         in_lds = true;
-        const GPtr<T> img = gimg + ((ptrdiff_t)v0 * pitch + u0);
+        const GPtr<IT> img = gimg + ((ptrdiff_t)v0 * pitch + u0);
         const float inv_tw = 1.0f / (float)tw;
         for (int idx = tid; idx < (int)area; idx += NT) {
           int row = (int)((float)idx * inv_tw);
@@ -849,13 +875,13 @@ __device__ __forceinline__ double fused_chunk(const ProblemDesc &pd, const PS &p
                  [&](int l) { return *reinterpret_cast<const Row4<T> *>(base + l * stride); }, f, Fu, Fv);
     } else if constexpr (BUF) {
       // byte offset of texel (iv - 1, iu - 1) in the padded image; iv, iu >= -2 keeps it non-negative
-      const int voff = ((pr[k].iv + (kImagePad - 1)) * pitch + (pr[k].iu + (kImagePad - 1))) * (int)sizeof(T);
+      const int voff = ((pr[k].iv + (kImagePad - 1)) * pitch + (pr[k].iu + (kImagePad - 1))) * (int)sizeof(IT);
       bicubic<T>(pr[k].fu, pr[k].fv,
-                 [&](int l) { return buf_load_row4<T>(rimg, voff, l * pitch * (int)sizeof(T)); }, f, Fu, Fv);
+                 [&](int l) { return RowLoad<T, IT>::buf(rimg, voff, l * pitch * (int)sizeof(IT)); }, f, Fu, Fv);
     } else {
-      const GPtr<T> base = gimg + ((ptrdiff_t)(pr[k].iv - 1) * pitch + (pr[k].iu - 1));
+      const GPtr<IT> base = gimg + ((ptrdiff_t)(pr[k].iv - 1) * pitch + (pr[k].iu - 1));
       bicubic<T>(pr[k].fu, pr[k].fv,
-                 [&](int l) { return load_row4<T>(base + (ptrdiff_t)l * pitch); }, f, Fu, Fv);
+                 [&](int l) { return RowLoad<T, IT>::flat(base + (ptrdiff_t)l * pitch); }, f, Fu, Fv);
     }
     T J[6];
     if constexpr (VAR) jacobian_row_var<T>(pd, ps, pr[k], Fu, Fv, J);
@@ -917,7 +943,7 @@ __device__ __forceinline__ double fused_chunk(const ProblemDesc &pd, const PS &p
 
 // NT = workgroup size (256 or 1024).  1024 = one workgroup per CU: four times fewer partial rows
 // to fold afterwards at the same points-per-lane latency.
-template <typename T, int PPT, int MODE, int NT, bool VAR, bool BUF>
+template <typename T, int PPT, int MODE, int NT, bool VAR, bool BUF, bool IMG32>
 __device__ __forceinline__ void eval_fused_body(
     const void *__restrict__ x0, const void *__restrict__ y0, const void *__restrict__ z0, int n0,
     int shape, int chunks_per_xcd,
@@ -977,7 +1003,7 @@ __device__ __forceinline__ void eval_fused_body(
     ps.unit_q = psp->unit_q;
     ps.full = psp;
     active = psp->active;
-    asm volatile("" ::"s"(pd.x), "s"(pd.y), "s"(pd.z), "s"(pd.dt), "s"(pd.n), "s"(pd.W), "s"(pd.H), "s"(pd.pitch),
+    asm volatile("" ::"s"(pd.x), "s"(pd.y), "s"(pd.z), "s"(IMG32 ? pd.dt32 : pd.dt), "s"(pd.n), "s"(pd.W), "s"(pd.H), "s"(pd.pitch),
                  "s"(Uni<T>::fx(pd)), "s"(Uni<T>::fy(pd)), "s"(Uni<T>::cx(pd)), "s"(Uni<T>::cy(pd)),
                  "s"(Uni<T>::loss_a(pd)), "s"(Uni<T>::loss_inv_b(pd)), "s"(Uni<T>::z_guard(pd)), "s"(Uni<T>::z_eps(pd)),
                  "s"(pd.loss_kind), "s"(pd.tile_begin), "s"(pd.variant), "s"(pd.group));
@@ -1027,7 +1053,7 @@ __device__ __forceinline__ void eval_fused_body(
   asm volatile("" ::"v"(X[0]), "v"(Y[0]), "v"(Z[0]));
 #endif
   EA_STAMP(2);  // points arrived
-  const double sum = fused_chunk<T, PPT, MODE, NT, VAR, BUF, PoseLite<T>>(pd, ps, X, Y, Z, count, s_red, s_box, s_tile, lds_texels,
+  const double sum = fused_chunk<T, PPT, MODE, NT, VAR, BUF, IMG32, PoseLite<T>>(pd, ps, X, Y, Z, count, s_red, s_box, s_tile, lds_texels,
                                                            tid < kAccSlots ? tid : -1);
   if (tid < kAccSlots) partials[(size_t)(pd.tile_begin + c) * kAccSlots + tid] = sum;
 #ifdef EA_STAMPS
@@ -1036,7 +1062,7 @@ __device__ __forceinline__ void eval_fused_body(
   EA_STAMP(7);  // row stored
 }
 
-template <typename T, int PPT, int MODE, int NT, bool VAR, bool BUF>
+template <typename T, int PPT, int MODE, int NT, bool VAR, bool BUF, bool IMG32 = false>
 __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
     // the first 16 dwords of the argument segment arrive in SGPRs with the wave (kernarg preload): what problem 0's point
     // loads need sits there, so that they can be issued at once, beside the descriptor fetch instead of behind it
@@ -1046,7 +1072,7 @@ __global__ __launch_bounds__(NT) void ea_eval_fused_kernel(
     int shape, int chunks_per_xcd,
     const ProblemDesc *__restrict__ probs, const PoseState *__restrict__ poses,
     double *__restrict__ partials, int lds_texels) {
-  eval_fused_body<T, PPT, MODE, NT, VAR, BUF>(x0, y0, z0, n0, shape, chunks_per_xcd, probs, poses, partials, lds_texels);
+  eval_fused_body<T, PPT, MODE, NT, VAR, BUF, IMG32>(x0, y0, z0, n0, shape, chunks_per_xcd, probs, poses, partials, lds_texels);
 }
 
 #ifndef EA_TU_VARIANT
@@ -1138,7 +1164,7 @@ template <typename T> using Pair = typename PairOf<T>::type;  // two consecutive
 #ifndef EA_ROWS_WAVES_F64
 #define EA_ROWS_WAVES_F64 4  // (fp64 occupancy target of the rows kernel, wavefronts per SIMD: A/B knob, scripts/ab_rows.sh)
 #endif
-template <typename T, bool VAR, bool BUF, int LAYOUT, bool STAGED>
+template <typename T, bool VAR, bool BUF, int LAYOUT, bool STAGED, bool IMG32 = false>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 ? EA_ROWS_WAVES_F64 : 8, 8)))
 void ea_eval_rows_kernel(
     const ProblemDesc *__restrict__ probs, const PoseState *__restrict__ poses, int chunks_per_xcd, int corrected, int nontemporal,
@@ -1177,15 +1203,18 @@ void ea_eval_rows_kernel(
   const int pitch = pd.pitch;
   T f, Fu, Fv, J[6];
   int state;
+  static_assert(!IMG32 || (std::is_same<T, double>::value && !VAR), "fp32-stored image: plain fp64 kernels");
+  typedef typename ImgOf<T, IMG32>::type IT;
+  const void *img_base = IMG32 ? pd.dt32 : pd.dt;
   auto sample = [&](int iu, int iv, T fu, T fv) {
     if constexpr (BUF) {
-      const __amdgpu_buffer_rsrc_t rimg = make_raw_buffer(pd.dt, (unsigned)pitch * (unsigned)(pd.H + 2 * kImagePad) * (unsigned)sizeof(T));
-      const int voff = ((iv + (kImagePad - 1)) * pitch + (iu + (kImagePad - 1))) * (int)sizeof(T);
-      bicubic<T>(fu, fv, [&](int l) { return buf_load_row4<T>(rimg, voff, l * pitch * (int)sizeof(T)); }, f, Fu, Fv);
+      const __amdgpu_buffer_rsrc_t rimg = make_raw_buffer(img_base, (unsigned)pitch * (unsigned)(pd.H + 2 * kImagePad) * (unsigned)sizeof(IT));
+      const int voff = ((iv + (kImagePad - 1)) * pitch + (iu + (kImagePad - 1))) * (int)sizeof(IT);
+      bicubic<T>(fu, fv, [&](int l) { return RowLoad<T, IT>::buf(rimg, voff, l * pitch * (int)sizeof(IT)); }, f, Fu, Fv);
     } else {
-      const GPtr<T> base = (GPtr<T>)(static_cast<const T *>(pd.dt) + (size_t)kImagePad * (size_t)pitch + kImagePad) +
-                           ((ptrdiff_t)(iv - 1) * pitch + (iu - 1));
-      bicubic<T>(fu, fv, [&](int l) { return load_row4<T>(base + (ptrdiff_t)l * pitch); }, f, Fu, Fv);
+      const GPtr<IT> base = (GPtr<IT>)(static_cast<const IT *>(img_base) + (size_t)kImagePad * (size_t)pitch + kImagePad) +
+                            ((ptrdiff_t)(iv - 1) * pitch + (iu - 1));
+      bicubic<T>(fu, fv, [&](int l) { return RowLoad<T, IT>::flat(base + (ptrdiff_t)l * pitch); }, f, Fu, Fv);
     }
   };
   if constexpr (VAR) {
@@ -1461,7 +1490,7 @@ __global__ __launch_bounds__(kLmThreads) void ea_reduce256_kernel(const GroupDes
 // instead of two dependent ones -- the fold's kernel boundary (1.45 us) and its memory round trip disappear under the
 // evaluation.  The fold workgroup sums in the order reduce_tiles<NT> gives a workgroup of this size.
 // Plain single-family problems, stencil rows from L2 (MODE 0).
-template <typename T, int PPT, int NT, bool BUF>
+template <typename T, int PPT, int NT, bool BUF, bool IMG32 = false>
 __global__ __launch_bounds__(NT) void ea_eval_fold_kernel(
     const void *__restrict__ x0, const void *__restrict__ y0, const void *__restrict__ z0, int n0,
     int shape, int chunks_per_xcd,
@@ -1474,7 +1503,7 @@ __global__ __launch_bounds__(NT) void ea_eval_fold_kernel(
     reduce_tiles<NT, 4>(prev_rows, gd.tile_begin, gd.tile_end, s_part, prev_out[blockIdx.y].acc);
     return;
   }
-  eval_fused_body<T, PPT, 0, NT, false, BUF>(x0, y0, z0, n0, shape, chunks_per_xcd, probs, poses, partials, lds_texels);
+  eval_fused_body<T, PPT, 0, NT, false, BUF, IMG32>(x0, y0, z0, n0, shape, chunks_per_xcd, probs, poses, partials, lds_texels);
 }
 
 // LM step: fold this problem's partial rows, advance the trust-region state machine, publish the
@@ -1632,21 +1661,31 @@ __global__ __launch_bounds__(64) void ea_make_poses_kernel(const double *__restr
 }
 
 // pad + convert a row-major [H][W] device image into the replicated-border layout
+// (dst32, inexact: fp64 problems only, nullable -- the float32 mirror of the image and a flag raised by any value the
+// mirror does not hold exactly; ProblemDesc::dt32)
 template <typename T>
-__global__ void ea_pad_image_kernel(const T *__restrict__ src, int H, int W, T *__restrict__ dst, int pitch) {
+__global__ void ea_pad_image_kernel(const T *__restrict__ src, int H, int W, T *__restrict__ dst, int pitch,
+                                    float *__restrict__ dst32, int *__restrict__ inexact) {
   const int u = blockIdx.x * blockDim.x + threadIdx.x;  // padded coords
   const int v = blockIdx.y;
   if (u >= W + 2 * kImagePad) return;
   const int su = min(max(u - kImagePad, 0), W - 1);
   const int sv = min(max(v - kImagePad, 0), H - 1);
-  dst[(size_t)v * pitch + u] = src[(size_t)sv * W + su];
+  const T val = src[(size_t)sv * W + su];
+  dst[(size_t)v * pitch + u] = val;
+  if (dst32) {
+    const float f = (float)val;
+    dst32[(size_t)v * pitch + u] = f;
+    if (!((T)f == val)) atomicOr(inexact, 1);  // (also NaN)
+  }
 }
 
 // The reference's Grid2D view (rows index u, columns index v: data[u * H + v], doubles; standalone_edge_align.cpp:258) ->
 // the padded image in the problem's dtype: transpose, replicate the border, convert.  A 32 x 32 tile goes through LDS so
 // that both the reads (v contiguous in the source) and the writes (u contiguous in the image) are coalesced.
 template <typename T>
-__global__ __launch_bounds__(256) void ea_grid_to_image_kernel(const double *__restrict__ grid, int W, int H, T *__restrict__ dst, int pitch) {
+__global__ __launch_bounds__(256) void ea_grid_to_image_kernel(const double *__restrict__ grid, int W, int H, T *__restrict__ dst, int pitch,
+                                                               float *__restrict__ dst32, int *__restrict__ inexact) {
   __shared__ double s_tile[32][33];
   const int PW = W + 2 * kImagePad, PH = H + 2 * kImagePad;
   const int u0 = blockIdx.x * 32, v0 = blockIdx.y * 32;   // padded coordinates of the tile
@@ -1662,7 +1701,15 @@ __global__ __launch_bounds__(256) void ea_grid_to_image_kernel(const double *__r
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int v = v0 + ty + 8 * k, u = u0 + tx;
-    if (v < PH && u < PW) dst[(size_t)v * pitch + u] = (T)s_tile[tx][ty + 8 * k];
+    if (v < PH && u < PW) {
+      const double val = s_tile[tx][ty + 8 * k];
+      dst[(size_t)v * pitch + u] = (T)val;
+      if (dst32) {
+        const float f = (float)val;
+        dst32[(size_t)v * pitch + u] = f;
+        if (!((double)f == val)) atomicOr(inexact, 1);  // (also NaN)
+      }
+    }
   }
 }
 
@@ -1722,12 +1769,30 @@ hipError_t launch_eval_fused_var(int dtype, int ppt, const ProblemDesc *probs, i
 
 hipError_t launch_eval_fused(int dtype, int ppt, int nt, int variant, const ProblemDesc *probs, int nterms, int chunk,
                              int max_chunks, int xcd_remap, const PoseState *poses, double *partials,
-                             int lds_bytes, int wide, int terms_are_groups, int buffer_loads, const void *x0, const void *y0,
+                             int lds_bytes, int wide, int terms_are_groups, int buffer_loads, int img32, const void *x0, const void *y0,
                              const void *z0, int n0, hipStream_t stream) {
   if (variant)
     return launch_eval_fused_var(dtype, ppt, probs, nterms, chunk, max_chunks, xcd_remap, poses, partials, terms_are_groups,
                                  buffer_loads, x0, y0, z0, n0, stream);
   EA_LAUNCH_PROLOGUE
+  if (img32) {
+    // fp64 arithmetic over the fp32-stored image (every term has ProblemDesc::dt32): the L2 path only
+    if (dtype != 0 || lds_texels > 0) return hipErrorInvalidValue;
+#define EA_LAUNCH_I(P, N)                                                                                              \
+  do {                                                                                                                 \
+    if (buffer_loads)                                                                                                  \
+      hipLaunchKernelGGL((ea_eval_fused_kernel<double, P, 0, N, false, true, true>), grid, dim3(N), shmem, stream, x0, y0, z0, n0, shape, \
+                         chunks_per_xcd, probs, poses, partials, lds_texels);                                          \
+    else                                                                                                               \
+      hipLaunchKernelGGL((ea_eval_fused_kernel<double, P, 0, N, false, false, true>), grid, dim3(N), shmem, stream, x0, y0, z0, n0, shape, \
+                         chunks_per_xcd, probs, poses, partials, lds_texels);                                          \
+  } while (0)
+    if (nt == 1024) EA_LAUNCH_I(1, 1024);
+    else if (ppt == 1) EA_LAUNCH_I(1, 256);
+    else EA_LAUNCH_I(2, 256);
+#undef EA_LAUNCH_I
+    return hipGetLastError();
+  }
 #define EA_LAUNCH_L(T, P, N)                                                          \
   do {                                                                                \
     if (lds_texels > 0) EA_LAUNCH(T, P, 1, N, false); else EA_LAUNCH(T, P, 0, N, false); \
@@ -1756,12 +1821,29 @@ hipError_t launch_eval_fused(int dtype, int ppt, int nt, int variant, const Prob
 
 // evaluation into `partials` + the fold of `prev_rows` -> `prev_out` in one launch (ea_eval_fold_kernel)
 hipError_t launch_eval_fold(int dtype, int ppt, int nt, const ProblemDesc *probs, int nterms, int chunk, int max_chunks,
-                            int xcd_remap, const PoseState *poses, double *partials, int buffer_loads, const void *x0,
+                            int xcd_remap, const PoseState *poses, double *partials, int buffer_loads, int img32, const void *x0,
                             const void *y0, const void *z0, int n0, const GroupDesc *groups, const double *prev_rows,
                             EvalOut *prev_out, hipStream_t stream) {
   const int lds_bytes = 0, terms_are_groups = 1;
   EA_LAUNCH_PROLOGUE
   const dim3 grid_f(grid.x + 1, grid.y);
+  if (img32) {
+    if (dtype != 0) return hipErrorInvalidValue;
+#define EA_LAUNCH_FI(P, N)                                                                                            \
+  do {                                                                                                                \
+    if (buffer_loads)                                                                                                 \
+      hipLaunchKernelGGL((ea_eval_fold_kernel<double, P, N, true, true>), grid_f, dim3(N), shmem, stream, x0, y0, z0, n0, shape,  \
+                         chunks_per_xcd, probs, poses, partials, lds_texels, groups, prev_rows, prev_out);            \
+    else                                                                                                              \
+      hipLaunchKernelGGL((ea_eval_fold_kernel<double, P, N, false, true>), grid_f, dim3(N), shmem, stream, x0, y0, z0, n0, shape, \
+                         chunks_per_xcd, probs, poses, partials, lds_texels, groups, prev_rows, prev_out);            \
+  } while (0)
+    if (nt == 1024) EA_LAUNCH_FI(1, 1024);
+    else if (ppt == 1) EA_LAUNCH_FI(1, 256);
+    else EA_LAUNCH_FI(2, 256);
+#undef EA_LAUNCH_FI
+    return hipGetLastError();
+  }
 #define EA_LAUNCH_F(T, P, N)                                                                                          \
   do {                                                                                                                \
     if (buffer_loads)                                                                                                 \
@@ -1808,7 +1890,7 @@ hipError_t launch_eval_points(int dtype, const ProblemDesc *probs, int problem, 
 }
 
 // materialised mode: rows of every term of the batch into the caller's device arrays (ea_eval_rows_kernel)
-hipError_t launch_eval_rows(int dtype, int variant, int buffer_loads, int layout, int staged, const ProblemDesc *probs, int nterms,
+hipError_t launch_eval_rows(int dtype, int variant, int buffer_loads, int img32, int layout, int staged, const ProblemDesc *probs, int nterms,
                             long long max_n, const PoseState *poses, int corrected, int nontemporal, long long total_rows,
                             void *r_out, void *J_out, unsigned int *n_invalid, hipStream_t stream) {
   if (nterms <= 0 || max_n <= 0) return hipSuccess;
@@ -1824,7 +1906,23 @@ hipError_t launch_eval_rows(int dtype, int variant, int buffer_loads, int layout
     else if (staged) EA_ROWS(T, V, B, 0, true);                                               \
     else EA_ROWS(T, V, B, 0, false);                                                          \
   } while (0)
-  if (variant) {  // distortion / second-camera terms: flat addressing
+  if (img32) {  // fp64 rows over the fp32-stored image
+    if (dtype != 0 || variant) return hipErrorInvalidValue;
+#define EA_ROWS_I(B)                                                                                                            \
+  do {                                                                                                                          \
+    if (layout == 1)                                                                                                            \
+      hipLaunchKernelGGL((ea_eval_rows_kernel<double, false, B, 1, false, true>), grid, dim3(kBlockThreads), 0, stream, probs, poses, chunks_per_xcd, \
+                         corrected, nontemporal, total_rows, static_cast<double *>(r_out), static_cast<double *>(J_out), n_invalid); \
+    else if (staged)                                                                                                            \
+      hipLaunchKernelGGL((ea_eval_rows_kernel<double, false, B, 0, true, true>), grid, dim3(kBlockThreads), 0, stream, probs, poses, chunks_per_xcd, \
+                         corrected, nontemporal, total_rows, static_cast<double *>(r_out), static_cast<double *>(J_out), n_invalid); \
+    else                                                                                                                        \
+      hipLaunchKernelGGL((ea_eval_rows_kernel<double, false, B, 0, false, true>), grid, dim3(kBlockThreads), 0, stream, probs, poses, chunks_per_xcd, \
+                         corrected, nontemporal, total_rows, static_cast<double *>(r_out), static_cast<double *>(J_out), n_invalid); \
+  } while (0)
+    if (buffer_loads) EA_ROWS_I(true); else EA_ROWS_I(false);
+#undef EA_ROWS_I
+  } else if (variant) {  // distortion / second-camera terms: flat addressing
     if (dtype == 1) EA_ROWS_L(float, true, false); else EA_ROWS_L(double, true, false);
   } else if (buffer_loads) {
     if (dtype == 1) EA_ROWS_L(float, false, true); else EA_ROWS_L(double, false, true);
@@ -1893,12 +1991,13 @@ hipError_t launch_make_poses(const double *qt, int n, int count, const ProblemDe
   return hipGetLastError();
 }
 
-hipError_t launch_pad_image(int dtype, const void *src, int H, int W, void *dst, int pitch, hipStream_t stream) {
+hipError_t launch_pad_image(int dtype, const void *src, int H, int W, void *dst, int pitch, float *dst32, int *inexact,
+                            hipStream_t stream) {
   dim3 block(256), grid((W + 2 * kImagePad + 255) / 256, H + 2 * kImagePad);
   if (dtype == 1)
-    hipLaunchKernelGGL((ea_pad_image_kernel<float>), grid, block, 0, stream, (const float *)src, H, W, (float *)dst, pitch);
+    hipLaunchKernelGGL((ea_pad_image_kernel<float>), grid, block, 0, stream, (const float *)src, H, W, (float *)dst, pitch, nullptr, nullptr);
   else
-    hipLaunchKernelGGL((ea_pad_image_kernel<double>), grid, block, 0, stream, (const double *)src, H, W, (double *)dst, pitch);
+    hipLaunchKernelGGL((ea_pad_image_kernel<double>), grid, block, 0, stream, (const double *)src, H, W, (double *)dst, pitch, dst32, inexact);
   return hipGetLastError();
 }
 
@@ -1910,10 +2009,11 @@ hipError_t launch_aos_to_soa(int dtype, const double *src, long long n, int stri
   return hipGetLastError();
 }
 
-hipError_t launch_grid_to_image(int dtype, const double *grid, int W, int H, void *dst, int pitch, hipStream_t stream) {
+hipError_t launch_grid_to_image(int dtype, const double *grid, int W, int H, void *dst, int pitch, float *dst32, int *inexact,
+                                hipStream_t stream) {
   dim3 block(256), tiles((W + 2 * kImagePad + 31) / 32, (H + 2 * kImagePad + 31) / 32);
-  if (dtype == 1) hipLaunchKernelGGL((ea_grid_to_image_kernel<float>), tiles, block, 0, stream, grid, W, H, (float *)dst, pitch);
-  else hipLaunchKernelGGL((ea_grid_to_image_kernel<double>), tiles, block, 0, stream, grid, W, H, (double *)dst, pitch);
+  if (dtype == 1) hipLaunchKernelGGL((ea_grid_to_image_kernel<float>), tiles, block, 0, stream, grid, W, H, (float *)dst, pitch, nullptr, nullptr);
+  else hipLaunchKernelGGL((ea_grid_to_image_kernel<double>), tiles, block, 0, stream, grid, W, H, (double *)dst, pitch, dst32, inexact);
   return hipGetLastError();
 }
 

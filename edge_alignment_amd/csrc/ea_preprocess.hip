@@ -473,7 +473,8 @@ __global__ void ea_edt_row_kernel(const int *__restrict__ G, const int *__restri
 template <typename T>
 __global__ void ea_dt_store_kernel(const int *__restrict__ dist_fix, const float *__restrict__ dist_f32 /* one of the two */,
                                    int H, int W, const unsigned int *__restrict__ minmax, int normalize, double lo, double hi,
-                                   T *__restrict__ dst, int pitch, float *__restrict__ plain /*nullable HxW*/) {
+                                   T *__restrict__ dst, int pitch, float *__restrict__ plain /*nullable HxW*/,
+                                   float *__restrict__ dst32 /*nullable: the float32 mirror of an fp64 problem's image, same pitch*/) {
   const int pu = blockIdx.x * blockDim.x + threadIdx.x, pv = blockIdx.y;  // padded coordinates
   if (pu >= W + 2 * kImagePad) return;
   const int u = min(max(pu - kImagePad, 0), W - 1), v = min(max(pv - kImagePad, 0), H - 1);
@@ -486,6 +487,7 @@ __global__ void ea_dt_store_kernel(const int *__restrict__ dist_fix, const float
     f = __fadd_rn(__fmul_rn(f, (float)scale), (float)shift);
   }
   dst[(size_t)pv * pitch + pu] = (T)f;
+  if (dst32) dst32[(size_t)pv * pitch + pu] = f;  // (the value IS a float: the mirror is exact by construction)
   if (plain && pu >= kImagePad && pu < W + kImagePad && pv >= kImagePad && pv < H + kImagePad)
     plain[(size_t)(pv - kImagePad) * W + (pu - kImagePad)] = f;
 }
@@ -692,12 +694,12 @@ hipError_t launch_chamfer(const uint8_t *mask, int H, int W, int *G, int *scratc
 }
 
 hipError_t launch_dt_store(int dtype, const int *dist_fix, const float *dist_f32, int H, int W, const unsigned int *minmax,
-                           int normalize, double lo, double hi, void *dst, int pitch, float *plain, hipStream_t s) {
+                           int normalize, double lo, double hi, void *dst, int pitch, float *plain, float *dst32, hipStream_t s) {
   dim3 block(256), grid((W + 2 * kImagePad + 255) / 256, H + 2 * kImagePad);
   if (dtype == 1)
-    hipLaunchKernelGGL((ea_dt_store_kernel<float>), grid, block, 0, s, dist_fix, dist_f32, H, W, minmax, normalize, lo, hi, (float *)dst, pitch, plain);
+    hipLaunchKernelGGL((ea_dt_store_kernel<float>), grid, block, 0, s, dist_fix, dist_f32, H, W, minmax, normalize, lo, hi, (float *)dst, pitch, plain, nullptr);
   else
-    hipLaunchKernelGGL((ea_dt_store_kernel<double>), grid, block, 0, s, dist_fix, dist_f32, H, W, minmax, normalize, lo, hi, (double *)dst, pitch, plain);
+    hipLaunchKernelGGL((ea_dt_store_kernel<double>), grid, block, 0, s, dist_fix, dist_f32, H, W, minmax, normalize, lo, hi, (double *)dst, pitch, plain, dst32);
   return hipGetLastError();
 }
 

@@ -47,7 +47,11 @@ struct ProblemDesc {
   // residual variants of standalone/utils.h:102-421 (variant != 0 selects the variant kernel)
   int32_t variant;               // bit 0: Brown-Conrady distortion, bit 1: second camera of a rigid rig
   int64_t row_begin;             // this term's first row in the batch's materialised outputs (ea_batch_eval_rows_device)
-  int32_t pad_[2];
+  const void *dt32;              // fp64 problems: the same padded image stored as float32 (same pitch in texels) when every
+                                 // value is exactly float-representable -- true of everything the reference's producers emit
+                                 // (CV_32F, utils.cpp:79-82) -- else NULL.  The plain fp64 kernels then fetch a stencil row
+                                 // with ONE 16-byte load instead of two and widen it: same doubles, same results, half the
+                                 // texture instructions and cache footprint.
   double dist[5];                // k1, k2, p1, p2, k3
   double A[9], d[3];             // second camera: b = A (R a' + t) + d,  [A d] = affine part of T12
   double Ai[9], di[3];           //                a' = Ai a + di,        [Ai di] = affine part of T12^-1
