@@ -134,6 +134,7 @@ struct ea_comm {
   double *d_send = nullptr, *d_recv = nullptr, *h_send = nullptr, *h_recv = nullptr;
   double *d_sums = nullptr;            // the 32 accumulator slots of ea_solve_sharded_comm
   int64_t allreduces = 0, allgathers = 0;
+  bool spoke = false;                  // the first collective has run (some RCCL builds announce themselves there, not at init)
 };
 
 extern "C" int ea_hip_runtime_copies(void) { return count_hip_runtimes(); }
@@ -279,7 +280,13 @@ extern "C" int ea_comm_gather_poses(ea_comm *c, ea_batch *after, const double *q
   }
   const size_t one = (size_t)count * 8;
   HIPCHK(hipMemcpyAsync(c->d_send, c->h_send, one * sizeof(double), hipMemcpyHostToDevice, st));
-  NCCLCHK(rccl().AllGather(c->d_send, c->d_recv, one, ncclDouble, c->comm, st));
+  if (!c->spoke) {
+    StdoutToStderr quiet;
+    c->spoke = true;
+    NCCLCHK(rccl().AllGather(c->d_send, c->d_recv, one, ncclDouble, c->comm, st));
+  } else {
+    NCCLCHK(rccl().AllGather(c->d_send, c->d_recv, one, ncclDouble, c->comm, st));
+  }
   HIPCHK(hipMemcpyAsync(c->h_recv, c->d_recv, one * (size_t)c->nranks * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   c->allgathers += 1;
@@ -301,7 +308,14 @@ extern "C" int ea_solve_sharded_comm(ea_problem *p, const ea_options *opt, ea_co
   HIPCHK(hipSetDevice(c->device));
   auto enqueue = [](void *buf, int count, void *stream, void *user) -> int {
     ea_comm *cc = static_cast<ea_comm *>(user);
-    const ncclResult_t r = rccl().AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, cc->comm, static_cast<hipStream_t>(stream));
+    ncclResult_t r;
+    if (!cc->spoke) {
+      StdoutToStderr quiet;
+      cc->spoke = true;
+      r = rccl().AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, cc->comm, static_cast<hipStream_t>(stream));
+    } else {
+      r = rccl().AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, cc->comm, static_cast<hipStream_t>(stream));
+    }
     if (r != ncclSuccess) {
       ea_internal_fail(EA_ERR_HIP, (std::string("ncclAllReduce: ") + rccl().GetErrorString(r)).c_str());
       return 1;

@@ -112,6 +112,7 @@ def test_cpp_host_threads_solve_per_device_batches_and_gather(hip, bundled_pair,
     m = 4
     out = subprocess.run([os.path.join(ROOT, "examples", "node_batch_demo"), p, str(m), "1"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
+    assert "RCCL version" not in out.stdout, out.stdout[:600]   # the library keeps RCCL's banner off the caller's stdout
     lines = out.stdout.strip().splitlines()
     ndev, pairs, solve_ms, gather_ms, same = lines[0].split()
     assert (int(ndev), int(pairs), int(same)) == (1, m, 1) and float(solve_ms) > 0 and float(gather_ms) > 0
