@@ -132,8 +132,10 @@ struct EventList {
 // pinned host blocks and streams are therefore kept and handed out again: device blocks to any request they fit without
 // wasting more than half, pinned blocks to requests of exactly their size and flags, streams to the next batch of the
 // device.  Bounded (kCacheMaxBytes per kind, kCacheMaxEntries blocks); ea_release_cached_memory() returns everything
-// to the driver.  A block is only put here by code that has drained the stream whose kernels may still WRITE it; kernels
-// of finished solves that are still queued only read (and discard) what the next owner may already be overwriting.
+// to the driver.  hipFree used to synchronise the device implicitly; the cache keeps that guarantee explicitly: a recycled
+// DEVICE block is handed out only after a device-wide drain that happened AFTER it was freed (one hipDeviceSynchronize --
+// microseconds on a device that is idle or only holds the early-exit launches a finished solve left queued -- before the
+// first reuse following any free; `stale`), so no launch enqueued on behalf of the previous owner can still touch it.
 namespace {
 struct CachedBlock { void *p; size_t bytes; int device; unsigned flags; };
 struct ResourceCache {
@@ -142,6 +144,7 @@ struct ResourceCache {
   std::vector<std::pair<int, hipStream_t>> streams;
   std::unordered_map<void *, CachedBlock> live;  // what is handed out (size / device / flags of a pointer)
   size_t dev_bytes = 0, pinned_bytes = 0;
+  std::unordered_map<int, bool> stale;           // device -> a block was freed since the device was last drained
 };
 ResourceCache &cache() { static ResourceCache *c = new ResourceCache; return *c; }  // (never destroyed: frees at exit race the runtime's teardown)
 constexpr size_t kCacheMaxBytes = (size_t)1 << 30;
@@ -165,6 +168,13 @@ hipError_t cached_malloc(void **out, size_t bytes, int device) {
       c.dev_bytes -= blk.bytes;
       c.live[blk.p] = blk;
       *out = blk.p;
+      bool &stale = c.stale[device];
+      if (stale) {
+        // launches queued for the block's previous owner (on any stream) finish before the new owner sees it
+        const hipError_t es = hipDeviceSynchronize();
+        if (es != hipSuccess) return es;
+        stale = false;
+      }
       return hipSuccess;
     }
   }
@@ -196,6 +206,7 @@ void cached_free(void *p) {
       if (c.dev_bytes + blk.bytes <= kCacheMaxBytes && c.dev.size() < kCacheMaxEntries) {
         c.dev.push_back(blk);
         c.dev_bytes += blk.bytes;
+        c.stale[blk.device] = true;
         return;
       }
     }

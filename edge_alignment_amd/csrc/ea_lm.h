@@ -523,6 +523,21 @@ EA_HD inline void lm_prepare_next(LMState *s, LMCold *c, LMTrace *tr, const LMOp
   }
 }
 
+// An evaluation is usable when no functor returned false AND cost, JtJ and Jtr are all finite -- ceres:
+// ResidualBlock::Evaluate's IsArrayValid check fails an evaluation whose residuals or Jacobians hold a NaN / Inf.  A finite
+// cost does not imply a finite system (fp32 products can overflow where the residual itself does not), and a non-finite
+// system would go through the factorisation and publish a NaN candidate pose.  The sum of the magnitudes of the 28 slots
+// is finite exactly when every slot is; four independent chains keep it off the lane's dependency chain.
+EA_HD inline bool lm_eval_usable(const double acc[kAccSlots]) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 28; i += 4) {
+    s0 += fabs(acc[i]); s1 += fabs(acc[i + 1]); s2 += fabs(acc[i + 2]); s3 += fabs(acc[i + 3]);
+  }
+  static_assert(kAccCost == 27 && kAccInvalid == 28, "slots 0..27 = JtJ, Jtr, cost");
+  return !(acc[kAccInvalid] > 0.0) && ((s0 + s1) + (s2 + s3) <= DBL_MAX);
+}
+
 // after the evaluation at the initial pose
 template <int STRAT>
 EA_HD inline void lm_begin(LMState *s, LMCold *c, LMTrace *tr, const LMOptions *o, const double acc[kAccSlots],
@@ -530,9 +545,9 @@ EA_HD inline void lm_begin(LMState *s, LMCold *c, LMTrace *tr, const LMOptions *
   pend->store_system = 0;
   pend->trace_it = -1;
   s->num_evals += 1;
-  // a functor returning false, or a non-finite residual (ceres: ResidualBlock::Evaluate's IsArrayValid check), fails the
-  // evaluation: at the start point the solve ends with FAILURE and the parameters untouched
-  if (EA_UNLIKELY(acc[kAccInvalid] > 0.0 || !(fabs(acc[kAccCost]) <= DBL_MAX))) { lm_finish(s, 2, 6); return; }
+  // a functor returning false, or a non-finite residual / Jacobian (lm_eval_usable), fails the evaluation: at the start
+  // point the solve ends with FAILURE and the parameters untouched
+  if (EA_UNLIKELY(!lm_eval_usable(acc))) { lm_finish(s, 2, 6); return; }
   lm_take_system(s, pend, acc);
   if (o->jacobi_scaling)
     for (int i = 0; i < 6; ++i) s->S[i] = 1.0 / (1.0 + sqrt(acc[kAccJtJ + sym6(i, i)]));
@@ -547,7 +562,7 @@ EA_HD inline void lm_advance(LMState *s, LMCold *c, LMTrace *tr, const LMOptions
   pend->store_system = 0;
   pend->trace_it = -1;
   s->num_evals += 1;
-  const bool eval_ok = !(acc[kAccInvalid] > 0.0) && (fabs(acc[kAccCost]) <= DBL_MAX);  // (non-finite: see lm_begin)
+  const bool eval_ok = lm_eval_usable(acc);  // (false: the step is rejected like one that raised the cost)
   const double cand_cost = eval_ok ? acc[kAccCost] : DBL_MAX;
   double dx[7];
 #pragma unroll

@@ -127,3 +127,26 @@ def test_resource_cache_hands_blocks_to_the_next_problem_without_changing_result
     assert L.ea_release_cached_memory() == 0
     got = run(pr_b, hip.EA_F64)
     assert got[0] == first[("b", hip.EA_F64)][0] and np.array_equal(got[2], first[("b", hip.EA_F64)][2])
+
+
+def test_recycled_blocks_are_drained_before_their_next_owner(hip):
+    """a finished solve leaves (evaluate, step) pairs queued past its end; destroying the problem at once and
+    building the next one on the same recycled device blocks must not let those launches meet the new owner's data.  The
+    cache drains the device once before the first reuse that follows a free.  Two same-sized problems with different data
+    alternate 60 times with six pairs kept queued ahead: every solve lands on the bits of its first run."""
+    prs = [synth.make_problem(120, 160, 6000, 40, seed, 130.0, 130.0, 79.5, 59.5, planted_q=synth.quat_from_axis_angle(ax, 0.012),
+                              planted_t=tt, normalize=True)
+           for seed, ax, tt in ((1, [1, 2, 3], (0.01, -0.005, 0.02)), (2, [3, -1, 2], (-0.01, 0.008, 0.01)))]
+    q0, t0 = np.array([1.0, 0, 0, 0]), np.zeros(3)
+
+    def run(pr):
+        P = hip.Problem(*pr["K"], dtype=hip.EA_F64)
+        P.set_points(pr["xyz"]); P.set_dt_grid(pr["grid"]); P.set_loss(hip.LOSS_CAUCHY, 1.0)
+        q, t, s = P.solve(q0, t0, iterations_per_sync=6)
+        P.close()   # at once: launches queued past the end of the solve are still in the stream
+        return q, t, s["num_iterations"], s["final_cost"]
+
+    first = [run(pr) for pr in prs]
+    for k in range(60):
+        got, want = run(prs[k & 1]), first[k & 1]
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2:] == want[2:], k

@@ -92,6 +92,56 @@ def test_shipped_lm_failure_and_limits(lm_host_shim, oracle):
     assert list(out.x[:]) == [1, 0, 0, 0, 0, 0, 0]
 
 
+def test_a_non_finite_system_fails_the_evaluation(lm_host_shim, oracle):
+    """a finite cost with an Inf / NaN in the JtJ / Jtr slots (fp32 products can overflow where the residual
+    does not) must not reach the factorisation.  Ceres fails such an evaluation (IsArrayValid): FAILURE at the start
+    point with the pose untouched; afterwards a rejected step -- the solve goes on from the last good pose and never
+    publishes a non-finite one."""
+    pr = synth.make_problem(120, 160, 600, 40, 21, 130.0, 130.0, 79.5, 59.5,
+                            planted_q=synth.quat_from_axis_angle([1, 2, 3], np.deg2rad(1.0)), planted_t=(0.01, -0.005, 0.02), normalize=True)
+    P = oracle.OracleProblem(pr["grid"], *pr["K"])
+    X = pr["xyz"].copy()
+
+    def run(poison_eval, slot, value):
+        calls = [0]
+        poses = []
+
+        def cb(pose, acc, _):
+            x = np.array([pose[i] for i in range(7)])
+            poses.append(x)
+            e = P.eval(X, x[:4], x[4:])
+            k = 0
+            for a in range(6):
+                for b in range(a, 6):
+                    acc[k] = e["JtJ"][a, b]; k += 1
+            for a in range(6):
+                acc[21 + a] = e["Jtr"][a]
+            acc[27] = e["cost"]; acc[28] = 0.0
+            for i in range(29, 32):
+                acc[i] = 0.0
+            if calls[0] == poison_eval:
+                acc[slot] = value
+            calls[0] += 1
+        out = ShimOut()
+        o = _opts()
+        q0 = np.array([1.0, 0, 0, 0]); t0 = np.zeros(3)
+        lm_host_shim.ea_lm_host_solve.argtypes = [C.POINTER(LMOptions), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, CB, C.c_void_p, C.POINTER(ShimOut)]
+        assert lm_host_shim.ea_lm_host_solve(C.byref(o), q0.ctypes.data_as(C.POINTER(C.c_double)), t0.ctypes.data_as(C.POINTER(C.c_double)), 0, CB(cb), None, C.byref(out)) == 0
+        return out, poses
+
+    clean, _ = run(-1, 0, 0.0)
+    for slot, value in ((3, np.inf), (24, np.nan), (0, -np.inf), (27, np.nan)):
+        out, poses = run(0, slot, value)                      # at the start point
+        assert out.termination == 2 and oracle.WHY[out.why] == "initial_eval_failed" and out.num_evals == 1, (slot, value)
+        assert list(out.x[:]) == [1, 0, 0, 0, 0, 0, 0]
+        out, poses = run(2, slot, value)                      # at a candidate: a rejected step, then the solve goes on
+        assert out.termination == 0 and out.num_unsuccessful >= 1, (slot, value)
+        assert all(np.all(np.isfinite(x)) for x in poses) and np.all(np.isfinite(out.x[:]))
+        assert out.it_successful[2] == 0
+        assert synth.rotation_angle_between(np.array(out.x[:4]), np.array(clean.x[:4])) < 1e-6
+        assert np.abs(np.array(out.x[4:]) - np.array(clean.x[4:])).max() < 1e-6
+
+
 def test_pose_state_general_derivative_matches_jet(lm_host_shim, oracle):
     # G_j of make_pose_state (used by the kernels for |q| != 1) against Jet autodiff
     rng = np.random.default_rng(5)
