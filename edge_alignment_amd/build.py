@@ -6,7 +6,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (source, extra flags).  ea_kernels.hip -- the plain functor's evaluation kernels, the fold and the LM step -- is scheduled
-# for instruction-level parallelism: same-box A/B (scripts/ab_sched.sh, bit-identical results) C2 2.99 -> 2.91 us, 32 x C2
+# for instruction-level parallelism: same-box A/B (scripts/archive/ab_sched.sh, bit-identical results) C2 2.99 -> 2.91 us, 32 x C2
 # fp64 tile order 25.0 -> 23.9 us, fp32 12.95 -> 12.65 us, C5 fp64 17.9 -> 17.2 us, the 1e5-point fp64 solve 166 -> 160 us.
 # The variant functors' instantiations (ea_kernels_var.hip = the same file under -DEA_TU_VARIANT) lose 4-7 % under that
 # strategy (a wave of occupancy in fp64) and keep the default one.

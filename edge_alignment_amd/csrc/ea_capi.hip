@@ -125,7 +125,7 @@ struct EventList {
 
 
 // ---- resource cache -----------------------------------------------------------------------------------------------
-// A fresh problem's first solve used to cost 6 ms against 0.14 ms for the solve itself (scripts/upload_probe.py): three
+// A fresh problem's first solve used to cost 6 ms against 0.14 ms for the solve itself (scripts/archive/upload_probe.py): three
 // hipMalloc for the points, one for the image, four hipMalloc + four hipHostMalloc + a stream for its batch, and the same
 // number of frees -- each a driver call of 0.1-1 ms, hipFree also a device synchronisation.  That is what the ceres facade
 // pays per ceres::Solve (one ea_problem per ceres::Problem, standalone_edge_align.cpp:256-293).  Freed device blocks,
@@ -561,7 +561,7 @@ static int reserve_points(ea_problem *p, int64_t n) {
 // Storage order for large point sets: tiles of T x T pixels of the reference frame (the identity-pose projection),
 // tiles in raster order, the caller's order inside a tile.  A wavefront's 64 points then sample a compact patch of
 // the DT image instead of a 1-2 row strip across its whole width, and the four stencil-row loads of neighbouring
-// points hit the lines the CU's L1 already holds (C5: 12.7 -> 8.1 us per evaluation, scripts/order_sweep.py).
+// points hit the lines the CU's L1 already holds (C5: 12.7 -> 8.1 us per evaluation, scripts/archive/order_sweep.py).
 // Sums are taken in storage order; per-point outputs and ea_problem_get_points stay in the caller's order.
 constexpr int64_t kAutoOrderPoints = 200000;  // below this a launch is latency-bound and the order does not matter
 
@@ -1618,7 +1618,7 @@ extern "C" int ea_batch_solve(ea_batch *b, const ea_options *opt_in, double *q, 
   // Concurrent halves: a batch of many problems is solved as two sub-batches on two streams, pumped by this one
   // thread.  Inside a batch the evaluation (all CUs busy) and the LM step (one workgroup per problem, pure latency)
   // alternate; with two streams one half's step runs under the other half's evaluation
-  // (32 x C2: 0.38 -> 0.32 ms fp32, 0.57 -> 0.46 ms fp64; scripts/split_batch_probe.py).  Every problem's arithmetic
+  // (32 x C2: 0.38 -> 0.32 ms fp32, 0.57 -> 0.46 ms fp64; scripts/archive/split_batch_probe.py).  Every problem's arithmetic
   // is what it is in the one-stream solve of the same batch (same launch shape, same chunks, same order of summation).
   int parts = b->t_streams > 0 ? b->t_streams : (count >= 16 ? 2 : 1);
   parts = std::max(1, std::min(parts, std::min(count, 8)));

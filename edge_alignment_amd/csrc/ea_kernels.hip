@@ -1162,7 +1162,7 @@ template <> struct PairOf<double> { typedef double type __attribute__((ext_vecto
 template <typename T> using Pair = typename PairOf<T>::type;  // two consecutive elements: one 8- / 16-byte access
 
 #ifndef EA_ROWS_WAVES_F64
-#define EA_ROWS_WAVES_F64 4  // (fp64 occupancy target of the rows kernel, wavefronts per SIMD: A/B knob, scripts/ab_rows.sh)
+#define EA_ROWS_WAVES_F64 4  // (fp64 occupancy target of the rows kernel, wavefronts per SIMD: A/B knob, scripts/archive/ab_rows.sh)
 #endif
 template <typename T, bool VAR, bool BUF, int LAYOUT, bool STAGED, bool IMG32 = false>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 ? EA_ROWS_WAVES_F64 : 8, 8)))

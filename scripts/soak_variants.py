@@ -10,7 +10,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 4321
 rng = np.random.default_rng(seed)
 t_end = time.time() + budget
-n_cases = n_solves = n_fail = n_capped = 0
+n_cases = n_solves = n_fail = n_capped = n_split = 0
 worst = {"f64": 0.0, "f32": 0.0}
 
 
@@ -32,11 +32,11 @@ while time.time() < t_end:
     loss = [(0, 1.0), (1, 1.0), (2, 0.3)][int(rng.integers(3))]
     dtype = capi.EA_F64 if rng.random() < 0.6 else capi.EA_F32
     tag, tol = ("f64", 1e-10) if dtype == capi.EA_F64 else ("f32", 5e-4)
-    if dtype == capi.EA_F32 and dist is not None and max(abs(dist[0]), abs(dist[1]), abs(dist[4])) > 0.5:
-        # a radial polynomial 1 + k1 r^2 + k2 r^4 + k3 r^6 with |k| > 0.5 cancels digits on points at normalised radius 1.5-2.5
-        # (the family's far points): fp32 rows of those points are good to ~2e-3, and so are the sums they dominate
-        # (seed 4321, case 14048: k2 = -0.61, 8.9e-4 on JtJ, every row within 2e-3 of the fp64 oracle's)
-        tol = 2e-3
+    # A radial polynomial 1 + k1 r^2 + k2 r^4 + k3 r^6 with |k| > 0.5 cancels digits on points at normalised radius > 1.5
+    # (the family's far points): fp32 rows of THOSE points are good to ~2e-3 (seed 4321, case 14048: k2 = -0.61).  The
+    # relaxed bar applies to them alone (round 3): such a family is evaluated in two parts -- points inside radius 1.5 at
+    # the ordinary 5e-4, the far points at 2e-3 -- so a regression on the well-conditioned rows stays visible.
+    split_far = dtype == capi.EA_F32 and dist is not None and max(abs(dist[0]), abs(dist[1]), abs(dist[4])) > 0.5
     q = synth.quat_mul(synth.quat_from_axis_angle(rng.normal(size=3), float(rng.uniform(0, 0.01))), Qp)
     if rng.random() < 0.2:
         q = q * float(rng.uniform(0.98, 1.02))
@@ -51,6 +51,47 @@ while time.time() < t_end:
         if second: P.set_second_camera(T12)
         return P
     P1, P2 = gpu(fams[0], K1, False), gpu(fams[1], K2, True)
+
+    def far_mask(X, second):
+        """normalised radius of every point in the camera that sees it, at pose (q, t) -- utils.h:120-127 / :208-245"""
+        Rq = synth.quat_to_R(q)
+        A = X
+        if second:
+            Ti = np.linalg.inv(T12)
+            A = X @ Ti[:3, :3].T + Ti[:3, 3]
+        Bp = A @ Rq.T + t
+        if second:
+            Bp = Bp @ T12[:3, :3].T + T12[:3, 3]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            rn = np.hypot(Bp[:, 0] / Bp[:, 2], Bp[:, 1] / Bp[:, 2])
+        return ~(rn <= 1.5)
+
+    if split_far and kind < 2:
+        # the two parts of the family, each against the oracle on the same points
+        fam, Kc, second, Oc = (fams[1], K2, True, O2) if kind == 1 else (fams[0], K1, False, O1)
+        far = far_mask(fam["xyz"], second)
+        for part, ptol in ((~far, 5e-4), (far, 2e-3)):
+            Xp = np.ascontiguousarray(fam["xyz"][part])
+            if len(Xp) == 0:
+                continue
+            Pp = capi.Problem(*Kc, dtype=dtype); Pp.set_points(Xp); Pp.set_dt_grid(fam["grid"]); Pp.set_loss(*loss); Pp.set_distortion(*dist)
+            if second: Pp.set_second_camera(T12)
+            gp, ep = Pp.eval(q, t), Oc.eval(Xp, q, t, eo.JAC_JET)
+            Pp.close()
+            assert int(gp["n_invalid"]) == int(ep["n_invalid"]), (n_cases, kind, "part")
+            if not ep["n_invalid"]:
+                rp = max(rel(gp["cost"], ep["cost"]), rel(gp["JtJ"], ep["JtJ"]))
+                if rp >= ptol:
+                    print("FAIL case", n_cases, "kind", kind, tag, "part tol", ptol, "points", len(Xp), "rel", rp, "dist", dist)
+                    n_fail += 1
+                if ptol == 5e-4:
+                    worst[tag] = max(worst[tag], rp)
+        n_split += 1
+        P1.close(); P2.close()
+        n_cases += 1
+        continue
+    if split_far:
+        tol = 2e-3   # (two-family kinds: the far points of both cameras sit in one sum; the per-part check above covers the family)
     if kind == 0:
         e = O1.eval(fams[0]["xyz"], q, t, eo.JAC_JET); g = P1.eval(q, t)
         got = (g["cost"], g["JtJ"], g["Jtr"], g["n_invalid"])
@@ -112,6 +153,11 @@ while time.time() < t_end:
                 m = min(10, len(s1["it_cost"]), len(so["it_cost"]))
                 head = all(s1["it_successful"][k] == so["it_successful"][k] and abs(s1["it_cost"][k] - so["it_cost"][k]) <= 1e-9 * abs(so["it_cost"][k]) for k in range(m))
                 ok = head and s1["termination"] == so["termination"] and abs(s1["final_cost"] - so["final_cost"]) <= 1e-3 * abs(so["final_cost"])
+                # and, independent of where the two trajectories drifted to (round 3): the evaluator itself at the ORACLE's
+                # final pose -- cost to 1e-9, the bar of every other fp64 evaluation
+                ge = P1.eval(qo, to)
+                eo_end = eo.eval_terms([O1, O2], [fams[0]["xyz"], fams[1]["xyz"]], qo, to, eo.JAC_JET)
+                ok = ok and int(ge["n_invalid"]) == int(eo_end["n_invalid"]) and (eo_end["n_invalid"] or rel(ge["cost"], eo_end["cost"]) <= 1e-9)
                 n_capped += 1
             if not ok:
                 n_fail += 1
@@ -128,4 +174,4 @@ while time.time() < t_end:
         assert rel(pc["total_cost"], want["total_cost"]) < 1e-12, n_cases
     P1.close(); P2.close()
     n_cases += 1
-print("soak (variants) %s:" % ("ok" if not n_fail else "FAILED %d" % n_fail) + " %d cases, %d joint solves (%d cut off by the iteration cap), seed %d; worst relative error f64 %.2e f32 %.2e" % (n_cases, n_solves, n_capped, seed, worst["f64"], worst["f32"]))
+print("soak (variants) %s:" % ("ok" if not n_fail else "FAILED %d" % n_fail) + " %d cases, %d joint solves (%d cut off by the iteration cap), %d fp32 families with |k| > 0.5 checked in two parts, seed %d; worst relative error f64 %.2e f32 %.2e (fp32: rows inside normalised radius 1.5)" % (n_cases, n_solves, n_capped, n_split, seed, worst["f64"], worst["f32"]))

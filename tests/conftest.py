@@ -17,7 +17,7 @@ def pytest_configure(config):
 def _torch_brings_the_gpu_up_first():
     """PyTorch-ROCm bundles its own HIP/HSA runtime: in a process that uses both (the on-stream collective of
     ea_solve_sharded_device, bench.py) torch has to initialise the GPU before libea_hip.so does, or torch's runtime finds
-    no device afterwards (scripts/order_probe.py).  No GPU: nothing happens."""
+    no device afterwards (scripts/archive/order_probe.py).  No GPU: nothing happens."""
     try:
         import torch
         if torch.cuda.is_available():

@@ -3,7 +3,7 @@
 The log: 1482 residual blocks (= ceil(44457 / 30): frame 1, stride 30, standalone_edge_align.cpp:267), CauchyLoss(1),
 identity start, LM defaults; 30 iterations, every step successful, CONVERGENCE on the function tolerance, cost
 8.743202 -> 0.5418352, final YPR = (-0.32, 1.52, 2.50) deg, t = (-0.01, 0.00, -0.05) m.  Its inputs are not stated; of
-the bundled frames only B = 5 lands on that pose (scripts/readme_log_sweep.py: B = 2, 3, 4 end 1-2 deg away), and no
+the bundled frames only B = 5 lands on that pose (scripts/archive/readme_log_sweep.py: B = 2, 3, 4 end 1-2 deg away), and no
 combination of B, edge threshold, median filter, blur, channel order and distance-transform mask reproduces the printed
 costs (closest initial cost with the shipped parameters: 9.4515; profiles/r02_readme_log_sweep.txt) -- the log predates the
 shipped pre-processing or OpenCV's differs from its restatement.  So the test pins what the log does pin: the block
