@@ -9,7 +9,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
 rng = np.random.default_rng(seed)
 t_end = time.time() + budget
-cases = solves = rows_checked = pipelines = 0
+cases = solves = rows_checked = pipelines = pose_sets = mirrored = 0
 worst = {"f64": 0.0, "f32": 0.0, "pose_f64": 0.0, "pose_f32": 0.0}
 while time.time() < t_end:
     m = int(rng.integers(1, 7))
@@ -98,6 +98,28 @@ while time.time() < t_end:
             assert np.abs(last[key] - g[key]).max() <= 1e-12 * max(np.abs(g[key]).max(), 1e-300), (cases, "riding fold vs eval", key)
         assert np.array_equal(last["n_invalid"], g["n_invalid"]), (cases, "riding fold: invalid count")
         pipelines += 1
+    # the product form of the same thing (round 3): ea_batch_eval_poses with K different poses per problem -- every pose's
+    # sums against ea_batch_eval at that pose (1e-12 fp64 / 2e-6 fp32: another summation order, pose constants built on the
+    # device), the dt_f32 mirror on or off at random (bit-identical either way, checked where both are taken)
+    if cases % 4 == 1:
+        K = int(rng.integers(1, 6))
+        Qk = np.stack([Q] * K); Tk = np.stack([T + 0.002 * rng.normal(size=T.shape) for _ in range(K)])
+        B.set_tuning("dt_f32", -1 if rng.random() < 0.7 else 0)
+        pk = B.eval_poses(Qk, Tk)
+        ptol = 1e-12 if dtype == capi.EA_F64 else 2e-6
+        for k in range(K):
+            gk = B.eval(Qk[k], Tk[k])
+            for key in ("cost", "JtJ", "Jtr"):
+                assert np.abs(pk[key][k] - gk[key]).max() <= ptol * max(np.abs(gk[key]).max(), 1e-300), (cases, "eval_poses vs eval", k, key)
+            assert np.array_equal(pk["n_invalid"][k], gk["n_invalid"]), (cases, "eval_poses: invalid count", k)
+        if dtype == capi.EA_F64 and B.info("dt_f32") == 1:
+            B.set_tuning("dt_f32", 0)
+            pk0 = B.eval_poses(Qk, Tk)
+            for key in ("cost", "JtJ", "Jtr", "n_invalid"):
+                assert np.array_equal(pk[key], pk0[key]), (cases, "fp32-stored image changed the bits", key)
+            mirrored += 1
+        B.set_tuning("dt_f32", -1)
+        pose_sets += 1
     if cases % 5 == 0:
         i = int(rng.integers(m))
         if Xs[i].shape[0] >= 500:
@@ -121,5 +143,5 @@ while time.time() < t_end:
     for P in Ps:
         P.close()
     cases += 1
-print("soak ok: %d batches, %d solves, %d row sets, %d pipelined sequences, seed %d; worst relative sum error f64 %.2e f32 %.2e; worst pose difference f64 %.2e rad f32 %.2e rad" % (
-    cases, solves, rows_checked, pipelines, seed, worst["f64"], worst["f32"], worst["pose_f64"], worst["pose_f32"]))
+print("soak ok: %d batches, %d solves, %d row sets, %d pipelined sequences, %d K-pose calls (%d of them bit-compared with and without the float32 image), seed %d; worst relative sum error f64 %.2e f32 %.2e; worst pose difference f64 %.2e rad f32 %.2e rad" % (
+    cases, solves, rows_checked, pipelines, pose_sets, mirrored, seed, worst["f64"], worst["f32"], worst["pose_f64"], worst["pose_f32"]))
