@@ -1819,12 +1819,18 @@ hipError_t launch_eval_fused(int dtype, int ppt, int nt, int variant, const Prob
   return hipGetLastError();
 }
 
+hipError_t launch_reduce_nt(int nt, const GroupDesc *groups, int count, const double *partials, EvalOut *out,
+                            hipStream_t stream);
+
 // evaluation into `partials` + the fold of `prev_rows` -> `prev_out` in one launch (ea_eval_fold_kernel)
 hipError_t launch_eval_fold(int dtype, int ppt, int nt, const ProblemDesc *probs, int nterms, int chunk, int max_chunks,
                             int xcd_remap, const PoseState *poses, double *partials, int buffer_loads, int img32, const void *x0,
                             const void *y0, const void *z0, int n0, const GroupDesc *groups, const double *prev_rows,
                             EvalOut *prev_out, hipStream_t stream) {
   const int lds_bytes = 0, terms_are_groups = 1;
+  // a batch without a single point has nothing to evaluate, but the previous step's fold is still owed (its result slot
+  // must not keep what an earlier owner of the memory left there): the stand-alone fold in the riders' summation order
+  if (nterms > 0 && max_chunks <= 0) return launch_reduce_nt(nt, groups, nterms, prev_rows, prev_out, stream);
   EA_LAUNCH_PROLOGUE
   const dim3 grid_f(grid.x + 1, grid.y);
   if (img32) {

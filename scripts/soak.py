@@ -110,7 +110,9 @@ while time.time() < t_end:
         for k in range(K):
             gk = B.eval(Qk[k], Tk[k])
             for key in ("cost", "JtJ", "Jtr"):
-                assert np.abs(pk[key][k] - gk[key]).max() <= ptol * max(np.abs(gk[key]).max(), 1e-300), (cases, "eval_poses vs eval", k, key)
+                assert np.abs(pk[key][k] - gk[key]).max() <= ptol * max(np.abs(gk[key]).max(), 1e-300), (
+                    cases, "eval_poses vs eval", k, key, tag, pk[key][k], gk[key], Qk[k], [x.shape for x in Xs], B.info("points_per_thread"), B.info("threads"),
+                    B.info("lds_bytes"), B.info("wide_accumulate"), B.info("poses_ride"), gk["n_invalid"])
             assert np.array_equal(pk["n_invalid"][k], gk["n_invalid"]), (cases, "eval_poses: invalid count", k)
         if dtype == capi.EA_F64 and B.info("dt_f32") == 1:
             B.set_tuning("dt_f32", 0)

@@ -49,7 +49,7 @@ def _check_batch_bit_identical(hip, B, m, q, t):
     assert _same(p_on, p_off)
     assert np.array_equal(s_on[0], s_off[0]) and np.array_equal(s_on[1], s_off[1])
     for a, b in zip(s_on[2], s_off[2]):
-        assert a["num_iterations"] == b["num_iterations"] and a["it_cost"] == b["it_cost"] and a["final_cost"] == b["final_cost"]
+        assert a["num_iterations"] == b["num_iterations"] and np.array_equal(a["it_cost"], b["it_cost"]) and a["final_cost"] == b["final_cost"]
 
 
 def test_bundled_pair_fp32_image_is_bit_identical(hip, bundled_pair):

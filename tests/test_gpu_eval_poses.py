@@ -144,6 +144,34 @@ def test_failed_functors_non_unit_quaternions_and_the_ros_flavour(hip, oracle):
         B.close(); P.close()
 
 
+def test_empty_problems_report_zeros_at_every_pose(hip):
+    """a problem without points (the reference's loop simply adds no block) has cost 0 and a zero system at every one of the
+    K poses -- alone in its batch (no evaluation launch at all: the riding folds still owe their results) and next to others"""
+    base = synth.make_problem(60, 80, 500, 12, 3, 65.0, 65.0, 39.5, 29.5, normalize=True)
+    for dtype in (hip.EA_F64, hip.EA_F32):
+        E = hip.Problem(*base["K"], dtype=dtype); E.set_points(np.zeros((0, 3))); E.set_dt_grid(base["grid"])
+        F = hip.Problem(*base["K"], dtype=dtype); F.set_points(base["xyz"]); F.set_dt_grid(base["grid"])
+        # (dirty the pinned result block first: a full problem leaves non-zero sums where the empty one's go next)
+        Bf = hip.Batch([F])
+        Bf.eval_poses(np.tile([1.0, 0, 0, 0], (6, 1, 1)), np.zeros((6, 1, 3)))
+        Bf.close()
+        for members in ([E], [E, F], [F, E, E]):
+            B = hip.Batch(members)
+            m = len(members)
+            for K in (1, 2, 5):
+                q = np.tile([1.0, 0, 0, 0], (K, m, 1)); t = 0.001 * np.arange(K * m * 3).reshape(K, m, 3)
+                got = B.eval_poses(q, t)
+                for k in range(K):
+                    ref = B.eval(q[k], t[k])
+                    for i, P in enumerate(members):
+                        if P is E:
+                            assert got["cost"][k, i] == 0.0 and not got["JtJ"][k, i].any() and not got["Jtr"][k, i].any() and got["n_invalid"][k, i] == 0
+                        else:
+                            assert abs(got["cost"][k, i] - ref["cost"][i]) <= 2e-6 * ref["cost"][i]
+            B.close()
+        E.close(); F.close()
+
+
 def test_argument_checks_and_state(hip):
     base = synth.make_problem(60, 80, 500, 12, 3, 65.0, 65.0, 39.5, 29.5, normalize=True)
     P = hip.Problem(*base["K"], dtype=hip.EA_F64)
