@@ -183,7 +183,7 @@ def test_argument_checks_and_state(hip):
         assert ei.value.code == hip.EA_ERR_STATE
         L = hip.load()
         assert L.ea_batch_set_poses(B._h, 0, None, None) == hip.EA_ERR_INVALID_ARG
-        q, t = np.tile([1.0, 0, 0, 0], (12, 1, 1)), np.zeros((12, 1, 3))
+        q, t = np.tile([1.0, 0, 0, 0], (12, 1, 1)), np.tile([0.01, -0.02, 0.015], (12, 1, 1))   # (off the planted pose: cost > 0)
         assert L.ea_batch_eval_poses(B._h, 0, hip._dp(q), hip._dp(t), None, None, None, None) == hip.EA_ERR_INVALID_ARG
         B.set_poses(q, t)
         B.eval_resident_poses(fetch=False)       # results stay in the library; nothing handed back
@@ -195,8 +195,8 @@ def test_argument_checks_and_state(hip):
         assert ei.value.code == hip.EA_ERR_STATE
         # growing K re-allocates; shrinking re-uses
         for K in (40, 3, 17):
-            qk, tk = np.tile([1.0, 0, 0, 0], (K, 1, 1)), np.zeros((K, 1, 3))
+            qk, tk = np.tile([1.0, 0, 0, 0], (K, 1, 1)), np.tile([0.01, -0.02, 0.015], (K, 1, 1))
             o = B.eval_poses(qk, tk)
-            assert o["cost"].shape == (K, 1) and np.all(o["cost"] == o["cost"][0])
+            assert o["cost"].shape == (K, 1) and np.all(o["cost"] == o["cost"][0]) and o["cost"][0, 0] > 0
     finally:
         B.close(); P.close()
