@@ -1,0 +1,20 @@
+#!/bin/bash
+# round 3, fifth GPU visit: the committed evidence -- bench lines, rocprofv3 kernel-trace stats of the same commands, PMC passes
+set -o pipefail
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03e; mkdir -p $O
+cd $R
+timeout -k 10 600 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err; echo "bench c2 rc=$?"
+timeout -k 10 600 python bench.py --steps 20 --warmup 5 > $O/bench_c2_steps20.json 2> $O/bench_c2_steps20.err; echo "bench c2 steps20 rc=$?"
+timeout -k 10 300 python bench.py --serial-steps --no-extras --no-cpu-baseline > $O/bench_c2_serial_steps.json 2> /dev/null; echo "bench serial rc=$?"
+timeout -k 10 300 python bench.py --workload c5 --no-extras --no-cpu-baseline > $O/bench_c5.json 2> /dev/null; echo "bench c5 rc=$?"
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c2_steps20 -o k -- python3 $R/bench.py --steps 20 --warmup 5 > $O/kt_c2_steps20.log 2>&1; echo "kernel-trace steps20 rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c2 -o k -- python3 $R/bench.py --no-extras --no-cpu-baseline > $O/kt_c2.log 2>&1; echo "kernel-trace c2 rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c5 -o k -- python3 $R/bench.py --workload c5 --no-extras --no-cpu-baseline > $O/kt_c5.log 2>&1; echo "kernel-trace c5 rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_sharded -o k -- python3 $R/scripts/prof_sharded.py > $O/kt_sharded.log 2>&1; echo "kernel-trace sharded rc=$?"
+tail -3 $O/kt_sharded.log
+cd $R
+bash scripts/pmc_traffic_bench.sh > $O/pmc_traffic_bench.txt 2>&1; echo "pmc traffic rc=$?"; tail -12 $O/pmc_traffic_bench.txt
+bash scripts/pmc_valu_refresh.sh > $O/pmc_valu_refresh.txt 2>&1; echo "pmc valu rc=$?"; tail -5 $O/pmc_valu_refresh.txt
+find $O -name "*kernel_stats.csv" | head; 
+for d in kt_c2_steps20 kt_c2 kt_c5 kt_sharded; do f=$(find $O/$d -name "*kernel_stats.csv" | head -1); echo "== $d"; head -8 $f | cut -c1-200; done
