@@ -17,7 +17,7 @@ LIB = os.path.join(_HERE, "lib", "libea_hip.so")
 # -amdgpu-kernarg-preload-count: the command processor hands the first 16 dwords of the kernel-argument segment to
 # every wave in SGPRs, so a kernel does not start with a scalar load of its own pointers and a wait (gfx950; kernels
 # keep a loading prologue for firmware without the feature).  Latency-bound launches: C2's evaluation 3.27 -> 3.00 us,
-# the 1e5-point fp32 evaluation 2.90 -> 2.62 us (same-box A/B); batches unchanged.
+# the 1e5-point fp32 evaluation 2.90 -> 2.62 us (same-box A/B, profiles/LOG.md section 5b); batches unchanged.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-mllvm", "-amdgpu-kernarg-preload-count=16",
          "-Wall", "-Wno-unused-function"]
 

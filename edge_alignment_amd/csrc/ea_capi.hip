@@ -1148,7 +1148,7 @@ static int batch_build(ea_batch *b) {
     HIPCHK(hipEventRecord(b->desc_done, b->stream));
   }
   // LDS staging of the DT footprint is available but off by default: on MI355X the unaligned 16-byte
-  // row loads served by the XCD's L2 beat it at every size measured
+  // row loads served by the XCD's L2 beat it at every size measured (profiles/LOG.md section 5)
   int use_lds = b->t_use_lds < 0 ? 0 : b->t_use_lds;
   int lds = b->t_lds_bytes >= 0 ? b->t_lds_bytes : (b->dtype == EA_F32 ? 32768 : 49152);
   if (lds > 61440) lds = 61440;

@@ -1731,7 +1731,7 @@ __global__ __launch_bounds__(256) void ea_aos_to_soa_kernel(const double *__rest
 // same file compiled with -DEA_TU_VARIANT through ea_kernels_var.hip (the distortion / second-camera functors only).
 // They differ in ONE compiler setting: the plain kernels are scheduled for instruction-level parallelism
 // (-mllvm -amdgpu-sched-strategy=max-ilp: -2 .. -4 % kernel time), which costs the variant kernels a wave of occupancy in
-// fp64 (123 -> 136 VGPRs) and 4-7 % of their time -- they keep the default strategy (build.py).
+// fp64 (123 -> 136 VGPRs) and 4-7 % of their time -- they keep the default strategy (build.py; profiles/LOG.md section 5b).
 #define EA_LAUNCH_B(T, P, L, N, V, B)                                                              \
   hipLaunchKernelGGL((ea_eval_fused_kernel<T, P, L, N, V, B>), grid, dim3(N), shmem, stream, x0, y0, z0, n0, shape, \
                      chunks_per_xcd, probs, poses, partials, lds_texels)

@@ -1,6 +1,6 @@
 """ea_batch_set_tuning("wide_accumulate", 1): an fp32 evaluation sums in fp64 from the lane's sum of <= points_per_thread
 products on (SURVEY section 7 step 3 asks for fp64 accumulation in fp32 mode; the default keeps a lane's and a wavefront's
-sums in fp32 -- DESIGN.md section 10).
+sums in fp32 -- profiles/LOG.md section 10).
 
 Properties checked: (1) at one point per lane the wide sums are fp64 sums of the same fp32 per-point products whatever
 the workgroup size or the addressing form, so two launch shapes agree to fp64 reordering (1e-13 relative), and they are
