@@ -9,12 +9,14 @@ resident in HBM: the fused per-point kernel (SE(3) warp, pinhole, bicubic DT sam
 row, IRLS weight, JtJ/Jtr/cost partials) plus the fixed-order fold of the partials.  The K timed steps
 are ONE call of the product API ea_batch_eval_resident_poses (include/ea_hip.h): K INDEPENDENT
 evaluations at K DIFFERENT poses -- the throughput a caller gets who asks for many evaluations at
-once (cost-surface probes, a line search, its own optimiser) -- in which the fold of step k-1 rides
-in the launch of step k.  It is NOT the cost of an evaluation inside the trust-region loop, where
-step k+1 depends on the fold and the LM step of k: that dependent form (evaluation -> fold, two
-launches per step) is carried beside the headline as `value_serial_dependent_steps` /
-roofline.step_ms_events_serial_dependent, and --serial-steps makes it the timed region; the loop
-itself is measured by lm_iters_per_s_at_1e5_pts.  Default workload = BASELINE.json configs[1]
+once (cost-surface probes, a line search, multi-start, its own optimiser).  Independent evaluations
+need not queue up behind each other: the pose is a batch dimension of the launch (G poses per
+evaluation launch, every (point, pose) pair evaluated in full, every pose's partial rows folded).
+It is NOT the cost of an evaluation inside the trust-region loop, where step k+1 depends on the
+fold and the LM step of k: that dependent form (evaluation -> fold, two launches per step, one
+pose per launch) is carried beside the headline as `value_serial_dependent_steps` /
+roofline.one_pose_per_launch, and --serial-steps makes it the timed region; the loop itself is
+measured by lm_iters_per_s_at_1e5_pts.  Default workload = BASELINE.json configs[1]
 (C2): single 640x480 frame pair, 5e4 edge points, fp64.  With N GPUs every rank evaluates its own
 independent frame pair (weak scaling, no data-path collective); the one collective is the pose
 all-gather (RCCL) after the per-rank LM solves, reported separately.
@@ -369,21 +371,24 @@ def main():
     # creates its events), then the K poses of the timed region go up (inputs resident in HBM when the clock starts) and
     # their sequence is run once (captures the graph) plus EA_BENCH_WARM_REPLAYS times more.
     # Timed: EXACTLY K steps between barrier+sync brackets = ONE call of the product API ea_batch_eval_resident_poses --
-    # K evaluations at K DIFFERENT poses (no two steps read the same stencils), each its per-point kernel and its fold in
-    # full, the fold of step k-1 riding in the launch of step k, one synchronisation, the K results unpacked into the
-    # caller's arrays.  --serial-steps: the LM loop's dependency instead (evaluation -> fold, two dependent launches per
-    # step, at the resident pose; a measurement hook).
+    # K evaluations at K DIFFERENT poses (no two steps read the same stencils), every (point, pose) pair through the whole
+    # per-point arithmetic and every pose's partial rows through the fold; the pose is a batch dimension of the launch (G
+    # poses per evaluation launch + one fold launch, ceil(K / G) such pairs), one synchronisation, the K results unpacked
+    # into the caller's arrays.  --serial-steps: the LM loop's dependency instead (evaluation -> fold, two dependent
+    # launches per step, at one pose; a measurement hook).
     B.bench_eval(q0, t0, 0, max(args.warmup, 1), kernel_pass=False)
     Qk, Tk = step_poses(args.steps, 1000 + rank)
     mode = "serial" if (args.serial_steps or args.no_graph) else "poses"
-    graph, pipelined, out_k, warm_replays = None, False, None, 0
+    graph, pipelined, out_k, warm_replays, G = None, False, None, 0, 1
     if mode == "poses":
         B.set_poses(Qk, Tk)
         out_k = B.eval_resident_poses()
-        pipelined = bool(B.info("poses_ride"))   # (plain single-family batch on the L2 path: the riding form)
+        pipelined = True
+        G = int(B.info("poses_per_launch"))
         graph = ("ea_batch_eval_resident_poses: %d evaluations at %d different poses (rotations <= 0.2 deg, translations <= 5 mm "
-                 "around the identity), one call; K launches (evaluation k + riding fold k-1) + one closing fold replayed from "
-                 "one hipGraph, one synchronisation, results unpacked" % (args.steps, args.steps))
+                 "around the identity), one call; %d evaluation launch(es) of up to %d poses each (grid = chunks x poses: every "
+                 "(point, pose) pair is evaluated in full) + as many fold launches, one synchronisation, results unpacked"
+                 % (args.steps, args.steps, -(-args.steps // G), G))
         warm_replays = int(os.environ.get("EA_BENCH_WARM_REPLAYS", "2"))
         for _ in range(warm_replays):
             B.eval_resident_poses(out=out_k)
@@ -451,69 +456,82 @@ def main():
     B.bench_eval(q0, t0, 0, 1, kernel_pass=False)  # (poses resident again for the measurements below)
 
     # Duration of the dominant kernel, HIP events on the library's stream.
-    #   kernel_ms               (event pair around replays of nk >= 100 steps at nk different poses) / nk -- a step IS one
-    #                           launch of the evaluation kernel (with the previous step's fold riding in it), the figure
-    #                           rocprofv3 --kernel-trace reports per launch for this command (profiles/); serial region:
-    #                           the evaluation's share of a step = that quotient minus the fold kernel's own time.  Never
-    #                           below kernel_ms_back_to_back.  `achieved` / `frac` are computed from it;
-    #   kernel_ms_back_to_back  one event pair around a run of plain evaluation launches executing from the queue, / their
-    #                           number: the kernel's execution window with the next dispatch already decoded;
-    #   kernel_ms_isolated      an event pair around every single launch of the serial pattern, which also contains the
-    #                           command processor's dispatch (~2.6 us) because nothing is in flight to hide it;
-    #   launch_floor_ms         an EMPTY kernel of the same grid in a replayed graph of nk nodes: what the launch mechanism
-    #                           costs per node whatever the kernel does -- frac_ceiling_at_floor = algorithmic bytes /
-    #                           launch_floor_ms / peak is the most this workload's ONE launch per step could reach.
+    #   kernel_ms               (event pair around the timed call's evaluation launches, executing back to back from the
+    #                           queue) / their number: the average duration of the dominant kernel -- the evaluation launch
+    #                           of G poses -- the figure rocprofv3 --kernel-trace reports per launch for this command
+    #                           (profiles/).  `achieved` / `frac` = G x (one evaluation's algorithmic bytes) / kernel_ms;
+    #   launch_floor_ms         an EMPTY kernel of the same grid in a replayed graph: what the launch mechanism costs per
+    #                           node whatever the kernel does; frac_ceiling_at_floor = algorithmic bytes / floor / peak;
+    #   one_pose_per_launch     the same kernel at one pose per launch (an LM iteration's launch, rounds 1-2's headline
+    #                           kernel): back-to-back duration, its floor and ceiling, the dependent two-launch step;
+    #   serial region (--serial-steps): the evaluation's share of a dependent step.
     nk = min(max(args.steps, 100), 1000)
     ms_steps, ms_kernel_isolated = B.bench_eval(q0, t0, 2, min(args.steps, 64))
     ms_steps, _ = B.bench_eval(q0, t0, 20, nk, kernel_pass=False)       # launch by launch (host-bound: ~3.1 us per launch)
     step_ms_eager = ms_steps / nk
-    step_ms_serial = step_ms_pipelined = None
     try:
         B.bench_capture(nk)
         step_ms_serial = min(B.bench_steps(nk, host_times=True)[2] for _ in range(3)) / nk
     except capi.EAError:
         step_ms_serial = step_ms_eager
-    if pipelined:
-        Qn, Tn = step_poses(nk, 2000 + rank)
-        B.set_poses(Qn, Tn)
-        step_ms_pipelined = min(B.bench_resident_poses(3) for _ in range(3)) / nk
-        B.bench_eval(q0, t0, 0, 1, kernel_pass=False)
     ms_fold = B.bench_fold(10, nk)
-    ms_kernel_b2b = B.bench_kernel(q0, t0, 10, nk)
-    step_ms = step_ms_pipelined if pipelined else step_ms_serial
-    ms_kernel = max(step_ms if pipelined else step_ms - ms_fold, ms_kernel_b2b)
-    bytes_launch = algorithmic_bytes(n_pts, H, W, esize)
+    ms_kernel_b2b = B.bench_kernel(q0, t0, 10, nk)          # one pose per launch (the LM loop's launch), back to back
+    bytes_eval = algorithmic_bytes(n_pts, H, W, esize)      # ONE evaluation of every point: 3 s per point + the image once
+    poses_launch = launches = None
+    if pipelined:
+        # The timed call's own launches (the K poses are resident again), between one event pair on the library's stream:
+        # with and without the fold launches.  The dominant kernel is the evaluation launch of G poses; its duration is the
+        # evaluations-only time / number of launches, its algorithmic bytes G x (one evaluation's bytes).
+        B.set_poses(Qk, Tk)
+        ms_run, launches = min(B.bench_resident_poses(5) for _ in range(3))
+        ms_evals, _ = min(B.bench_resident_poses(5, evaluations_only=True) for _ in range(3))
+        B.bench_eval(q0, t0, 0, 1, kernel_pass=False)
+        poses_launch = args.steps / launches
+        ms_kernel = ms_evals / launches
+        bytes_launch = bytes_eval * poses_launch
+        step_ms = ms_run / args.steps
+    else:
+        step_ms = step_ms_serial
+        ms_kernel = max(step_ms - ms_fold, ms_kernel_b2b)
+        bytes_launch = bytes_eval
     achieved = bytes_launch / (ms_kernel * 1e-3) / 1e9
-    try:
-        floor_ms = capi.graph_floor_ms(local_rank, nodes=nk, grid=max(1, int(B.info("num_tiles"))), block=int(B.info("threads")))
+    try:   # the launch mechanism's floor for THIS grid: an empty kernel of as many workgroups in a replayed graph
+        floor_ms = capi.graph_floor_ms(local_rank, nodes=max(8, min(nk, 20000 // max(1, int(poses_launch or 1)))),
+                                       grid=max(1, int(B.info("num_tiles") * (poses_launch or 1))), block=int(B.info("threads")))
+        floor_one_ms = capi.graph_floor_ms(local_rank, nodes=nk, grid=max(1, int(B.info("num_tiles"))), block=int(B.info("threads")))
     except capi.EAError:
-        floor_ms = None
+        floor_ms = floor_one_ms = None
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
             tj = json.load(open(pmc_path))
-            traffic = (tj.get(args.workload + "_riding_fold") if pipelined else None) or tj.get(args.workload, {})
+            traffic = (tj.get(args.workload + "_poses_%d" % args.steps) if pipelined else None) or {}
             traffic = traffic.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "%s<%s>" % ("ea_eval_fold_kernel" if pipelined else "ea_eval_fused_kernel", "double" if esize == 8 else "float"),
-                "kernel_ms": ms_kernel, "kernel_ms_back_to_back": ms_kernel_b2b,
-                "frac_back_to_back": bytes_launch / (ms_kernel_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "kernel": "ea_eval_fused_kernel<%s>" % ("double" if esize == 8 else "float"),
+                "kernel_ms": ms_kernel,
+                "evaluation_launches_in_timed_region": launches, "poses_per_launch": poses_launch,
+                "algorithmic_bytes_per_launch": bytes_launch, "algorithmic_bytes_per_evaluation": bytes_eval,
                 "launch_floor_ms": floor_ms,
                 "frac_ceiling_at_floor": (bytes_launch / (floor_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if floor_ms else None,
-                "frac_of_ceiling_at_floor": (floor_ms / ms_kernel) if floor_ms else None,
-                "fold_kernel_ms": ms_fold, "step_ms_events": step_ms,
-                "step_ms_events_serial_dependent": step_ms_serial,
-                "step_ms_events_eager_launches": step_ms_eager, "kernel_ms_isolated": ms_kernel_isolated,
-                "algorithmic_bytes_per_launch": bytes_launch,
+                # the same kernel with ONE pose per launch (what an LM iteration launches; rounds 1-2's headline kernel):
+                # a launch of 196 workgroups is bounded by the launch mechanism, not by the chip
+                "one_pose_per_launch": {"kernel_ms_back_to_back": ms_kernel_b2b,
+                                        "frac": bytes_eval / (ms_kernel_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "launch_floor_ms": floor_one_ms,
+                                        "frac_ceiling_at_floor": (bytes_eval / (floor_one_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if floor_one_ms else None,
+                                        "kernel_ms_isolated": ms_kernel_isolated, "fold_kernel_ms": ms_fold,
+                                        "step_ms_events_serial_dependent": step_ms_serial, "step_ms_events_eager_launches": step_ms_eager,
+                                        "counter_busy": counter_busy(args.workload, ms_kernel_b2b)},
+                "step_ms_events": step_ms, "step_ms_events_serial_dependent": step_ms_serial,
                 # (fp64 over a float32-stored image, when every texel is float-representable: same doubles, 4-byte texels read;
                 # achieved / frac stay on the algorithmic 8-byte definition)
                 "image_texel_bytes_read": 4 if B.info("dt_f32") else esize,
-                "counter_busy": counter_busy(args.workload, ms_kernel),
-                "secondary": valu_issue(args.workload, ms_kernel_b2b)}
+                "secondary": valu_issue(args.workload, ms_kernel / max(1.0, float(poses_launch or 1)))}
 
     # Materialised mode of the same workload ("report both numbers"): r and the 1x6 row of every point written
     # out in the batch's dtype (ea_batch_eval_rows_device), the bandwidth-bound form of the path: 3 s in + 7 s out per
@@ -737,7 +755,7 @@ def main():
                      for Px, cfgx in zip(Ps, problems))
             us_serial = ms / 100 * 1e3
             us_step = us_serial
-            try:  # the launch pattern of the headline: fold of step k-1 riding in evaluation k, 100 steps replayed from a graph
+            try:  # independent evaluations of the whole batch at one pose: fold of step k-1 riding in evaluation k, 100 steps replayed from a graph
                 Bx.bench_capture_pipelined(100)
                 us_step = min(Bx.bench_steps(100, host_times=True)[2] for _ in range(3)) / 100 * 1e3
             except capi.EAError:

@@ -151,7 +151,7 @@ def load():
     L.ea_batch_bench_result_riding.argtypes = [vp, dp, dp, dp, i64p]
     L.ea_batch_bench_kernel.argtypes = [vp, dp, dp, C.c_int, C.c_int, dp]
     L.ea_batch_bench_fold.argtypes = [vp, C.c_int, C.c_int, dp]
-    L.ea_batch_bench_resident_poses.argtypes = [vp, C.c_int, dp]
+    L.ea_batch_bench_resident_poses.argtypes = [vp, C.c_int, C.c_int, dp, C.POINTER(C.c_int)]
     L.ea_bench_graph_floor.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, dp]
     L.ea_batch_row_offsets.argtypes = [vp, i64p]
     L.ea_problem_num_rows.argtypes = [vp, i64p]
@@ -722,11 +722,12 @@ class Batch:
         _check(load().ea_batch_eval_resident_poses(self._h, *ptrs))
         return out
 
-    def bench_resident_poses(self, reps):
-        """ms per replay of the resident poses' graph (event pair on the batch's stream around `reps` replays)"""
-        ms = C.c_double()
-        _check(load().ea_batch_bench_resident_poses(self._h, int(reps), C.byref(ms)))
-        return ms.value
+    def bench_resident_poses(self, reps, evaluations_only=False):
+        """(ms per run of the resident poses' launches -- one event pair on the batch's stream around `reps` runs --,
+        evaluation launches per run); evaluations_only: without the fold launches"""
+        ms, n = C.c_double(), C.c_int()
+        _check(load().ea_batch_bench_resident_poses(self._h, int(reps), int(evaluations_only), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def solve(self, q, t, **opts):
         q = _f64(q).reshape(-1, 4).copy()

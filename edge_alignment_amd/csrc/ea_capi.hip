@@ -419,8 +419,12 @@ struct ea_batch {
   double *h_kqt = nullptr, *d_kqt = nullptr;      // q, t staging: cap x count x 7 doubles (pinned / device)
   PoseState *d_kposes = nullptr;                  // cap x count
   EvalOut *h_kout = nullptr, *dv_kout = nullptr;  // cap x count, pinned + the device's view of it
-  hipGraphExec_t kp_graph = nullptr;
-  int kp_graph_K = 0;
+  // G poses per launch: the descriptor / group tables replicated G times (copy g of a term owns the partial rows and the pose
+  // slot of pose g) and the partial rows of G poses
+  int kp_G = 0, t_kp_G = 0;   // (t_kp_G > 0: tuning key "poses_per_launch" caps G)
+  ProblemDesc *d_kprobs = nullptr;
+  GroupDesc *d_kgroups = nullptr;
+  double *d_krows = nullptr;
   bool needs_drain = false;     // a solve gave up on its deadline with launches still queued: synchronise before reuse
   const void *x0 = nullptr, *y0 = nullptr, *z0 = nullptr;  // problem 0's point arrays and count, handed to the evaluation
   int n0 = 0;                                              // kernel in its preloaded arguments
@@ -839,13 +843,10 @@ static void bench_ring_free(ea_batch *b) {
   b->d_bench_rows = nullptr; b->d_bench_out = nullptr; b->bench_ring = 0; b->bench_riding_steps = 0;
 }
 
-static void kposes_drop_graph(ea_batch *b) {
-  if (b->kp_graph) { (void)hipGraphExecDestroy(b->kp_graph); b->kp_graph = nullptr; }
-  b->kp_graph_K = 0;
-}
+static void kposes_free_tables(ea_batch *b);
 
 static void kposes_free(ea_batch *b) {
-  kposes_drop_graph(b);
+  kposes_free_tables(b);
   cached_free(b->d_kqt); cached_free(b->d_kposes);
   cached_host_free(b->h_kqt); cached_host_free(b->h_kout);
   b->d_kqt = nullptr; b->d_kposes = nullptr; b->h_kqt = nullptr; b->h_kout = nullptr; b->dv_kout = nullptr;
@@ -1003,8 +1004,8 @@ static int batch_build(ea_batch *b) {
   b->built = false;  // until the last allocation and upload below has succeeded
   if (b->bench_graph) { (void)hipGraphExecDestroy(b->bench_graph); b->bench_graph = nullptr; b->bench_graph_steps = 0; b->bench_riding_steps = 0; }
   bench_ring_free(b);  // (sized by the row count of the old build)
-  kposes_drop_graph(b);
-  b->kp_K = 0;         // (resident pose states were built for the old descriptors' flavour)
+  b->kp_K = 0;         // (resident pose states and the replicated tables were built for the old descriptors)
+  b->kp_G = 0;
   // terms of a problem follow it; all share its pose
   std::vector<const ea_problem *> terms;
   std::vector<int> term_group;
@@ -1234,12 +1235,69 @@ extern "C" int ea_batch_eval(ea_batch *b, const double *q, const double *t, doub
 // ---- K evaluations at K different poses (ea_batch_set_poses / ea_batch_eval_resident_poses / ea_batch_eval_poses) ------
 // What a caller that drives its own optimiser -- or probes a cost surface, or runs a line search -- asks of the evaluator:
 // ceres::Problem::Evaluate once per pose (src/SolveEA.cpp:241 is the reference's one call of it).  One evaluation through
-// ea_batch_eval is a launch pair and a synchronisation (~30 us on a 5e4-point pair, 3 us of which are the kernel); K of
-// them here are K launches + 1 replayed from one hipGraph, the fold of evaluation k-1 riding in the launch of evaluation k
-// (ea_eval_fold_kernel) where the batch allows it, the K results folded straight into pinned host memory, ONE
-// synchronisation.  Every evaluation runs its per-point kernel and its fold in full, at its own pose.
+// ea_batch_eval is a launch pair and a synchronisation (~30 us on a 5e4-point pair, 3 us of which are the kernel, run by
+// 196 workgroups on a 256-CU chip).  K independent evaluations do not have to queue up behind each other: the POSE is one
+// more batch dimension.  The evaluation kernel already takes (workgroup column, term) grids with a descriptor and a pose
+// per term; here the descriptor table is replicated G times -- copy g of term j keeps j's points and image and owns its own
+// partial rows and pose slot g -- so ONE launch of (chunks, G x terms) workgroups evaluates every point at G poses, one
+// fold launch of G x count workgroups folds them straight into pinned host memory (ea_batch_eval's summation order: the
+// sums of pose k are those ea_batch_eval returns at pose k), and K poses are ceil(K / G) such pairs behind one
+// synchronisation.  Every (point, pose) pair runs the whole per-point arithmetic; nothing is shared between poses but the
+// bytes of the points and the image, which the later poses find in the caches.  (Round 3 first chained K launches with the
+// fold of evaluation k-1 riding in launch k -- 3.3 us per C2 evaluation, one small launch at a time; G poses per launch
+// fill the chip.)
 
-static bool kposes_can_ride(const ea_batch *b) { return !b->any_variant && b->terms_are_groups && b->lds_bytes == 0 && !b->wide; }
+// G: poses per launch -- enough workgroups to fill the chip several times over (~32k), within the grid's y limit and 64 MB
+// of partial rows
+static int kposes_group(const ea_batch *b, int K) {
+  const int64_t wgs = std::max<int64_t>(1, (int64_t)b->ntiles);
+  int64_t g = (32768 + wgs - 1) / wgs;
+  g = std::min<int64_t>(g, 65535 / std::max(1, b->nterms));
+  g = std::min<int64_t>(g, ((int64_t)64 << 20) / (wgs * kAccSlots * (int64_t)sizeof(double)));
+  if (b->t_kp_G > 0) g = std::min<int64_t>(g, b->t_kp_G);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(g, K));
+}
+
+static void kposes_free_tables(ea_batch *b) {
+  cached_free(b->d_kprobs); cached_free(b->d_kgroups); cached_free(b->d_krows);
+  b->d_kprobs = nullptr; b->d_kgroups = nullptr; b->d_krows = nullptr;
+  b->kp_G = 0;
+}
+
+// the replicated descriptor / group tables and the partial rows of G poses; rebuilt when the batch was (kp_G = 0)
+static int kposes_tables(ea_batch *b, int G) {
+  if (b->kp_G >= G && !(b->t_kp_G > 0 && b->kp_G > b->t_kp_G)) return EA_OK;
+  HIPCHK(hipStreamSynchronize(b->stream));
+  kposes_free_tables(b);
+  const size_t nterms = (size_t)b->nterms, count = b->probs.size(), rows = (size_t)b->ntiles;
+  const ProblemDesc *hd = reinterpret_cast<const ProblemDesc *>(b->h_desc);                          // (batch_build's staging block)
+  const GroupDesc *hg = reinterpret_cast<const GroupDesc *>(b->h_desc + nterms * sizeof(ProblemDesc));
+  std::vector<ProblemDesc> descs((size_t)G * nterms);
+  std::vector<GroupDesc> groups((size_t)G * count);
+  for (int g = 0; g < G; ++g) {
+    for (size_t j = 0; j < nterms; ++j) {
+      ProblemDesc d = hd[j];
+      d.tile_begin += (int32_t)(g * rows); d.tile_end += (int32_t)(g * rows);
+      d.group += (int32_t)(g * count);
+      descs[(size_t)g * nterms + j] = d;
+    }
+    for (size_t i = 0; i < count; ++i) {
+      GroupDesc gd = hg[i];
+      gd.tile_begin += (int32_t)(g * rows); gd.tile_end += (int32_t)(g * rows);
+      gd.term_begin += (int32_t)(g * nterms); gd.term_end += (int32_t)(g * nterms);
+      groups[(size_t)g * count + i] = gd;
+    }
+  }
+  HIPCHK(cached_malloc(reinterpret_cast<void **>(&b->d_kprobs), std::max<size_t>(1, descs.size()) * sizeof(ProblemDesc), b->device));
+  HIPCHK(cached_malloc(reinterpret_cast<void **>(&b->d_kgroups), groups.size() * sizeof(GroupDesc), b->device));
+  HIPCHK(cached_malloc(reinterpret_cast<void **>(&b->d_krows), std::max<size_t>(1, (size_t)G * rows) * kAccSlots * sizeof(double), b->device));
+  if (!descs.empty()) HIPCHK(hipMemcpyAsync(b->d_kprobs, descs.data(), descs.size() * sizeof(ProblemDesc), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_kgroups, groups.data(), groups.size() * sizeof(GroupDesc), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemsetAsync(b->d_krows, 0, std::max<size_t>(1, (size_t)G * rows) * kAccSlots * sizeof(double), b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));  // (the host vectors go out of scope)
+  b->kp_G = G;
+  return EA_OK;
+}
 
 static int kposes_reserve(ea_batch *b, int K) {
   const size_t count = b->probs.size();
@@ -1264,6 +1322,7 @@ extern "C" int ea_batch_set_poses(ea_batch *b, int K, const double *q, const dou
   if (rc != EA_OK) return rc;
   b->kp_K = 0;
   if ((rc = kposes_reserve(b, K)) != EA_OK) return rc;
+  if ((rc = kposes_tables(b, kposes_group(b, K))) != EA_OK) return rc;
   const size_t n = (size_t)K * b->probs.size();
   // (the previous upload out of the same staging block has been consumed: every call below ends with its pose kernel
   // enqueued behind the copy, and the evaluations that follow are synchronised before they return)
@@ -1279,102 +1338,53 @@ extern "C" int ea_batch_set_poses(ea_batch *b, int K, const double *q, const dou
   return EA_OK;
 }
 
-static int launch_eval_at(ea_batch *b, const PoseState *poses, double *rows) {
-  HIPCHK(launch_eval_fused(b->dtype, b->ppt, b->nt, b->any_variant, b->d_probs, b->nterms, b->chunk, b->max_chunks,
-                           b->xcd_remap, poses, rows, b->lds_bytes, b->wide, b->terms_are_groups, b->buffer_loads, b->img32,
-                           b->x0, b->y0, b->z0, b->n0, b->stream));
+// the K evaluations of the resident poses on the batch's stream, G poses per launch pair, results into dv_kout[k * count + i]
+static int enqueue_resident_poses(ea_batch *b, int K, bool folds = true) {
+  const int count = (int)b->probs.size(), G = b->kp_G;
+  for (int start = 0; start < K; start += G) {
+    const int g = std::min(G, K - start);
+    HIPCHK(launch_eval_fused(b->dtype, b->ppt, b->nt, b->any_variant, b->d_kprobs, g * b->nterms, b->chunk, b->max_chunks,
+                             b->xcd_remap, b->d_kposes + (size_t)start * count, b->d_krows, b->lds_bytes, b->wide,
+                             b->terms_are_groups, b->buffer_loads, b->img32, b->x0, b->y0, b->z0, b->n0, b->stream));
+    if (folds) HIPCHK(launch_reduce(b->d_kgroups, g * count, b->d_krows, b->dv_kout + (size_t)start * count, b->stream));
+  }
   return EA_OK;
 }
-
-// the K evaluations of the resident poses on the batch's stream, results into dv_kout[k * count + i]
-static hipError_t enqueue_resident_poses(ea_batch *b, int K) {
-  const size_t count = b->probs.size();
-  if (!kposes_can_ride(b) || K == 1) {
-    // evaluation -> fold, one pair per pose, in the summation order of ea_batch_eval
-    for (int k = 0; k < K; ++k) {
-      if (launch_eval_at(b, b->d_kposes + (size_t)k * count, b->d_partials) != EA_OK) return hipErrorUnknown;
-      const hipError_t e = launch_reduce(b->d_groups, (int)count, b->d_partials, b->dv_kout + (size_t)k * count, b->stream);
-      if (e != hipSuccess) return e;
-    }
-    return hipSuccess;
-  }
-  const size_t row_doubles = (size_t)b->tiles_cap * kAccSlots;
-  for (int k = 0; k < K; ++k) {
-    double *rows = b->d_bench_rows + row_doubles * (size_t)(k & 1);
-    const PoseState *poses = b->d_kposes + (size_t)k * count;
-    if (k == 0) {
-      if (launch_eval_at(b, poses, rows) != EA_OK) return hipErrorUnknown;
-    } else {
-      const hipError_t e = launch_eval_fold(b->dtype, b->ppt, b->nt, b->d_probs, b->nterms, b->chunk, b->max_chunks, b->xcd_remap, poses,
-                                            rows, b->buffer_loads, b->img32, b->x0, b->y0, b->z0, b->n0, b->d_groups,
-                                            b->d_bench_rows + row_doubles * (size_t)((k - 1) & 1),
-                                            b->dv_kout + (size_t)(k - 1) * count, b->stream);
-      if (e != hipSuccess) return e;
-    }
-  }
-  return launch_reduce_nt(b->nt, b->d_groups, (int)count, b->d_bench_rows + row_doubles * (size_t)((K - 1) & 1),
-                          b->dv_kout + (size_t)(K - 1) * count, b->stream);
-}
-
-static int bench_ring_ensure(ea_batch *b);
 
 extern "C" int ea_batch_eval_resident_poses(ea_batch *b, double *cost, double *JtJ, double *Jtr, int64_t *n_invalid) {
   if (!b) return fail(EA_ERR_INVALID_ARG, "NULL argument");
   int rc = batch_build(b);
   if (rc != EA_OK) return rc;
   const int K = b->kp_K;
-  if (K < 1) return fail(EA_ERR_STATE, "no poses resident (ea_batch_set_poses first; a change of the batch's problems drops them)");
+  if (K < 1 || b->kp_G < 1) return fail(EA_ERR_STATE, "no poses resident (ea_batch_set_poses first; a change of the batch's problems drops them)");
   const int count = (int)b->probs.size();
-  const bool ride = kposes_can_ride(b) && K > 1;
-  if (ride && (rc = bench_ring_ensure(b)) != EA_OK) return rc;
-  // K <= 2: the launches go out as they are; longer sequences are captured once per K and replayed -- a replay costs the
-  // host one call, the launches then execute back to back from the queue (enqueued one by one the host needs ~4 us per
-  // launch, more than a 5e4-point evaluation runs)
-  if (K > 2 && b->kp_graph_K != K) {
-    kposes_drop_graph(b);
-    HIPCHK(hipStreamSynchronize(b->stream));
-    HIPCHK(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
-    const hipError_t e = enqueue_resident_poses(b, K);
-    hipGraph_t graph = nullptr;
-    const hipError_t ee = hipStreamEndCapture(b->stream, &graph);
-    if (e != hipSuccess || ee != hipSuccess || !graph) {
-      if (graph) (void)hipGraphDestroy(graph);
-      return fail(EA_ERR_HIP, std::string("graph capture (resident poses): ") + hipGetErrorString(e != hipSuccess ? e : ee));
-    }
-    const hipError_t ei = hipGraphInstantiate(&b->kp_graph, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (ei != hipSuccess) { b->kp_graph = nullptr; return fail(EA_ERR_HIP, std::string("graph instantiate: ") + hipGetErrorString(ei)); }
-    b->kp_graph_K = K;
-  }
-  if (K > 2) {
-    HIPCHK(hipGraphLaunch(b->kp_graph, b->stream));
-  } else {
-    const hipError_t e = enqueue_resident_poses(b, K);
-    if (e != hipSuccess) return fail(EA_ERR_HIP, std::string("resident poses: ") + hipGetErrorString(e));
-  }
+  if ((rc = enqueue_resident_poses(b, K)) != EA_OK) return rc;
   HIPCHK(hipStreamSynchronize(b->stream));
   const size_t n = (size_t)K * (size_t)count;
   if (cost || JtJ || Jtr || n_invalid) unpack_eval_out(b->h_kout, (int)n, cost, JtJ, Jtr, n_invalid);
   return EA_OK;
 }
 
-// (ea_hip_dev.h) `reps` replays of the resident poses' graph between one event pair on the batch's stream: milliseconds
-// per replay, the device's own view of the K evaluations (what bench.py divides by K for the kernel's duration)
-extern "C" int ea_batch_bench_resident_poses(ea_batch *b, int reps, double *ms_per_replay) {
-  if (!b || !ms_per_replay || reps < 1) return fail(EA_ERR_INVALID_ARG, "bad argument");
-  int rc = ea_batch_eval_resident_poses(b, nullptr, nullptr, nullptr, nullptr);  // (captures on first use)
+// (ea_hip_dev.h) `reps` runs of the resident poses' launches between one event pair on the batch's stream: milliseconds
+// per run, the device's own view of the K evaluations; evaluations_only: without the fold launches (what bench.py divides
+// by the number of evaluation launches for the dominant kernel's duration); launches (nullable) = evaluation launches per run
+extern "C" int ea_batch_bench_resident_poses(ea_batch *b, int reps, int evaluations_only, double *ms_per_run, int *launches) {
+  if (!b || !ms_per_run || reps < 1) return fail(EA_ERR_INVALID_ARG, "bad argument");
+  int rc = ea_batch_eval_resident_poses(b, nullptr, nullptr, nullptr, nullptr);
   if (rc != EA_OK) return rc;
-  if (!b->kp_graph) return fail(EA_ERR_STATE, "sequences of fewer than three poses are not replayed from a graph");
   EventPair evp;
   HIPCHK(hipEventCreate(&evp.e0));
   HIPCHK(hipEventCreate(&evp.e1));
+  // (the stream is held while the runs are enqueued: the launches execute back to back from the queue)
+  HIPCHK(hipLaunchHostFunc(b->stream, [](void *) { std::this_thread::sleep_for(std::chrono::milliseconds(2)); }, nullptr));
   HIPCHK(hipEventRecord(evp.e0, b->stream));
-  for (int i = 0; i < reps; ++i) HIPCHK(hipGraphLaunch(b->kp_graph, b->stream));
+  for (int i = 0; i < reps; ++i) if ((rc = enqueue_resident_poses(b, b->kp_K, !evaluations_only)) != EA_OK) return rc;
   HIPCHK(hipEventRecord(evp.e1, b->stream));
   HIPCHK(hipEventSynchronize(evp.e1));
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, evp.e0, evp.e1));
-  *ms_per_replay = (double)ms / reps;
+  *ms_per_run = (double)ms / reps;
+  if (launches) *launches = (b->kp_K + b->kp_G - 1) / b->kp_G;
   return EA_OK;
 }
 
@@ -2133,6 +2143,7 @@ extern "C" int ea_batch_set_tuning(ea_batch *b, const char *key, int value) {
   else if (k == "solve_streams") { b->t_streams = value; return EA_OK; }
   else if (k == "rows_staged") { b->t_rows_staged = value; return EA_OK; }
   else if (k == "rows_nontemporal") { b->t_rows_nt = value; return EA_OK; }
+  else if (k == "poses_per_launch") { b->t_kp_G = value > 0 ? value : 0; b->kp_K = 0; return EA_OK; }  // (resident poses are dropped)
   else return fail(EA_ERR_INVALID_ARG, "unknown tuning key: " + k);
   b->built = false;
   return EA_OK;
@@ -2152,7 +2163,7 @@ extern "C" int ea_batch_get_info(const ea_batch *b, const char *key, int64_t *va
   else if (k == "dt_f32") *value = b->img32;
   else if (k == "num_points") { int64_t s = 0; for (auto *p : b->probs) s += p->n; *value = s; }
   else if (k == "num_rows") *value = b->total_rows;
-  else if (k == "poses_ride") *value = kposes_can_ride(b) ? 1 : 0;  // ea_batch_eval_poses takes the riding-fold form
+  else if (k == "poses_per_launch") *value = b->kp_G;  // G of the last ea_batch_set_poses (0: none resident)
   else return fail(EA_ERR_INVALID_ARG, "unknown info key: " + k);
   return EA_OK;
 }

@@ -52,9 +52,10 @@ int ea_batch_bench_rows(ea_batch *b, const double *q, const double *t, int corre
                         void *J_dev, int64_t capacity_rows, int warmup, int launches, double *ms_per_launch);
 /* the same for the fold kernel of ea_batch_eval, over the partial rows the last evaluation left */
 int ea_batch_bench_fold(ea_batch *b, int warmup, int launches, double *ms_per_launch);
-/* `reps` replays of the graph behind ea_batch_eval_resident_poses between one event pair on the batch's stream:
- * milliseconds per replay of the K resident poses (K >= 3) */
-int ea_batch_bench_resident_poses(ea_batch *b, int reps, double *ms_per_replay);
+/* `reps` runs of the launches behind ea_batch_eval_resident_poses between one event pair on the batch's stream (held while
+ * they are enqueued): milliseconds per run of the K resident poses; evaluations_only: the fold launches left out;
+ * launches (nullable): evaluation launches per run */
+int ea_batch_bench_resident_poses(ea_batch *b, int reps, int evaluations_only, double *ms_per_run, int *launches);
 /* the floor of the launch mechanism: a hipGraph of `nodes` EMPTY kernels of grid x block threads replayed between one event
  * pair, milliseconds per node (best of four replays after the uploading one) */
 int ea_bench_graph_floor(int device, int nodes, int grid, int block, double *ms_per_node);

@@ -299,15 +299,16 @@ int ea_batch_solve(ea_batch *b, const ea_options *opt, double *q, double *t,
                    ea_summary *summaries);
 
 /* K evaluations of every problem of the batch at K DIFFERENT poses, one call -- what a caller that runs its own optimiser,
- * a line search or a cost-surface probe asks of the evaluator: ceres::Problem::Evaluate once per pose (the reference's own
- * call of it: src/SolveEA.cpp:241).  q: K x count x 4, t: K x count x 3 (pose k of problem i at [k * count + i]); outputs in
- * the layout of ea_batch_eval with the same leading index: cost K x count, JtJ K x count x 36, Jtr K x count x 6, n_invalid
- * K x count; any of them may be NULL.  The K evaluations are K launches + 1 replayed from one hipGraph (captured once per K
- * and batch), the fold of evaluation k-1 riding in the launch of evaluation k, the results folded straight into pinned
- * host memory, ONE synchronisation: 3-5 us per evaluation of a 5e4-point pair against ~30 us through ea_batch_eval.
- * Every evaluation runs its per-point kernel and its fold in full.  The folds of 256-thread launches sum in another
- * order than ea_batch_eval's (equal to rounding); batches with variant functors, shared-pose terms, LDS staging or
- * "wide_accumulate" take the plain evaluation + fold pair per pose (ea_batch_eval's summation order). */
+ * a line search, multi-start or a cost-surface probe asks of the evaluator: ceres::Problem::Evaluate once per pose (the
+ * reference's own call of it: src/SolveEA.cpp:241).  q: K x count x 4, t: K x count x 3 (pose k of problem i at
+ * [k * count + i]); outputs in the layout of ea_batch_eval with the same leading index: cost K x count, JtJ K x count x 36,
+ * Jtr K x count x 6, n_invalid K x count; any of them may be NULL.  Independent evaluations do not queue up behind each
+ * other: the pose is a batch dimension of the launch -- G poses per evaluation launch (grid = chunks x G x terms, every
+ * (point, pose) pair through the whole per-point arithmetic) and one fold launch for their partial rows, ceil(K / G) such
+ * pairs, the results folded straight into pinned host memory, ONE synchronisation: well under 1 us per evaluation of a
+ * 5e4-point pair from a few dozen poses on, against ~30 us through ea_batch_eval.  The sums of pose k are those
+ * ea_batch_eval returns at pose k (same partial rows, same summation order; the pose-dependent constants are built on the
+ * device, so the last bits may differ).  Every kind of batch is covered (variant functors, shared-pose terms, LDS staging). */
 int ea_batch_eval_poses(ea_batch *b, int K, const double *q, const double *t, double *cost, double *JtJ, double *Jtr,
                         int64_t *n_invalid);
 /* The same in two halves, for a caller that evaluates the same poses again (or wants the upload off its critical path):
@@ -345,8 +346,11 @@ int ea_eval_rows_device(ea_problem *p, const double q[4], const double t[3], int
 
 /* ---- tuning ---------------------------------------------------------------------------- */
 /* tuning knobs: key in {"lds_bytes", "points_per_thread", "use_lds", "xcd_remap", "threads", "buffer_loads",
- * "solve_streams", "rows_staged", "rows_nontemporal", "wide_accumulate"};
+ * "solve_streams", "rows_staged", "rows_nontemporal", "wide_accumulate", "dt_f32", "poses_per_launch"};
  * value < 0 restores the default.
+ * "dt_f32" = 0: an fp64 batch reads its fp64 images even where a float32 mirror holds them exactly (default: the mirror
+ * when every term has one; results are bit-identical either way).  "poses_per_launch" = g > 0 caps the poses one
+ * evaluation launch of ea_batch_eval_poses covers (default: enough to fill the chip, ~32k workgroups).
  * "wide_accumulate" = 1: an fp32 batch sums in fp64 from a lane's sum of <= points_per_thread products on (default: a
  * lane's and a wavefront's sums are fp32, everything above fp64).  Plain functor on the L2 path; ignored for fp64
  * batches, variant functors and the LDS-staged form (ea_batch_get_info "wide_accumulate" reports what is in effect).

@@ -2,10 +2,13 @@
 DIFFERENT poses in one call (what K calls of ceres::Problem::Evaluate give, src/SolveEA.cpp:241), against the CPU oracle at
 EACH of the K poses and against ea_batch_eval pose by pose.
 
+The pose is a batch dimension of the launch: G poses per evaluation launch (the descriptor table replicated G times, copy g
+owning the partial rows and the pose slot of pose g) + one fold launch, ceil(K / G) such pairs.
+
 Tolerances: fp64 1e-11 / fp32 1e-4 relative against the oracle (the bars of test_gpu_shapes.py); against ea_batch_eval
-1e-13 (fp64) / 1e-6 (fp32) relative -- the riding folds sum the same partial rows in another fixed order, and the pose
-constants are built on the device (make_pose_state in a kernel) instead of on the host (same formulas, fused
-multiply-adds placed by another compiler); a replay of the same poses must land on the same bits."""
+1e-13 (fp64) / 1e-6 (fp32) relative -- the same partial rows in the same summation order, but the pose constants are built
+on the device (make_pose_state in a kernel) instead of on the host (same formulas, fused multiply-adds placed by another
+compiler); a second run of the same poses must land on the same bits."""
 import numpy as np
 import pytest
 
@@ -64,6 +67,12 @@ def test_k_poses_match_the_oracle_at_every_pose(hip, oracle, dtype_name, tol, to
             # resident poses: a second run of the same K poses lands on the same bits, without a new upload
             again = B.eval_resident_poses()
             assert all(np.array_equal(again[f], got[f]) for f in ("cost", "JtJ", "Jtr", "n_invalid")), K
+            # ... and so does any split of the K poses over evaluation launches (G poses per launch: 1, 3, K)
+            for g in (1, 3, 0):
+                B.set_tuning("poses_per_launch", g)
+                split = B.eval_poses(q, t)
+                assert B.info("poses_per_launch") == (min(g, K) if g else K), (K, g)
+                assert all(np.array_equal(split[f], got[f]) for f in ("cost", "JtJ", "Jtr", "n_invalid")), (K, g)
         # every launch shape the batch can resolve to
         q, t = _poses(rng, 5, len(probs))
         first = None
