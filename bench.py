@@ -517,6 +517,7 @@ def main():
                 "evaluation_launches_in_timed_region": launches, "poses_per_launch": poses_launch,
                 "algorithmic_bytes_per_launch": bytes_launch, "algorithmic_bytes_per_evaluation": bytes_eval,
                 "launch_floor_ms": floor_ms,
+                # (what the launch mechanism alone would allow this grid; above 1 it has stopped being the bound)
                 "frac_ceiling_at_floor": (bytes_launch / (floor_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if floor_ms else None,
                 # the same kernel with ONE pose per launch (what an LM iteration launches; rounds 1-2's headline kernel):
                 # a launch of 196 workgroups is bounded by the launch mechanism, not by the chip
@@ -763,6 +764,18 @@ def main():
             res = {"evals_per_s": npts / (us_step * 1e-6), "us_per_step": us_step, "us_per_step_serial_launches": us_serial, "kernel_us": msk * 1e3,
                    "roofline_frac": by / (msk * 1e-3) / 1e9 / HBM_PEAK_GBS, "image_texel_bytes_read": 4 if Bx.info("dt_f32") else esz, "points": int(npts),
                    "point_order_tile_px": Ps[0].point_order}
+            try:  # the product call for independent evaluations: K different poses per problem, the pose a batch dimension of the launch
+                Kp = 8
+                rngp = np.random.default_rng(9)
+                Qp = np.stack([Q] * Kp); Tp = np.stack([T + rngp.uniform(-0.005, 0.005, size=T.shape) for _ in range(Kp)])
+                Bx.set_poses(Qp, Tp)
+                ms_run, nl = min(Bx.bench_resident_poses(3) for _ in range(2))
+                ms_ev, _ = min(Bx.bench_resident_poses(3, evaluations_only=True) for _ in range(2))
+                res["k_poses"] = {"K": Kp, "evaluation_launches": nl, "us_per_evaluation": ms_run / Kp * 1e3, "evals_per_s": npts * Kp / (ms_run * 1e-3),
+                                  "kernel_us_per_launch": ms_ev / nl * 1e3, "roofline_frac": by * Kp / (ms_ev * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                Bx.bench_eval(Q, T, 0, 1, kernel_pass=False)
+            except capi.EAError as e:
+                res["k_poses"] = {"error": str(e)}
             if valu_key:
                 res["valu_issue"] = valu_issue(valu_key, msk)
             if traffic_key:   # HBM-side bytes per launch from the PMC passes (profiles/pmc_traffic.json) over the live kernel time

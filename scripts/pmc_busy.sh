@@ -9,6 +9,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_busy; mkdir -p $O
 for w in ${WORKLOADS:-c2 c5}; do
   for pass in "SQ_BUSY_CYCLES SQ_WAVES" "GRBM_GUI_ACTIVE"; do
     tag=$(echo $pass | cut -d' ' -f1)
+    rm -rf $O/${w}_$tag
     (cd /tmp && timeout -k 10 200 rocprofv3 --pmc $pass -d $O/${w}_$tag -o p --output-format csv -- python3 $R/bench.py --workload $w --steps 200 --warmup 20 --no-extras --no-cpu-baseline > $O/${w}_$tag.log 2>&1)
     rc=$?; echo "$w $tag rc=$rc"
     if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "timed out: stopping"; exit 1; fi
@@ -25,13 +26,16 @@ for w in ("c2", "c5"):
         by = {}
         for f in glob.glob("%s/%s_%s/**/*counter_collection.csv" % (out, w, tag), recursive=True):
             for r in csv.DictReader(open(f)):
-                if r["Counter_Name"] in ctrs and "ea_eval_fold_kernel" in r["Kernel_Name"]:
-                    by.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                # the one-pose launch of the evaluation kernel (an LM iteration's launch; the smallest grid of that kernel in the run)
+                if r["Counter_Name"] in ctrs and "ea_eval_fused_kernel" in r["Kernel_Name"]:
+                    by.setdefault((r["Counter_Name"], int(r["Grid_Size"])), []).append(float(r["Counter_Value"]))
+        small = min((g for (_, g) in by), default=None)
+        by = {c: v for (c, g), v in by.items() if g == small}
         for k, v in by.items():
             med[k] = statistics.median(v)
             print(w, k, "dispatches", len(v), "median", med[k], "min", min(v), "max", max(v))
     if "SQ_BUSY_CYCLES" in med:
-        res[w] = {"kernel": "ea_eval_fold_kernel", "sq_busy_cycles_per_launch": med["SQ_BUSY_CYCLES"], "sq_waves_per_launch": med.get("SQ_WAVES"),
+        res[w] = {"kernel": "ea_eval_fused_kernel, one pose per launch", "sq_busy_cycles_per_launch": med["SQ_BUSY_CYCLES"], "sq_waves_per_launch": med.get("SQ_WAVES"),
                   "kernel_ms_from_counters": med["SQ_BUSY_CYCLES"] / 32.0 / CLOCK * 1e3,
                   "grbm_gui_active_per_launch": med.get("GRBM_GUI_ACTIVE"),
                   "kernel_ms_from_grbm_gui_active": (med["GRBM_GUI_ACTIVE"] / 8.0 / CLOCK * 1e3) if "GRBM_GUI_ACTIVE" in med else None,

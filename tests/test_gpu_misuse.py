@@ -2,7 +2,7 @@
 with a live handle and one bad argument -- NULL data, zero / negative / overflowing extents, unknown enum values, NaN
 thresholds and intrinsics, invalid ceres::Solver::Options (Options::IsValid), stale members.  Each call must return an
 error code (or behave as documented) and leave the handle evaluating the reference problem to the same bits.  The cases
-live in scripts/archive/misuse_probe.py, which also runs each of them in a forked child to report crashes (none)."""
+live in scripts/misuse_probe.py, which also runs each of them in a forked child to report crashes (none)."""
 import importlib.util
 import os
 
