@@ -99,6 +99,7 @@ def counter_busy(workload_key, kernel_ms):
     the shader clock.  Reported beside the live figure with their ratio."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_busy.json")))[workload_key]
+        d = {k: v for k, v in d.items() if k != "note"}
     except Exception:
         return None
     out = dict(d)
@@ -512,8 +513,9 @@ def main():
             traffic = None
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "ea_eval_fused_kernel<%s>" % ("double" if esize == 8 else "float"),
+                "kernel": ("ea_eval_poses_kernel<%s>" if pipelined else "ea_eval_fused_kernel<%s>") % ("double" if esize == 8 else "float"),
                 "kernel_ms": ms_kernel,
+                "counter_busy": counter_busy("%s_poses_%d" % (args.workload, args.steps), ms_kernel) if pipelined else None,
                 "evaluation_launches_in_timed_region": launches, "poses_per_launch": poses_launch,
                 "algorithmic_bytes_per_launch": bytes_launch, "algorithmic_bytes_per_evaluation": bytes_eval,
                 "launch_floor_ms": floor_ms,

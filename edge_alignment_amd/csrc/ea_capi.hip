@@ -30,6 +30,10 @@ hipError_t launch_eval_fused(int dtype, int ppt, int nt, int variant, const Prob
                              int max_chunks, int xcd_remap, const PoseState *poses, double *partials,
                              int lds_bytes, int wide, int terms_are_groups, int buffer_loads, int img32, const void *x0, const void *y0,
                              const void *z0, int n0, hipStream_t stream);
+hipError_t launch_eval_poses(int dtype, int ppt, int nt, int variant, const ProblemDesc *probs, int nterms, int chunk,
+                             int max_chunks, int xcd_remap, const PoseState *poses, double *partials,
+                             int lds_bytes, int wide, int terms_are_groups, int buffer_loads, int img32, const void *x0, const void *y0,
+                             const void *z0, int n0, hipStream_t stream);
 hipError_t launch_pixel_cost(int dtype, const ProblemDesc *probs, int problem, int n, const PoseState *poses, void *partials,
                              hipStream_t stream);
 hipError_t launch_eval_rows(int dtype, int variant, int buffer_loads, int img32, int layout, int staged, const ProblemDesc *probs, int nterms,
@@ -1343,7 +1347,7 @@ static int enqueue_resident_poses(ea_batch *b, int K, bool folds = true) {
   const int count = (int)b->probs.size(), G = b->kp_G;
   for (int start = 0; start < K; start += G) {
     const int g = std::min(G, K - start);
-    HIPCHK(launch_eval_fused(b->dtype, b->ppt, b->nt, b->any_variant, b->d_kprobs, g * b->nterms, b->chunk, b->max_chunks,
+    HIPCHK(launch_eval_poses(b->dtype, b->ppt, b->nt, b->any_variant, b->d_kprobs, g * b->nterms, b->chunk, b->max_chunks,
                              b->xcd_remap, b->d_kposes + (size_t)start * count, b->d_krows, b->lds_bytes, b->wide,
                              b->terms_are_groups, b->buffer_loads, b->img32, b->x0, b->y0, b->z0, b->n0, b->stream));
     if (folds) HIPCHK(launch_reduce(b->d_kgroups, g * count, b->d_krows, b->dv_kout + (size_t)start * count, b->stream));

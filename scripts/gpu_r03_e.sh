@@ -14,7 +14,10 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_sharded -o k -- python3 $R/scripts/prof_sharded.py > $O/kt_sharded.log 2>&1; echo "kernel-trace sharded rc=$?"
 tail -3 $O/kt_sharded.log
 cd $R
-bash scripts/pmc_traffic_bench.sh > $O/pmc_traffic_bench.txt 2>&1; echo "pmc traffic rc=$?"; tail -12 $O/pmc_traffic_bench.txt
+STEPS=20 bash scripts/pmc_traffic_bench.sh > $O/pmc_traffic_bench.txt 2>&1; echo "pmc traffic (20 poses) rc=$?"
+STEPS=2000 bash scripts/pmc_traffic_bench.sh >> $O/pmc_traffic_bench.txt 2>&1; echo "pmc traffic (2000 poses) rc=$?"; grep -n "hbm_bytes_per_launch\|_poses_" $O/pmc_traffic_bench.txt | tail -12
+STEPS=20 bash scripts/pmc_busy.sh > $O/pmc_busy.txt 2>&1; echo "pmc busy (20) rc=$?"
+STEPS=2000 bash scripts/pmc_busy.sh >> $O/pmc_busy.txt 2>&1; echo "pmc busy (2000) rc=$?"; grep -n "kernel_ms_from_counters\|\"c[25]" $O/pmc_busy.txt | tail -16
 bash scripts/pmc_valu_refresh.sh > $O/pmc_valu_refresh.txt 2>&1; echo "pmc valu rc=$?"; tail -5 $O/pmc_valu_refresh.txt
 find $O -name "*kernel_stats.csv" | head; 
 for d in kt_c2_steps20 kt_c2 kt_c5 kt_sharded; do f=$(find $O/$d -name "*kernel_stats.csv" | head -1); echo "== $d"; head -8 $f | cut -c1-200; done

@@ -1,6 +1,6 @@
 #!/bin/bash
-# HBM-side traffic of the bench command's own dominant kernel -- the evaluation launch of G poses (ea_eval_fused_kernel with
-# the largest grid of the run; the same kernel's one-pose launches of the secondary measurements are left out) --:
+# HBM-side traffic of the bench command's own dominant kernel -- the evaluation launch of G poses (ea_eval_poses_kernel: the
+# evaluation kernel under the name its pose-batched launches carry; full launches = the largest grid of the run) --:
 # rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --workload W --steps S`, counters only.
 # bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request; guide, HBM section).
 cd /tmp && export TMPDIR=/tmp
@@ -28,7 +28,7 @@ for w in ("c2", "c5"):
                     by.setdefault((r["Kernel_Name"].split("(")[0][-60:], int(r["Grid_Size"])), []).append(float(r["Counter_Value"]))
         for k, v in sorted(by.items()):
             print(w, ctr, k, "dispatches", len(v), "median_KB", statistics.median(v), "min", min(v), "max", max(v))
-        fused = [k for k in by if "ea_eval_fused_kernel" in k[0]]
+        fused = [k for k in by if "ea_eval_poses_kernel" in k[0]]
         if fused:
             big = max(fused, key=lambda k: k[1])   # the launch of G poses: the largest grid of that kernel in the run
             med[ctr] = statistics.median(by[big])
@@ -36,9 +36,9 @@ for w in ("c2", "c5"):
     if "FETCH_SIZE" in med and "WRITE_SIZE" in med:
         res["%s_poses_%d" % (w, steps)] = {"hbm_bytes_per_launch": (2 * med["FETCH_SIZE"] + med["WRITE_SIZE"]) * 1024,
                                    "FETCH_SIZE_KB": med["FETCH_SIZE"], "WRITE_SIZE_KB": med["WRITE_SIZE"], "grid_size": med["grid"], "round": 3,
-                                   "note": "scripts/pmc_traffic_bench.sh: the bench command's own dominant kernel (ea_eval_fused_kernel, the launch of %d poses = the largest grid of the run), "
+                                   "note": "scripts/pmc_traffic_bench.sh: the bench command's own dominant kernel (ea_eval_poses_kernel: the launch of G poses, of %d in the timed region), "
                                            "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --steps %d, median over its launches; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024. "
                                            "The poses of one launch share the points and the image: the later ones find them in L2 / Infinity Cache, so the HBM-side bytes are far BELOW the algorithmic bytes (one pass per pose)" % (steps, steps)}
-json.dump(res, open(out + "/traffic_riding.json", "w"), indent=1)
+json.dump(res, open(out + "/traffic_poses_%d.json" % steps, "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY

@@ -38,7 +38,7 @@ def test_driver_command_prints_one_valid_line(hip):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-12
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
     # the dominant kernel is the evaluation launch of G poses: its bytes are G x one evaluation's
-    assert "ea_eval_fused_kernel" in r["kernel"] and r["evaluation_launches_in_timed_region"] == 1 and r["poses_per_launch"] == 20
+    assert "ea_eval_poses_kernel" in r["kernel"] and r["evaluation_launches_in_timed_region"] == 1 and r["poses_per_launch"] == 20
     assert abs(r["algorithmic_bytes_per_launch"] - 20 * r["algorithmic_bytes_per_evaluation"]) < 1 and r["algorithmic_bytes_per_evaluation"] == 3657600
     assert 2e-3 < r["kernel_ms"] < 0.2
     assert r["traffic"] is None or r["traffic"] / r["algorithmic_bytes_per_launch"] < 2.0
