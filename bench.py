@@ -327,18 +327,9 @@ def main():
     # The collectives of the measured modes are the library's own (include/ea_hip.h ea_comm_*: ncclAllGather /
     # ncclAllReduce from librccl on the library's stream); torch.distributed carries the rendezvous (the 128-byte id), the
     # max-over-ranks of the timed region and -- in a gloo rehearsal, where RCCL cannot hold two ranks on one GPU -- the
-    # exchanges themselves.  One rank: a one-rank communicator (created with the extras, not before the headline).
-    comm, comm_error = None, None
-    if multi and args.dist_backend == "nccl":
-        try:
-            comm = capi.Comm.from_process_group(device=local_rank)
-        except Exception as e:   # (the torch.distributed forms of the same exchanges take over; the line says so)
-            comm_error = repr(e)
-        ok = torch.tensor([0 if comm is None else 1], dtype=torch.int32, device=coll_dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0 and comm is not None:   # every rank or none
-            comm.close(); comm = None
-
+    # exchanges themselves.  One rank: a one-rank communicator.  Created below, with the extras and under their watchdog: a
+    # communicator meeting a real node for the first time must not stand between the process and its headline.
+    comm, comm_error = None, None   # (created with the extras, under their watchdog: after the headline is complete)
     # The barrier of the timed bracket.  Ranks of one node: an epoch barrier through shared memory (a few microseconds;
     # edge_alignment_amd/dist.py NodeBarrier) -- the closing barrier sits INSIDE the timed region, and a collective-based one
     # costs as much as the K = 20 steps it brackets.  Anything unexpected: torch.distributed.barrier().
@@ -619,6 +610,23 @@ def main():
     watchdog.daemon = True
     if not args.no_extras:
         watchdog.start()
+        leg[0] = "RCCL communicator (ea_comm_create)"
+        if multi and args.dist_backend == "nccl":
+            try:
+                comm = capi.Comm.from_process_group(device=local_rank)
+            except Exception as e:   # (the torch.distributed forms of the same exchanges take over; the line says so)
+                comm_error = repr(e)
+            ok = torch.tensor([0 if comm is None else 1], dtype=torch.int32, device=coll_dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and comm is not None:   # every rank or none
+                comm.close(); comm = None
+        elif not multi:
+            try:
+                comm = capi.Comm(capi.comm_unique_id(), 1, 0, device=local_rank)   # (N = 1: the same calls on a one-rank communicator)
+            except Exception as e:
+                comm_error = repr(e)
+        if comm_error:
+            extras["comm_error"] = comm_error
 
     if not args.no_extras:
         leg[0] = "LM iterations/s at 1e5 points"
@@ -640,13 +648,6 @@ def main():
         # language -- sees; the Python wrapper adds ~8 us per solve of ctypes marshalling, reported beside it
         lm_local = its / (lib_ms * 1e-3)
         # the one collective: all-gather of the solved poses (7 doubles + status per problem)
-        if comm is None and not multi:
-            try:
-                comm = capi.Comm(capi.comm_unique_id(), 1, 0, device=local_rank)   # (N = 1: the same calls on a one-rank communicator)
-            except Exception as e:
-                comm_error = repr(e)
-        if comm_error:
-            extras["comm_error"] = comm_error
         pg1 = ead.PoseGather(1, world, device=coll_dev if multi else "cpu", force_collective=multi, comm=comm)  # buffers allocated once, outside the clock
         pg1.gather([q], [t], [s["termination"]])
         tg = time.perf_counter()

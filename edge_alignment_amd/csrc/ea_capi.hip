@@ -43,6 +43,8 @@ hipError_t launch_eval_points(int dtype, const ProblemDesc *probs, int problem, 
                               double *r_out, double *J_out, int corrected, hipStream_t stream);
 hipError_t launch_reduce(const GroupDesc *groups, int count, const double *partials, EvalOut *out,
                          hipStream_t stream);
+hipError_t launch_reduce_done(const GroupDesc *groups, int count, const double *partials, EvalOut *out, unsigned int *counter,
+                              int *host_flag, int seq, hipStream_t stream);
 hipError_t launch_eval_fold(int dtype, int ppt, int nt, const ProblemDesc *probs, int nterms, int chunk, int max_chunks,
                             int xcd_remap, const PoseState *poses, double *partials, int buffer_loads, int img32, const void *x0,
                             const void *y0, const void *z0, int n0, const GroupDesc *groups, const double *prev_rows,
@@ -395,7 +397,9 @@ struct ea_batch {
   unsigned char *h_lm_block = nullptr;
   LMState *h_states = nullptr;
   LMTrace *h_traces = nullptr;
-  int *h_progress = nullptr;            // pinned, device-visible: [running x count | evaluations started x count | steps complete x count]
+  int *h_progress = nullptr;            // pinned, device-visible: [running x count | evaluations started x count | steps complete x count | done flag]
+  unsigned int *d_done_count = nullptr; // workgroups of the last fold of a synchronous evaluation that have delivered (ea_reduce_done_kernel)
+  int done_seq = 0;                     // the value the flag takes when the current call's results have all landed
   // tuning (-1 = heuristic)
   int t_lds_bytes = -1, t_ppt = -1, t_use_lds = -1, t_xcd = -1, t_nt = -1, t_streams = -1, t_variant = 0;
   int t_wide = 0, wide = 0;              // "wide_accumulate": an fp32 kernel sums in fp64 from the lane's sum on (plain functor, L2 path)
@@ -867,7 +871,8 @@ static void batch_free_device(ea_batch *b) {
   if (b->bench_e1) { (void)hipEventDestroy(b->bench_e1); b->bench_e1 = nullptr; }
   (void)hipFree(b->d_one_row); b->d_one_row = nullptr;
   cached_free(b->d_probs); cached_free(b->d_groups); cached_free(b->d_lm_block); cached_free(b->d_cold);
-  cached_free(b->d_partials); cached_free(b->d_out);
+  cached_free(b->d_partials); cached_free(b->d_out); cached_free(b->d_done_count);
+  b->d_done_count = nullptr;
   cached_host_free(b->h_lm_block); cached_host_free(b->h_out);
   cached_host_free(b->h_progress); cached_host_free(b->h_deliver);
   if (b->h_desc) cached_host_free(b->h_desc);
@@ -905,7 +910,10 @@ extern "C" int ea_batch_create(ea_batch **out, ea_problem *const *problems, int 
   if (e == hipSuccess) e = cached_host_malloc(reinterpret_cast<void **>(&b->h_lm_block), lm_bytes, hipHostMallocDefault, b->device);
   if (e == hipSuccess) e = cached_host_malloc(reinterpret_cast<void **>(&b->h_out), c * sizeof(EvalOut), hipHostMallocMapped, b->device);
   if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&b->dv_out), b->h_out, 0);
-  if (e == hipSuccess) e = cached_host_malloc(reinterpret_cast<void **>(&b->h_progress), 3 * c * sizeof(int), hipHostMallocMapped, b->device);
+  if (e == hipSuccess) e = cached_host_malloc(reinterpret_cast<void **>(&b->h_progress), (3 * c + 1) * sizeof(int), hipHostMallocMapped, b->device);
+  if (e == hipSuccess) e = cached_malloc(reinterpret_cast<void **>(&b->d_done_count), 256, b->device);
+  if (e == hipSuccess) e = hipMemsetAsync(b->d_done_count, 0, 256, b->stream);
+  if (e == hipSuccess) b->h_progress[3 * c] = 0;
   if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&b->d_progress), b->h_progress, 0);
   if (e == hipSuccess) e = cached_host_malloc(reinterpret_cast<void **>(&b->h_deliver), c * (sizeof(LMState) + sizeof(LMTrace)), hipHostMallocMapped, b->device);
   if (e == hipSuccess) {
@@ -1218,6 +1226,28 @@ static void unpack_eval_out(const ea_batch *b, int count, double *cost, double *
   unpack_eval_out(b->h_out, count, cost, JtJ, Jtr, n_invalid);
 }
 
+// The last fold of a synchronous evaluation raises a flag in pinned host memory once every result has landed there
+// (ea_reduce_done_kernel); the host polls it instead of waiting for the stream's completion signal, which arrives ~10 us
+// later.  The poll is bounded: should the flag not show up (it always has), the stream is synchronised the classic way --
+// the results are complete then, and a device fault surfaces as the error it is.
+static hipError_t launch_last_fold(ea_batch *b, const GroupDesc *groups, int count, const double *rows, EvalOut *out) {
+  const size_t c = b->probs.size();
+  b->done_seq = b->done_seq == 0x7fffffff ? 1 : b->done_seq + 1;
+  return launch_reduce_done(groups, count, rows, out, b->d_done_count, b->d_progress + 3 * c, b->done_seq, b->stream);
+}
+
+static int wait_results(ea_batch *b) {
+  const size_t c = b->probs.size();
+  SpinWait wait(2000.0);
+  while (__atomic_load_n(&b->h_progress[3 * c], __ATOMIC_ACQUIRE) != b->done_seq) {
+    if (wait.poll()) {
+      HIPCHK(hipStreamSynchronize(b->stream));
+      return EA_OK;
+    }
+  }
+  return EA_OK;
+}
+
 extern "C" int ea_batch_eval(ea_batch *b, const double *q, const double *t, double *cost, double *JtJ,
                              double *Jtr, int64_t *n_invalid) {
   if (!b || !q || !t) return fail(EA_ERR_INVALID_ARG, "NULL argument");
@@ -1230,8 +1260,8 @@ extern "C" int ea_batch_eval(ea_batch *b, const double *q, const double *t, doub
   if (rc != EA_OK) return rc;
   // the fold writes its 256 bytes per problem straight into pinned host memory: no device-to-host copy behind it (-6 us
   // of a 31 us call); the kernel's end makes them visible
-  HIPCHK(launch_reduce(b->d_groups, count, b->d_partials, b->dv_out, b->stream));
-  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(launch_last_fold(b, b->d_groups, count, b->d_partials, b->dv_out));
+  if ((rc = wait_results(b)) != EA_OK) return rc;
   unpack_eval_out(b, count, cost, JtJ, Jtr, n_invalid);
   return EA_OK;
 }
@@ -1343,14 +1373,16 @@ extern "C" int ea_batch_set_poses(ea_batch *b, int K, const double *q, const dou
 }
 
 // the K evaluations of the resident poses on the batch's stream, G poses per launch pair, results into dv_kout[k * count + i]
-static int enqueue_resident_poses(ea_batch *b, int K, bool folds = true) {
+static int enqueue_resident_poses(ea_batch *b, int K, bool folds = true, bool flag_last = false) {
   const int count = (int)b->probs.size(), G = b->kp_G;
   for (int start = 0; start < K; start += G) {
     const int g = std::min(G, K - start);
     HIPCHK(launch_eval_poses(b->dtype, b->ppt, b->nt, b->any_variant, b->d_kprobs, g * b->nterms, b->chunk, b->max_chunks,
                              b->xcd_remap, b->d_kposes + (size_t)start * count, b->d_krows, b->lds_bytes, b->wide,
                              b->terms_are_groups, b->buffer_loads, b->img32, b->x0, b->y0, b->z0, b->n0, b->stream));
-    if (folds) HIPCHK(launch_reduce(b->d_kgroups, g * count, b->d_krows, b->dv_kout + (size_t)start * count, b->stream));
+    if (!folds) continue;
+    if (flag_last && start + g >= K) HIPCHK(launch_last_fold(b, b->d_kgroups, g * count, b->d_krows, b->dv_kout + (size_t)start * count));
+    else HIPCHK(launch_reduce(b->d_kgroups, g * count, b->d_krows, b->dv_kout + (size_t)start * count, b->stream));
   }
   return EA_OK;
 }
@@ -1362,8 +1394,8 @@ extern "C" int ea_batch_eval_resident_poses(ea_batch *b, double *cost, double *J
   const int K = b->kp_K;
   if (K < 1 || b->kp_G < 1) return fail(EA_ERR_STATE, "no poses resident (ea_batch_set_poses first; a change of the batch's problems drops them)");
   const int count = (int)b->probs.size();
-  if ((rc = enqueue_resident_poses(b, K)) != EA_OK) return rc;
-  HIPCHK(hipStreamSynchronize(b->stream));
+  if ((rc = enqueue_resident_poses(b, K, true, true)) != EA_OK) return rc;
+  if ((rc = wait_results(b)) != EA_OK) return rc;
   const size_t n = (size_t)K * (size_t)count;
   if (cost || JtJ || Jtr || n_invalid) unpack_eval_out(b->h_kout, (int)n, cost, JtJ, Jtr, n_invalid);
   return EA_OK;

@@ -1493,6 +1493,30 @@ __global__ __launch_bounds__(kFoldThreads) void ea_reduce_kernel(const GroupDesc
   reduce_tiles<kFoldThreads, 4>(partials, gd.tile_begin, gd.tile_end, s_part, out[blockIdx.x].acc);
 }
 
+// The same fold for the synchronous evaluations (ea_batch_eval, ea_batch_eval_poses), whose results go straight into pinned
+// host memory: the workgroup that finishes last raises a flag there, so that the host can poll for "every result has
+// landed" instead of waiting for the stream's completion signal (~10 us later).  Every workgroup's 32 result words are
+// stored by its wavefront 0; lane 0 of that wavefront makes them visible system-wide (the fence waits for the wavefront's
+// stores), then counts itself in; the workgroup that completes the count re-arms the counter and raises the flag to
+// `seq` (release, system scope).  Launches on one stream execute in order: earlier folds of the same call are complete.
+__global__ __launch_bounds__(kFoldThreads) void ea_reduce_done_kernel(const GroupDesc *__restrict__ groups,
+                                                                       const double *__restrict__ partials,
+                                                                       EvalOut *__restrict__ out, unsigned int *__restrict__ counter,
+                                                                       int *__restrict__ host_flag, int seq) {
+  __shared__ __align__(16) double s_part[reduce_tiles_lds<kFoldThreads>()];
+  const GroupDesc gd = groups[blockIdx.x];
+  reduce_tiles<kFoldThreads, 4>(partials, gd.tile_begin, gd.tile_end, s_part, out[blockIdx.x].acc);
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    const unsigned int prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == gridDim.x - 1) {
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 // The fold as a 256-thread workgroup sums it when it rides in an evaluation launch (ea_eval_fold_kernel below; 8 rows in
 // flight per lane keep the riding workgroup inside the evaluation's register budget): closes a pipelined sequence.
 __global__ __launch_bounds__(kLmThreads) void ea_reduce256_kernel(const GroupDesc *__restrict__ groups,
@@ -2004,6 +2028,13 @@ hipError_t launch_reduce(const GroupDesc *groups, int count, const double *parti
                          hipStream_t stream) {
   if (count <= 0) return hipSuccess;
   hipLaunchKernelGGL(ea_reduce_kernel, dim3(count), dim3(kFoldThreads), 0, stream, groups, partials, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce_done(const GroupDesc *groups, int count, const double *partials, EvalOut *out, unsigned int *counter,
+                              int *host_flag, int seq, hipStream_t stream) {
+  if (count <= 0) return hipErrorInvalidValue;  // (somebody has to raise the flag)
+  hipLaunchKernelGGL(ea_reduce_done_kernel, dim3(count), dim3(kFoldThreads), 0, stream, groups, partials, out, counter, host_flag, seq);
   return hipGetLastError();
 }
 
