@@ -209,3 +209,33 @@ def test_argument_checks_and_state(hip):
             assert o["cost"].shape == (K, 1) and np.all(o["cost"] == o["cost"][0]) and o["cost"][0, 0] > 0
     finally:
         B.close(); P.close()
+
+
+def test_many_problems_times_many_poses(hip):
+    """40 small problems x 300 poses: one launch of 12 000 (problem, pose) columns -- inside the grid's y limit -- and the same
+    again split over launches of 7 poses; spot-checked against ea_batch_eval"""
+    base = synth.make_problem(60, 80, 900, 12, 3, 65.0, 65.0, 39.5, 29.5, planted_q=synth.quat_from_axis_angle([1, 2, 3], 0.01),
+                              planted_t=(0.004, -0.002, 0.006), normalize=True)
+    rng = np.random.default_rng(3)
+    Ps = []
+    for i in range(40):
+        P = hip.Problem(*base["K"], dtype=hip.EA_F64)
+        P.set_points(base["xyz"][rng.choice(900, int(rng.integers(1, 900)), replace=False)]); P.set_dt_grid(base["grid"])
+        Ps.append(P)
+    B = hip.Batch(Ps)
+    try:
+        K = 300
+        q, t = _poses(rng, K, 40, scale=0.3)
+        got = B.eval_poses(q, t)
+        assert B.info("poses_per_launch") == K
+        for k in (0, 137, 299):
+            ref = B.eval(q[k], t[k])
+            assert _rel(got["cost"][k], ref["cost"]) <= 1e-13 and _rel(got["JtJ"][k], ref["JtJ"]) <= 1e-12
+            assert np.array_equal(got["n_invalid"][k], ref["n_invalid"])
+        B.set_tuning("poses_per_launch", 7)
+        split = B.eval_poses(q, t)
+        assert all(np.array_equal(split[f], got[f]) for f in ("cost", "JtJ", "Jtr", "n_invalid"))
+    finally:
+        B.close()
+        for P in Ps:
+            P.close()
