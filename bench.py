@@ -62,7 +62,7 @@ SIMDS = 256 * 4                # MI355X: 256 CUs x 4 SIMDs
 VALU_PEAK_IPS = SIMDS * 2.4e9 / 2.0  # one wave64 vector instruction per 2 cycles and SIMD at 2.4 GHz (guide: v_fma_f32 2 cyc)
 
 
-def valu_issue(workload_key, kernel_ms):
+def valu_issue(workload_key, kernel_ms, insts=None, source=None):
     """Second bound of the same kernel: vector-instruction issue.  SQ_INSTS_VALU per launch comes from
     the committed PMC pass (profiles/pmc_valu.json), the duration is the live one.  `frac` is against the 2-cycle issue
     peak of the guide; `frac_of_measured_ceiling` is against what this machine sustains on the kernel's mix of instruction
@@ -72,13 +72,13 @@ def valu_issue(workload_key, kernel_ms):
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_valu.json")))[workload_key]
     except Exception:
         return None
-    n = d["sq_insts_valu_per_launch"]
+    n = insts if insts else d["sq_insts_valu_per_launch"]   # (insts: counted on the launch itself, e.g. a pose-batched one)
     achieved = n / (kernel_ms * 1e-3)
     c = d.get("cheap_class_fraction_static", 0.5)
     ceiling = SIMDS / ((c * 1.05 + (1.0 - c) * 1.75) * 1e-9)
     return {"bound": "valu_issue", "achieved": achieved, "peak": VALU_PEAK_IPS, "unit": "wave64 instr/s",
             "frac": achieved / VALU_PEAK_IPS, "measured_ceiling": ceiling, "frac_of_measured_ceiling": achieved / ceiling,
-            "sq_insts_valu_per_launch": n, "source": "profiles/pmc_valu.json (rocprofv3 --pmc SQ_INSTS_VALU) / live kernel time"}
+            "sq_insts_valu_per_launch": n, "source": source or "profiles/pmc_valu.json (rocprofv3 --pmc SQ_INSTS_VALU) / live kernel time"}
 
 
 def step_poses(K, seed):
@@ -489,7 +489,8 @@ def main():
     achieved = bytes_launch / (ms_kernel * 1e-3) / 1e9
     try:   # the launch mechanism's floor for THIS grid: an empty kernel of as many workgroups in a replayed graph
         floor_ms = capi.graph_floor_ms(local_rank, nodes=max(8, min(nk, 20000 // max(1, int(poses_launch or 1)))),
-                                       grid=max(1, int(B.info("num_tiles") * (poses_launch or 1))), block=int(B.info("threads")))
+                                       grid=max(1, int((B.info("poses_tiles") if pipelined else B.info("num_tiles")) * (poses_launch or 1))),
+                                       block=int(B.info("poses_threads") if pipelined else B.info("threads")))
         floor_one_ms = capi.graph_floor_ms(local_rank, nodes=nk, grid=max(1, int(B.info("num_tiles"))), block=int(B.info("threads")))
     except capi.EAError:
         floor_ms = floor_one_ms = None
@@ -508,6 +509,8 @@ def main():
                 "kernel_ms": ms_kernel,
                 "counter_busy": counter_busy("%s_poses_%d" % (args.workload, args.steps), ms_kernel) if pipelined else None,
                 "evaluation_launches_in_timed_region": launches, "poses_per_launch": poses_launch,
+                "launch_shape": {"threads": int(B.info("poses_threads")), "points_per_thread": int(B.info("poses_points_per_thread")),
+                                 "workgroups_per_pose": int(B.info("poses_tiles"))} if pipelined else None,
                 "algorithmic_bytes_per_launch": bytes_launch, "algorithmic_bytes_per_evaluation": bytes_eval,
                 "launch_floor_ms": floor_ms,
                 # (what the launch mechanism alone would allow this grid; above 1 it has stopped being the bound)
@@ -525,7 +528,20 @@ def main():
                 # (fp64 over a float32-stored image, when every texel is float-representable: same doubles, 4-byte texels read;
                 # achieved / frac stay on the algorithmic 8-byte definition)
                 "image_texel_bytes_read": 4 if B.info("dt_f32") else esize,
-                "secondary": valu_issue(args.workload, ms_kernel / max(1.0, float(poses_launch or 1)))}
+                "secondary": None}
+    if pipelined:
+        cb = roofline["counter_busy"] or {}
+        if cb.get("sq_insts_valu_per_launch") and cb.get("grid_size"):
+            # instructions counted on a full launch of the committed PMC pass -> per pose -> this run's average launch.
+            # (one problem per batch here: the grid is 8 * ceil(workgroups per pose / 8) columns x poses x threads)
+            cols = -(-int(B.info("poses_tiles")) // 8) * 8
+            poses_pmc = cb["grid_size"] / float(cols * int(B.info("poses_threads")))
+            roofline["secondary"] = valu_issue(args.workload, ms_kernel, insts=cb["sq_insts_valu_per_launch"] / poses_pmc * poses_launch,
+                                               source="profiles/pmc_busy.json (rocprofv3 --pmc SQ_INSTS_VALU on ea_eval_poses_kernel) / live kernel time")
+        if roofline["secondary"] is None:
+            roofline["secondary"] = valu_issue(args.workload, ms_kernel / max(1.0, float(poses_launch or 1)))
+    else:
+        roofline["secondary"] = valu_issue(args.workload, ms_kernel)
 
     # Materialised mode of the same workload ("report both numbers"): r and the 1x6 row of every point written
     # out in the batch's dtype (ea_batch_eval_rows_device), the bandwidth-bound form of the path: 3 s in + 7 s out per

@@ -430,6 +430,9 @@ struct ea_batch {
   // G poses per launch: the descriptor / group tables replicated G times (copy g of a term owns the partial rows and the pose
   // slot of pose g) and the partial rows of G poses
   int kp_G = 0, t_kp_G = 0;   // (t_kp_G > 0: tuning key "poses_per_launch" caps G)
+  // the launch shape of the pose-batched evaluation -- a throughput shape (more points per lane than the latency shape one
+  // evaluation of the same batch takes) -- and the partial rows / widest term it implies per pose
+  int kp_ppt = 1, kp_nt = 256, kp_chunk = 256, kp_ntiles = 0, kp_max_chunks = 0;
   ProblemDesc *d_kprobs = nullptr;
   GroupDesc *d_kgroups = nullptr;
   double *d_krows = nullptr;
@@ -1274,17 +1277,40 @@ extern "C" int ea_batch_eval(ea_batch *b, const double *q, const double *t, doub
 // more batch dimension.  The evaluation kernel already takes (workgroup column, term) grids with a descriptor and a pose
 // per term; here the descriptor table is replicated G times -- copy g of term j keeps j's points and image and owns its own
 // partial rows and pose slot g -- so ONE launch of (chunks, G x terms) workgroups evaluates every point at G poses, one
-// fold launch of G x count workgroups folds them straight into pinned host memory (ea_batch_eval's summation order: the
-// sums of pose k are those ea_batch_eval returns at pose k), and K poses are ceil(K / G) such pairs behind one
-// synchronisation.  Every (point, pose) pair runs the whole per-point arithmetic; nothing is shared between poses but the
+// fold launch of G x count workgroups folds them straight into pinned host memory (the sums of pose k are those
+// ea_batch_eval returns at pose k up to rounding: the pose path cuts the points into chunks of its own, kposes_shape),
+// and K poses are ceil(K / G) such pairs behind one synchronisation.  Every (point, pose) pair runs the whole per-point arithmetic; nothing is shared between poses but the
 // bytes of the points and the image, which the later poses find in the caches.  (Round 3 first chained K launches with the
 // fold of evaluation k-1 riding in launch k -- 3.3 us per C2 evaluation, one small launch at a time; G poses per launch
 // fill the chip.)
 
 // G: poses per launch -- enough workgroups to fill the chip several times over (~32k), within the grid's y limit and 64 MB
 // of partial rows
+// Launch shape.  One evaluation of a batch is shaped for latency (one point per lane on frame-sized problems: as many
+// wavefronts as possible, few partial rows for the LM step to fold); a launch of G poses is throughput-bound, where more
+// points per lane amortise the wavefront butterfly and 256-lane workgroups keep the occupancy
+// (profiles/r03_ab_poses_shape.txt: C2 fp64 0.69 -> 0.58 us per evaluation at two points per lane, fp32 0.33 -> 0.27; C5
+// fp32 5.65 -> 4.50 at 256 x 4 instead of 1024 x 4).  Explicit tuning ("points_per_thread", "threads") wins.
+static void kposes_shape(ea_batch *b) {
+  int nt = 256, ppt = b->dtype == EA_F64 ? 2 : (b->max_n >= 200000 ? 4 : 2);
+  if (b->lds_bytes > 0 || b->wide) { nt = b->nt; ppt = b->ppt; }          // (those forms keep the shape they were tuned at)
+  if (b->t_nt == 1024 || b->t_nt == 256) nt = b->t_nt;
+  if (b->t_ppt == 1 || b->t_ppt == 2 || b->t_ppt == 4) ppt = b->t_ppt;
+  if (nt == 1024 && b->dtype == EA_F64) ppt = 1;
+  if (b->dtype == EA_F64 && ppt > 2) ppt = 2;
+  if (b->any_variant) { nt = 256; ppt = std::min(ppt, 2); }
+  b->kp_nt = nt; b->kp_ppt = ppt; b->kp_chunk = nt * ppt;
+  const ProblemDesc *hd = reinterpret_cast<const ProblemDesc *>(b->h_desc);
+  int rows = 0, widest = 0;
+  for (int j = 0; j < b->nterms; ++j) {
+    const int nchunks = (int)(((int64_t)hd[j].n + b->kp_chunk - 1) / b->kp_chunk);
+    rows += nchunks; widest = std::max(widest, nchunks);
+  }
+  b->kp_ntiles = rows; b->kp_max_chunks = widest;
+}
+
 static int kposes_group(const ea_batch *b, int K) {
-  const int64_t wgs = std::max<int64_t>(1, (int64_t)b->ntiles);
+  const int64_t wgs = std::max<int64_t>(1, (int64_t)b->kp_ntiles);
   int64_t g = (32768 + wgs - 1) / wgs;
   g = std::min<int64_t>(g, 65535 / std::max(1, b->nterms));
   g = std::min<int64_t>(g, ((int64_t)64 << 20) / (wgs * kAccSlots * (int64_t)sizeof(double)));
@@ -1303,21 +1329,24 @@ static int kposes_tables(ea_batch *b, int G) {
   if (b->kp_G >= G && !(b->t_kp_G > 0 && b->kp_G > b->t_kp_G)) return EA_OK;
   HIPCHK(hipStreamSynchronize(b->stream));
   kposes_free_tables(b);
-  const size_t nterms = (size_t)b->nterms, count = b->probs.size(), rows = (size_t)b->ntiles;
+  const size_t nterms = (size_t)b->nterms, count = b->probs.size(), rows = (size_t)b->kp_ntiles;
   const ProblemDesc *hd = reinterpret_cast<const ProblemDesc *>(b->h_desc);                          // (batch_build's staging block)
   const GroupDesc *hg = reinterpret_cast<const GroupDesc *>(b->h_desc + nterms * sizeof(ProblemDesc));
+  // the partial rows of one pose in the pose path's own chunking (kposes_shape)
+  std::vector<int32_t> row0(nterms + 1, 0);
+  for (size_t j = 0; j < nterms; ++j) row0[j + 1] = row0[j] + (int32_t)(((int64_t)hd[j].n + b->kp_chunk - 1) / b->kp_chunk);
   std::vector<ProblemDesc> descs((size_t)G * nterms);
   std::vector<GroupDesc> groups((size_t)G * count);
   for (int g = 0; g < G; ++g) {
     for (size_t j = 0; j < nterms; ++j) {
       ProblemDesc d = hd[j];
-      d.tile_begin += (int32_t)(g * rows); d.tile_end += (int32_t)(g * rows);
+      d.tile_begin = row0[j] + (int32_t)(g * rows); d.tile_end = row0[j + 1] + (int32_t)(g * rows);
       d.group += (int32_t)(g * count);
       descs[(size_t)g * nterms + j] = d;
     }
     for (size_t i = 0; i < count; ++i) {
       GroupDesc gd = hg[i];
-      gd.tile_begin += (int32_t)(g * rows); gd.tile_end += (int32_t)(g * rows);
+      gd.tile_begin = row0[(size_t)hg[i].term_begin] + (int32_t)(g * rows); gd.tile_end = row0[(size_t)hg[i].term_end] + (int32_t)(g * rows);
       gd.term_begin += (int32_t)(g * nterms); gd.term_end += (int32_t)(g * nterms);
       groups[(size_t)g * count + i] = gd;
     }
@@ -1356,6 +1385,7 @@ extern "C" int ea_batch_set_poses(ea_batch *b, int K, const double *q, const dou
   if (rc != EA_OK) return rc;
   b->kp_K = 0;
   if ((rc = kposes_reserve(b, K)) != EA_OK) return rc;
+  if (b->kp_G == 0) kposes_shape(b);   // (once per build of the batch)
   if ((rc = kposes_tables(b, kposes_group(b, K))) != EA_OK) return rc;
   const size_t n = (size_t)K * b->probs.size();
   // (the previous upload out of the same staging block has been consumed: every call below ends with its pose kernel
@@ -1377,7 +1407,7 @@ static int enqueue_resident_poses(ea_batch *b, int K, bool folds = true, bool fl
   const int count = (int)b->probs.size(), G = b->kp_G;
   for (int start = 0; start < K; start += G) {
     const int g = std::min(G, K - start);
-    HIPCHK(launch_eval_poses(b->dtype, b->ppt, b->nt, b->any_variant, b->d_kprobs, g * b->nterms, b->chunk, b->max_chunks,
+    HIPCHK(launch_eval_poses(b->dtype, b->kp_ppt, b->kp_nt, b->any_variant, b->d_kprobs, g * b->nterms, b->kp_chunk, b->kp_max_chunks,
                              b->xcd_remap, b->d_kposes + (size_t)start * count, b->d_krows, b->lds_bytes, b->wide,
                              b->terms_are_groups, b->buffer_loads, b->img32, b->x0, b->y0, b->z0, b->n0, b->stream));
     if (!folds) continue;
@@ -2200,6 +2230,9 @@ extern "C" int ea_batch_get_info(const ea_batch *b, const char *key, int64_t *va
   else if (k == "num_points") { int64_t s = 0; for (auto *p : b->probs) s += p->n; *value = s; }
   else if (k == "num_rows") *value = b->total_rows;
   else if (k == "poses_per_launch") *value = b->kp_G;  // G of the last ea_batch_set_poses (0: none resident)
+  else if (k == "poses_points_per_thread") *value = b->kp_ppt;   // launch shape of the pose-batched evaluation
+  else if (k == "poses_threads") *value = b->kp_nt;
+  else if (k == "poses_tiles") *value = b->kp_ntiles;            // partial rows (= workgroups with work) per pose
   else return fail(EA_ERR_INVALID_ARG, "unknown info key: " + k);
   return EA_OK;
 }

@@ -306,9 +306,11 @@ int ea_batch_solve(ea_batch *b, const ea_options *opt, double *q, double *t,
  * other: the pose is a batch dimension of the launch -- G poses per evaluation launch (grid = chunks x G x terms, every
  * (point, pose) pair through the whole per-point arithmetic) and one fold launch for their partial rows, ceil(K / G) such
  * pairs, the results folded straight into pinned host memory, ONE synchronisation: well under 1 us per evaluation of a
- * 5e4-point pair from a few dozen poses on, against ~30 us through ea_batch_eval.  The sums of pose k are those
- * ea_batch_eval returns at pose k (same partial rows, same summation order; the pose-dependent constants are built on the
- * device, so the last bits may differ).  Every kind of batch is covered (variant functors, shared-pose terms, LDS staging). */
+ * 5e4-point pair from a few dozen poses on, against ~27 us through ea_batch_eval.  The sums of pose k are those
+ * ea_batch_eval returns at pose k up to rounding (the pose-batched launch takes a throughput shape -- more points per
+ * lane -- so the partial rows are cut differently, and the pose-dependent constants are built on the device); any split of
+ * the K poses over launches gives the same bits.  Every kind of batch is covered (variant functors, shared-pose terms,
+ * LDS staging). */
 int ea_batch_eval_poses(ea_batch *b, int K, const double *q, const double *t, double *cost, double *JtJ, double *Jtr,
                         int64_t *n_invalid);
 /* The same in two halves, for a caller that evaluates the same poses again (or wants the upload off its critical path):
