@@ -419,10 +419,14 @@ def main():
     # the timed steps computed what ea_batch_eval computes at their poses (first, middle and last step checked; the riding
     # folds sum in another order: equal to rounding)
     if mode == "poses":
+        # (the pose-batched launch cuts the points into other chunks than a single evaluation: fp64 sums agree to rounding of
+        # the fold, fp32 ones to the rounding of the per-lane / per-wavefront fp32 partial sums)
+        rt = 1.0 if esize == 8 else 1e6
         for k in sorted({0, args.steps // 2, args.steps - 1}):
             want = B.eval(Qk[k], Tk[k])
-            if not (np.allclose(out_k["cost"][k], want["cost"], rtol=1e-12, atol=0) and np.allclose(out_k["JtJ"][k], want["JtJ"], rtol=1e-11, atol=1e-300)
-                    and np.allclose(out_k["Jtr"][k], want["Jtr"], rtol=1e-10, atol=1e-300) and np.array_equal(out_k["n_invalid"][k], want["n_invalid"])):
+            sc = np.abs(want["JtJ"]).max()
+            if not (np.allclose(out_k["cost"][k], want["cost"], rtol=1e-12 * rt, atol=0) and np.allclose(out_k["JtJ"][k], want["JtJ"], rtol=1e-11 * rt, atol=1e-12 * rt * sc)
+                    and np.allclose(out_k["Jtr"][k], want["Jtr"], rtol=1e-10 * rt, atol=1e-12 * rt * np.sqrt(sc * max(float(np.max(want["cost"])), 1e-300))) and np.array_equal(out_k["n_invalid"][k], want["n_invalid"])):
                 raise SystemExit("bench.py: timed step %d differs from ea_batch_eval at its pose" % k)
         if args.steps > 1 and np.array_equal(out_k["cost"][0], out_k["cost"][-1]):
             raise SystemExit("bench.py: the timed steps were not evaluated at different poses")
