@@ -400,6 +400,7 @@ struct ea_batch {
   int *h_progress = nullptr;            // pinned, device-visible: [running x count | evaluations started x count | steps complete x count | done flag]
   unsigned int *d_done_count = nullptr; // workgroups of the last fold of a synchronous evaluation that have delivered (ea_reduce_done_kernel)
   int done_seq = 0;                     // the value the flag takes when the current call's results have all landed
+  int t_poll = 1;                       // tuning key "poll_results": 0 = wait for the stream's completion signal instead (A/B)
   // tuning (-1 = heuristic)
   int t_lds_bytes = -1, t_ppt = -1, t_use_lds = -1, t_xcd = -1, t_nt = -1, t_streams = -1, t_variant = 0;
   int t_wide = 0, wide = 0;              // "wide_accumulate": an fp32 kernel sums in fp64 from the lane's sum on (plain functor, L2 path)
@@ -1241,6 +1242,10 @@ static hipError_t launch_last_fold(ea_batch *b, const GroupDesc *groups, int cou
 
 static int wait_results(ea_batch *b) {
   const size_t c = b->probs.size();
+  if (!b->t_poll) {
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return EA_OK;
+  }
   SpinWait wait(2000.0);
   while (__atomic_load_n(&b->h_progress[3 * c], __ATOMIC_ACQUIRE) != b->done_seq) {
     if (wait.poll()) {
@@ -2209,6 +2214,7 @@ extern "C" int ea_batch_set_tuning(ea_batch *b, const char *key, int value) {
   else if (k == "solve_streams") { b->t_streams = value; return EA_OK; }
   else if (k == "rows_staged") { b->t_rows_staged = value; return EA_OK; }
   else if (k == "rows_nontemporal") { b->t_rows_nt = value; return EA_OK; }
+  else if (k == "poll_results") { b->t_poll = value != 0; return EA_OK; }
   else if (k == "poses_per_launch") { b->t_kp_G = value > 0 ? value : 0; b->kp_K = 0; return EA_OK; }  // (resident poses are dropped)
   else return fail(EA_ERR_INVALID_ARG, "unknown tuning key: " + k);
   b->built = false;
