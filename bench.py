@@ -373,6 +373,11 @@ def main():
     mode = "serial" if (args.serial_steps or args.no_graph) else "poses"
     graph, pipelined, out_k, warm_replays, G = None, False, None, 0, 1
     if mode == "poses":
+        # This caller ends its timed bracket on a device synchronisation (the contract): it waits for the stream's completion
+        # signal inside the call rather than returning on the library's done flag ~6 us earlier and paying a cold device
+        # wait of ~11 us right behind it (profiles/r03_ab_poll.txt: 33.6 against 39.0 us per K = 20 call + torch.cuda.synchronize;
+        # a caller that consumes the results at once sees 25.5 against 31.2 us with the flag, the library's default).
+        B.set_tuning("poll_results", 0)
         B.set_poses(Qk, Tk)
         out_k = B.eval_resident_poses()
         pipelined = True
@@ -437,6 +442,7 @@ def main():
             raise SystemExit("bench.py: the timed steps' result differs from ea_batch_eval's")
     # the product calls by the wall clock, beside the headline: one ea_batch_eval (launch pair + synchronisation), and
     # ea_batch_eval_poses all in one (pose upload and device-side pose constants inside)
+    B.set_tuning("poll_results", 1)   # (the library's default: return on the done flag)
     B.eval(q0, t0)
     tl = time.perf_counter()
     for _ in range(50):
