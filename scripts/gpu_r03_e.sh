@@ -3,6 +3,7 @@
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03e; mkdir -p $O
 cd $R
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $O/tests.txt 2>&1; echo "tests rc=$?"; tail -3 $O/tests.txt
 timeout -k 10 600 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err; echo "bench c2 rc=$?"
 timeout -k 10 600 python bench.py --steps 20 --warmup 5 > $O/bench_c2_steps20.json 2> $O/bench_c2_steps20.err; echo "bench c2 steps20 rc=$?"
 timeout -k 10 300 python bench.py --serial-steps --no-extras --no-cpu-baseline > $O/bench_c2_serial_steps.json 2> /dev/null; echo "bench serial rc=$?"
