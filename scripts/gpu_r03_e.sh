@@ -22,3 +22,8 @@ STEPS=2000 bash scripts/pmc_busy.sh >> $O/pmc_busy.txt 2>&1; echo "pmc busy (200
 bash scripts/pmc_valu_refresh.sh > $O/pmc_valu_refresh.txt 2>&1; echo "pmc valu rc=$?"; tail -5 $O/pmc_valu_refresh.txt
 find $O -name "*kernel_stats.csv" | head; 
 for d in kt_c2_steps20 kt_c2 kt_c5 kt_sharded; do f=$(find $O/$d -name "*kernel_stats.csv" | head -1); echo "== $d"; head -8 $f | cut -c1-200; done
+# the tracer's durations per (kernel, grid): --stats averages every shape the kernel name was launched in
+for d in kt_c2_steps20 kt_c2 kt_c5; do echo "== $d"; python3 scripts/kt_by_grid.py $O/$d ea_eval_poses; done > $O/kt_by_grid.txt 2>&1; cat $O/kt_by_grid.txt | cut -c1-140
+# the raw per-dispatch tables are large (gpurun_out/ travels back only below 64 MiB): keep the summaries
+find $R/gpurun_out -name "*kernel_trace.csv" -delete; find $R/gpurun_out -name "*counter_collection.csv" -delete; find $R/gpurun_out -name "*.log" -size +200k -delete
+du -sh $R/gpurun_out
