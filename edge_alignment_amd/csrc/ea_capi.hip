@@ -54,6 +54,12 @@ hipError_t launch_reduce_nt(int nt, const GroupDesc *groups, int count, const do
 hipError_t launch_lm_step(const GroupDesc *groups, int count, const double *partials, PoseState *poses,
                           LMState *states, LMCold *cold, LMTrace *traces, const LMOptions &opt, int *running_flags,
                           LMState *host_states, LMTrace *host_traces, const GroupDesc &first, int post_done, hipStream_t stream);
+hipError_t launch_lm_iter(int dtype, int ppt, const ProblemDesc *probs, int count, int chunk, int max_chunks, int xcd_remap,
+                          PoseState *poses, const double *rows_in, double *rows_out, int buffer_loads, int img32,
+                          const void *x0, const void *y0, const void *z0, int n0, const GroupDesc *groups,
+                          const LMState *st_in, LMState *st_out, const LMCold *cold_in, LMCold *cold_out, LMTrace *traces,
+                          const LMOptions &opt, int *progress, LMState *host_states, LMTrace *host_traces,
+                          const GroupDesc &first, hipStream_t stream);
 hipError_t launch_pad_image(int dtype, const void *src, int H, int W, void *dst, int pitch, float *dst32, int *inexact,
                             hipStream_t stream);
 hipError_t launch_make_poses(const double *qt, int n, int count, const ProblemDesc *probs, const GroupDesc *groups,
@@ -437,6 +443,14 @@ struct ea_batch {
   ProblemDesc *d_kprobs = nullptr;
   GroupDesc *d_kgroups = nullptr;
   double *d_krows = nullptr;
+  // one launch per LM iteration (ea_lm_iter_kernel): the second buffer of each pair a launch reads / writes -- states and cold
+  // systems [LMState x count | LMCold x count] and partial rows -- beside d_states, d_cold, d_partials
+  unsigned char *d_iter_alt = nullptr;
+  int iter_alt_count = 0;
+  double *d_partials_alt = nullptr;
+  int tiles_cap_alt = 0;
+  int t_fused = -1;             // tuning key "fused_iterations": -1 = whenever the solve qualifies, 0 = never (A/B, tests)
+  int last_fused = 0;           // info key "fused_iterations": the last solve of this batch ran one launch per iteration
   bool needs_drain = false;     // a solve gave up on its deadline with launches still queued: synchronise before reuse
   const void *x0 = nullptr, *y0 = nullptr, *z0 = nullptr;  // problem 0's point arrays and count, handed to the evaluation
   int n0 = 0;                                              // kernel in its preloaded arguments
@@ -875,6 +889,8 @@ static void batch_free_device(ea_batch *b) {
   if (b->bench_e1) { (void)hipEventDestroy(b->bench_e1); b->bench_e1 = nullptr; }
   (void)hipFree(b->d_one_row); b->d_one_row = nullptr;
   cached_free(b->d_probs); cached_free(b->d_groups); cached_free(b->d_lm_block); cached_free(b->d_cold);
+  cached_free(b->d_iter_alt); cached_free(b->d_partials_alt);
+  b->d_iter_alt = nullptr; b->d_partials_alt = nullptr; b->iter_alt_count = 0; b->tiles_cap_alt = 0;
   cached_free(b->d_partials); cached_free(b->d_out); cached_free(b->d_done_count);
   b->d_done_count = nullptr;
   cached_host_free(b->h_lm_block); cached_host_free(b->h_out);
@@ -1544,6 +1560,7 @@ struct SolveRun {
   int seen = 0;   // evaluations the device had completed at the last look (progress = this moved, or a pair went out)
   unsigned spins = 0;
   bool done = false, fetch = false, moved = false;
+  bool fused = false;  // one launch per iteration (ea_lm_iter_kernel) instead of (evaluate, step) pairs
 };
 
 static double resolve_timeout_ms(const ea_options &o) { return o.solve_timeout_ms == 0.0 ? 5000.0 : o.solve_timeout_ms; }
@@ -1565,6 +1582,29 @@ static int solve_start(SolveRun &r, const ea_options &o, const LMOptions &lo, co
                              (void *)(intptr_t)b->t_test_stall_ms));
   HIPCHK(hipMemcpyAsync(b->d_lm_block, b->h_lm_block, (size_t)count * (sizeof(PoseState) + sizeof(LMState)),
                         hipMemcpyHostToDevice, b->stream));
+  // One launch per iteration when every workgroup of the evaluation can run the LM step itself for free: LM strategy, one
+  // plain residual family per problem in 256-thread workgroups on the L2 path, and the whole grid (chunks + the writer,
+  // rounded to the XCDs) resident at once -- the kernel holds one workgroup per CU (ea_lm_iter_kernel).
+  {
+    const int gx = b->xcd_remap ? 8 * ((b->max_chunks + 1 + 7) / 8) : b->max_chunks + 1;
+    r.fused = b->t_fused != 0 && lo.strategy == 0 && b->nt == 256 && !b->any_variant && b->lds_bytes == 0 && !b->wide &&
+              b->terms_are_groups && b->max_chunks > 0 && (int64_t)gx * count <= 256;
+    if (r.fused) {
+      if (b->iter_alt_count < count) {
+        cached_free(b->d_iter_alt);
+        b->d_iter_alt = nullptr; b->iter_alt_count = 0;
+        HIPCHK(cached_malloc(reinterpret_cast<void **>(&b->d_iter_alt), (size_t)count * (sizeof(LMState) + sizeof(LMCold)), b->device));
+        b->iter_alt_count = count;
+      }
+      if (b->tiles_cap_alt < b->tiles_cap) {
+        cached_free(b->d_partials_alt);
+        b->d_partials_alt = nullptr; b->tiles_cap_alt = 0;
+        HIPCHK(cached_malloc(reinterpret_cast<void **>(&b->d_partials_alt), (size_t)b->tiles_cap * kAccSlots * sizeof(double), b->device));
+        b->tiles_cap_alt = b->tiles_cap;
+      }
+    }
+    b->last_fused = r.fused ? 1 : 0;
+  }
   r.ahead = o.iterations_per_sync > 0 ? o.iterations_per_sync : 2;  // measured: 2 beats 1, 3, 4, 6 by 1-3 %
   r.budget = o.max_num_iterations + 2;  // every pair consumes at least one iteration
   r.enq = 0; r.spins = 0; r.seen = 0; r.done = false; r.fetch = false; r.moved = true;
@@ -1585,10 +1625,26 @@ static int solve_pump(SolveRun &r, const LMOptions &lo) {
   if (!any) { r.done = true; r.moved = true; return EA_OK; }
   if (done != r.seen) { r.seen = done; r.moved = true; }
   if (r.enq < r.budget && r.enq - done < r.ahead) {
-    int rc = batch_launch_eval(b);
-    if (rc != EA_OK) return rc;
-    HIPCHK(launch_lm_step(b->d_groups, count, b->d_partials, b->d_poses, b->d_states, b->d_cold, b->d_traces, lo,
-                          b->d_progress, b->dv_states, b->dv_traces, b->group0, 0, b->stream));
+    if (r.fused) {
+      // launch j = enq + 1 steps on what launch j - 1 left in the buffers of parity (j - 1) and evaluates into those of parity j;
+      // launch 0 is the plain evaluation at the start pose
+      if (r.enq == 0) {
+        int rc = batch_launch_eval(b);
+        if (rc != EA_OK) return rc;
+      }
+      LMState *st[2] = {b->d_states, reinterpret_cast<LMState *>(b->d_iter_alt)};
+      LMCold *cold[2] = {b->d_cold, reinterpret_cast<LMCold *>(b->d_iter_alt + (size_t)b->iter_alt_count * sizeof(LMState))};
+      double *rows[2] = {b->d_partials, b->d_partials_alt};
+      const int in = r.enq & 1, out = in ^ 1;
+      HIPCHK(launch_lm_iter(b->dtype, b->ppt, b->d_probs, count, b->chunk, b->max_chunks, b->xcd_remap, b->d_poses, rows[in], rows[out],
+                            b->buffer_loads, b->img32, b->x0, b->y0, b->z0, b->n0, b->d_groups, st[in], st[out], cold[in], cold[out],
+                            b->d_traces, lo, b->d_progress, b->dv_states, b->dv_traces, b->group0, b->stream));
+    } else {
+      int rc = batch_launch_eval(b);
+      if (rc != EA_OK) return rc;
+      HIPCHK(launch_lm_step(b->d_groups, count, b->d_partials, b->d_poses, b->d_states, b->d_cold, b->d_traces, lo,
+                            b->d_progress, b->dv_states, b->dv_traces, b->group0, 0, b->stream));
+    }
     ++r.enq;
     r.spins = 0;
     r.moved = true;
@@ -1615,7 +1671,12 @@ static int solve_collect(SolveRun &r, const ea_options &o, bool want_traces) {
   if (r.fetch) {
     HIPCHK(hipMemcpyAsync(b->h_states, b->d_states, (size_t)count * (sizeof(LMState) + sizeof(LMTrace)),
                           hipMemcpyDeviceToHost, b->stream));
+    if (r.fused && (r.enq & 1))  // a solve cut short is still running: every launch wrote, the last one into the other buffer
+      HIPCHK(hipMemcpyAsync(b->h_states, b->d_iter_alt, (size_t)count * sizeof(LMState), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
+    if (r.fused)  // a problem that ended earlier stopped alternating buffers: its final state is the delivered one
+      for (int i = 0; i < count; ++i)
+        if (__atomic_load_n(&b->h_progress[i], __ATOMIC_ACQUIRE) == 0) b->h_states[i] = b->hd_states[i];
     return EA_OK;
   }
   std::memcpy(b->h_states, b->hd_states, (size_t)count * sizeof(LMState));
@@ -2215,6 +2276,7 @@ extern "C" int ea_batch_set_tuning(ea_batch *b, const char *key, int value) {
   else if (k == "rows_staged") { b->t_rows_staged = value; return EA_OK; }
   else if (k == "rows_nontemporal") { b->t_rows_nt = value; return EA_OK; }
   else if (k == "poll_results") { b->t_poll = value != 0; return EA_OK; }
+  else if (k == "fused_iterations") { b->t_fused = value; return EA_OK; }
   else if (k == "poses_per_launch") { b->t_kp_G = value > 0 ? value : 0; b->kp_K = 0; return EA_OK; }  // (resident poses are dropped)
   else return fail(EA_ERR_INVALID_ARG, "unknown tuning key: " + k);
   b->built = false;
@@ -2239,6 +2301,7 @@ extern "C" int ea_batch_get_info(const ea_batch *b, const char *key, int64_t *va
   else if (k == "poses_points_per_thread") *value = b->kp_ppt;   // launch shape of the pose-batched evaluation
   else if (k == "poses_threads") *value = b->kp_nt;
   else if (k == "poses_tiles") *value = b->kp_ntiles;            // partial rows (= workgroups with work) per pose
+  else if (k == "fused_iterations") *value = b->last_fused;      // the last solve ran one launch per LM iteration (ea_lm_iter_kernel)
   else return fail(EA_ERR_INVALID_ARG, "unknown info key: " + k);
   return EA_OK;
 }

@@ -941,6 +941,17 @@ __device__ __forceinline__ double fused_chunk(const ProblemDesc &pd, const PS &p
   return sum;
 }
 
+// a value every lane of the wavefront holds (read from LDS, say) as a scalar-register operand
+template <typename T> __device__ __forceinline__ T uniform_scalar(T v);
+template <> __device__ __forceinline__ float uniform_scalar<float>(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+template <> __device__ __forceinline__ double uniform_scalar<double>(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 // NT = workgroup size (256 or 1024).  1024 = one workgroup per CU: four times fewer partial rows
 // to fold afterwards at the same points-per-lane latency.
 template <typename T, int PPT, int MODE, int NT, bool VAR, bool BUF, bool IMG32>
@@ -1686,6 +1697,204 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_step_kernel(
   EA_LM_STAMP(5, ev_);
 }
 
+// ---- one launch per LM iteration ----------------------------------------------------------------------------------------
+//
+// ea_solve's loop as (evaluate, step) pairs pays two kernel boundaries per iteration and, in between, the publication of the
+// candidate pose through memory: evaluation kernel ends -> step kernel starts cold on one CU, folds, runs the state machine,
+// stores pose and state, ends -> evaluation kernel starts cold, fetches descriptor and pose, ...  For ONE small problem the
+// evaluation is at most one workgroup per CU, and every CU but one idles through the step.  Here every workgroup of the
+// evaluation runs the step itself: it folds the previous launch's partial rows (the same reduce_tiles in the same order),
+// runs the state machine on its lane 0 -- identical instructions on identical inputs, so every workgroup arrives at the same
+// candidate pose without talking to the others -- and evaluates its own points at that pose straight away, its point loads
+// having travelled beside the fold.  One kernel boundary per iteration instead of two, no pose round trip through memory, and
+// the cold start of the evaluation (descriptor, points) hidden behind the fold.  Nothing is handed from one workgroup to
+// another inside a launch; what a launch reads (state, cold system, rows) it never writes: those three are ping-ponged
+// between two buffers by the parity of the launch.
+//
+// One more workgroup than chunks: the one past the last chunk has no points and is the WRITER -- state, cold system, trace row,
+// the pose (for whoever evaluates at it afterwards), the host's progress words and, when the solve ends, the final delivery
+// into pinned host memory, exactly as ea_lm_step_kernel does them.  Its stores do not sit in any evaluator's memory counter.
+// A finished problem is recognised by every later launch from poses[p].active == 0 (written once, by the writer of the
+// launch in which the state machine stopped; in that launch every workgroup finds out by itself).
+// LM strategy, one plain residual family per problem, 256-thread workgroups, stencil rows from L2; the host only takes this
+// path when the whole grid is resident at once (<= 256 workgroups), see solve_start.
+template <typename T, int PPT, bool BUF, bool IMG32>
+__global__ __launch_bounds__(kLmThreads) void ea_lm_iter_kernel(
+    const void *__restrict__ x0, const void *__restrict__ y0, const void *__restrict__ z0, int n0,
+    int shape, int chunks_per_xcd,
+    const ProblemDesc *__restrict__ probs, PoseState *__restrict__ poses,
+    const double *__restrict__ rows_in, double *__restrict__ rows_out, const GroupDesc *__restrict__ groups,
+    const LMState *__restrict__ st_in, LMState *__restrict__ st_out, const LMCold *__restrict__ cold_in,
+    LMCold *__restrict__ cold_out, LMTrace *__restrict__ traces, LMOptions opt_arg,
+    int *__restrict__ progress /* pinned host: [running x n | evals x n] */,
+    LMState *__restrict__ host_states, LMTrace *__restrict__ host_traces, GroupDesc first) {
+  constexpr int NT = kLmThreads;
+  __shared__ __align__(16) double s_part[reduce_tiles_lds<NT>()];
+  __shared__ double s_acc[kAccSlots];
+  __shared__ LMState s_st;
+  __shared__ PoseState s_ps;
+  __shared__ int s_trace_it, s_store_system;
+  extern __shared__ __align__(16) unsigned char smem[];
+  double *s_red = reinterpret_cast<double *>(smem);
+  int *s_box = reinterpret_cast<int *>(smem + kRedBytes);
+  constexpr int kStateWords = (int)(sizeof(LMState) / 8), kColdWords = (int)(sizeof(LMCold) / 8);
+  constexpr int kPoseDoubles = 4 + 3 + 9 + 27, kPoseFloats = 9 + 3 + 27;
+  static_assert(kStateWords <= NT && kColdWords <= NT, "one 8-byte word per lane");
+  const int chunk = shape & 0xffff, xcd_remap = (shape >> 16) & 1;
+  const int p = blockIdx.y, tid = threadIdx.x;
+  const int bx = blockIdx.x;
+  const int c = xcd_remap ? (bx & 7) * chunks_per_xcd + (bx >> 3) : bx;
+  const bool writer = bx == (int)gridDim.x - 1;  // (= the last chunk index in either mapping; the launcher sizes the grid past the data)
+  const long long start = (long long)c * chunk;
+  LMOptions opt = opt_arg;
+  asm volatile("" : "+s"(opt.max_num_iterations), "+s"(opt.function_tolerance), "+s"(opt.gradient_tolerance),
+                    "+s"(opt.parameter_tolerance), "+s"(opt.initial_trust_region_radius), "+s"(opt.max_trust_region_radius),
+                    "+s"(opt.min_trust_region_radius), "+s"(opt.min_relative_decrease), "+s"(opt.min_lm_diagonal),
+                    "+s"(opt.max_lm_diagonal), "+s"(opt.max_num_consecutive_invalid_steps), "+s"(opt.jacobi_scaling),
+                    "+s"(opt.strategy));
+  // problem 0's points go out first (their addresses came with the wave), then everything uniform in one batch
+  T X[PPT], Y[PPT], Z[PPT];
+  const bool early = BUF && p == 0 && n0 > 0 && start < n0;  // (uniform)
+  if constexpr (BUF) {
+    if (early) {
+      const int count0 = min(chunk, (int)(n0 - start));
+      const __amdgpu_buffer_rsrc_t rx = make_raw_buffer(static_cast<const T *>(x0) + start, (unsigned)count0 * (unsigned)sizeof(T));
+      const __amdgpu_buffer_rsrc_t ry = make_raw_buffer(static_cast<const T *>(y0) + start, (unsigned)count0 * (unsigned)sizeof(T));
+      const __amdgpu_buffer_rsrc_t rz = make_raw_buffer(static_cast<const T *>(z0) + start, (unsigned)count0 * (unsigned)sizeof(T));
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const int poff = min(tid + k * NT, count0 - 1) * (int)sizeof(T);
+        X[k] = buf_load_elem<T>(rx, poff); Y[k] = buf_load_elem<T>(ry, poff); Z[k] = buf_load_elem<T>(rz, poff);
+      }
+    }
+  }
+  const ProblemDesc pd = probs[p];
+  const int active = poses[p].active;
+  GroupDesc gd = first;
+  if (p != 0) gd = groups[p];  // (uniform)
+  const int evals_before = st_in[p].num_evals;
+  const double state_word = tid < kStateWords ? reinterpret_cast<const double *>(st_in + p)[tid] : 0.0;
+  asm volatile("" ::"s"(pd.x), "s"(pd.y), "s"(pd.z), "s"(IMG32 ? pd.dt32 : pd.dt), "s"(pd.n), "s"(pd.W), "s"(pd.H), "s"(pd.pitch),
+               "s"(Uni<T>::fx(pd)), "s"(Uni<T>::fy(pd)), "s"(Uni<T>::cx(pd)), "s"(Uni<T>::cy(pd)),
+               "s"(Uni<T>::loss_a(pd)), "s"(Uni<T>::loss_inv_b(pd)), "s"(Uni<T>::z_guard(pd)), "s"(Uni<T>::z_eps(pd)),
+               "s"(pd.loss_kind), "s"(pd.tile_begin), "s"(active), "s"(evals_before));
+  if (!active) return;  // the solve of this problem ended in an earlier launch
+  const bool evaluator = start < pd.n;
+  if (!evaluator && !writer) return;
+  const int count = evaluator ? min(chunk, (int)(pd.n - start)) : 0;
+  if (evaluator && !early) {
+    const T *px = static_cast<const T *>(pd.x) + start, *py = static_cast<const T *>(pd.y) + start, *pz = static_cast<const T *>(pd.z) + start;
+    if constexpr (BUF) {
+      const __amdgpu_buffer_rsrc_t rx = make_raw_buffer(px, (unsigned)count * (unsigned)sizeof(T));
+      const __amdgpu_buffer_rsrc_t ry = make_raw_buffer(py, (unsigned)count * (unsigned)sizeof(T));
+      const __amdgpu_buffer_rsrc_t rz = make_raw_buffer(pz, (unsigned)count * (unsigned)sizeof(T));
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const int poff = min(tid + k * NT, count - 1) * (int)sizeof(T);
+        X[k] = buf_load_elem<T>(rx, poff); Y[k] = buf_load_elem<T>(ry, poff); Z[k] = buf_load_elem<T>(rz, poff);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const int jj = min(tid + k * NT, count - 1);
+        X[k] = ((GPtr<T>)px)[jj]; Y[k] = ((GPtr<T>)py)[jj]; Z[k] = ((GPtr<T>)pz)[jj];
+      }
+    }
+  }
+  // ---- the step, in every workgroup: fold of the previous launch's rows + the state machine on lane 0
+  reduce_tiles<NT, 8>(rows_in, gd.tile_begin, gd.tile_end, s_part, s_acc);
+  if (tid < kStateWords) reinterpret_cast<double *>(&s_st)[tid] = state_word;
+  __syncthreads();
+  if (writer && tid == 64)
+    __hip_atomic_store(progress + gridDim.y + p, evals_before + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  LMPending pend;
+  double acc[kAccSlots];
+  if (tid == 0) {
+    LMState st;
+    lm_copy_state(&st, &s_st);
+#pragma unroll
+    for (int i = 0; i < kAccSlots; ++i) acc[i] = s_acc[i];
+    // (the LM strategy reads the cold system -- JtJ, Jtr at x after a rejected step -- and never writes it; the trace rows of
+    // invalid steps are the writer's)
+    LMCold *cold = const_cast<LMCold *>(cold_in) + p;
+    LMTrace *tr = writer ? traces + p : nullptr;
+    if (EA_UNLIKELY(st.num_evals == 0)) lm_begin<0>(&st, cold, tr, &opt, acc, &pend);
+    else lm_advance<0>(&st, cold, tr, &opt, acc, &pend);
+    make_pose_core(st.cand, st.rot_transposed, st.running, &s_ps, /*zero_unused_G=*/false);
+    lm_copy_state(&s_st, &st);
+    s_trace_it = pend.trace_it;
+    s_store_system = pend.store_system;
+  }
+  __syncthreads();
+  const int running = s_st.running;
+  if (writer) {
+    if (tid < kStateWords) reinterpret_cast<double *>(st_out + p)[tid] = reinterpret_cast<const double *>(&s_st)[tid];
+    {
+      const double *pd_src = reinterpret_cast<const double *>(&s_ps);
+      const int a = tid - 64, f = tid - 128;
+      const bool skip_g = s_ps.unit_q != 0;
+      if (a >= 0 && a < kPoseDoubles) reinterpret_cast<double *>(poses + p)[a] = (skip_g && a >= 16) ? 0.0 : pd_src[a];
+      if (f >= 0 && f < kPoseFloats) {
+        const double v = f < 9 ? s_ps.R[f] : (f < 12 ? s_ps.t[f - 9] : (skip_g ? 0.0 : s_ps.G[f - 12]));
+        (&poses[p].Rf[0])[f] = (float)v;
+      }
+      if (tid == 192) { poses[p].unit_q = s_ps.unit_q; poses[p].active = s_ps.active; }
+    }
+    // the cold system of the next launch: this evaluation's (accepted step) or the one this launch read (rejected step)
+    if (!s_store_system && tid < kColdWords)
+      reinterpret_cast<double *>(cold_out + p)[tid] = reinterpret_cast<const double *>(cold_in + p)[tid];
+    if (tid == 0) lm_flush(&pend, cold_out + p, traces + p, acc);
+    if (!running) {
+      if (host_states) {
+        if (tid < kStateWords) reinterpret_cast<double *>(host_states + p)[tid] = reinterpret_cast<const double *>(&s_st)[tid];
+        const int last = min(s_st.iteration, kTrace - 1);
+        auto copy_row = [&](int r) {
+          const LMTrace &src = traces[p];
+          LMTrace &dst = host_traces[p];
+          dst.it_cost[r] = src.it_cost[r];
+          dst.it_cost_change[r] = src.it_cost_change[r];
+          dst.it_gradient_max_norm[r] = src.it_gradient_max_norm[r];
+          dst.it_step_norm[r] = src.it_step_norm[r];
+          dst.it_relative_decrease[r] = src.it_relative_decrease[r];
+          dst.it_radius[r] = src.it_radius[r];
+          dst.it_successful[r] = src.it_successful[r];
+        };
+        if (s_trace_it == last) {
+          if (tid < last) copy_row(tid);
+          if (tid == 0) {
+            LMPending h = pend;
+            h.store_system = 0;
+            lm_flush(&h, cold_out + p, host_traces + p, acc);
+          }
+        } else if (tid == 0) {
+          __threadfence();
+          for (int r = 0; r <= last; ++r) copy_row(r);
+        }
+        __threadfence_system();
+      }
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(progress + p, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
+  if (!running) return;  // (uniform: every workgroup of the problem arrived at the same state)
+  // ---- the evaluation at the candidate pose, which this workgroup holds in LDS
+  if (!s_ps.unit_q) {  // (uniform, rare) the general-quaternion Jacobian reads G through the pose pointer
+    if (tid < 27) s_ps.Gf[tid] = (float)s_ps.G[tid];
+    __syncthreads();
+  }
+  PoseLite<T> ps;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) ps.R[i] = uniform_scalar<T>((T)s_ps.R[i]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) ps.t[i] = uniform_scalar<T>((T)s_ps.t[i]);
+  ps.unit_q = __builtin_amdgcn_readfirstlane(s_ps.unit_q);
+  ps.full = &s_ps;
+  const double sum = fused_chunk<T, PPT, 0, NT, false, BUF, IMG32, PoseLite<T>>(pd, ps, X, Y, Z, count, s_red, s_box, (T *)nullptr, 0,
+                                                                            tid < kAccSlots ? tid : -1);
+  if (tid < kAccSlots) rows_out[(size_t)(pd.tile_begin + c) * kAccSlots + tid] = sum;
+}
+
 // q (w, x, y, z) and t of n = K x count poses, 7 doubles each -> the PoseState the evaluation kernels read, built on the
 // device (ea_batch_set_poses: K different poses per problem go up as 56 bytes each instead of a 600-byte PoseState the
 // host would have to compute).  Pose i belongs to problem i % count; its rotation is applied transposed for the ROS
@@ -2048,6 +2257,39 @@ hipError_t launch_lm_step(const GroupDesc *groups, int count, const double *part
   else
     hipLaunchKernelGGL(ea_lm_step_kernel<1>, dim3(count), dim3(kLmThreads), 0, stream, groups, partials, poses,
                        states, cold, traces, opt, progress, host_states, host_traces, first, post_done);
+  return hipGetLastError();
+}
+
+// ea_lm_iter_kernel: launch j of a solve reads what launch j - 1 wrote (state, cold system, rows) and writes the other
+// buffer of each pair.  The grid is one workgroup larger than the evaluation's (the writer), rounded to the 8 XCDs.
+hipError_t launch_lm_iter(int dtype, int ppt, const ProblemDesc *probs, int count, int chunk, int max_chunks, int xcd_remap,
+                          PoseState *poses, const double *rows_in, double *rows_out, int buffer_loads, int img32,
+                          const void *x0, const void *y0, const void *z0, int n0, const GroupDesc *groups,
+                          const LMState *st_in, LMState *st_out, const LMCold *cold_in, LMCold *cold_out, LMTrace *traces,
+                          const LMOptions &opt, int *progress, LMState *host_states, LMTrace *host_traces,
+                          const GroupDesc &first, hipStream_t stream) {
+  if (count <= 0) return hipSuccess;
+  if (chunk <= 0 || chunk > 0xffff || chunk != kLmThreads * ppt || opt.strategy != 0) return hipErrorInvalidValue;
+  const int chunks_per_xcd = (max_chunks + 1 + 7) / 8;
+  const dim3 grid(xcd_remap ? chunks_per_xcd * 8 : max_chunks + 1, count);
+  const int shape = chunk | ((xcd_remap ? 1 : 0) << 16) | (1 << 17);
+  const size_t shmem = (size_t)kHdrBytes;
+#define EA_ITER(T, P, B, I)                                                                                                \
+  hipLaunchKernelGGL((ea_lm_iter_kernel<T, P, B, I>), grid, dim3(kLmThreads), shmem, stream, x0, y0, z0, n0, shape,        \
+                     chunks_per_xcd, probs, poses, rows_in, rows_out, groups, st_in, st_out, cold_in, cold_out, traces, opt, \
+                     progress, host_states, host_traces, first)
+#define EA_ITER_B(T, P, I) do { if (buffer_loads) EA_ITER(T, P, true, I); else EA_ITER(T, P, false, I); } while (0)
+  if (dtype == 1) {
+    if (img32) return hipErrorInvalidValue;
+    if (ppt == 1) EA_ITER_B(float, 1, false); else if (ppt == 2) EA_ITER_B(float, 2, false); else if (ppt == 4) EA_ITER_B(float, 4, false);
+    else return hipErrorInvalidValue;
+  } else if (img32) {
+    if (ppt == 1) EA_ITER_B(double, 1, true); else if (ppt == 2) EA_ITER_B(double, 2, true); else return hipErrorInvalidValue;
+  } else {
+    if (ppt == 1) EA_ITER_B(double, 1, false); else if (ppt == 2) EA_ITER_B(double, 2, false); else return hipErrorInvalidValue;
+  }
+#undef EA_ITER_B
+#undef EA_ITER
   return hipGetLastError();
 }
 

@@ -348,7 +348,8 @@ int ea_eval_rows_device(ea_problem *p, const double q[4], const double t[3], int
 
 /* ---- tuning ---------------------------------------------------------------------------- */
 /* tuning knobs: key in {"lds_bytes", "points_per_thread", "use_lds", "xcd_remap", "threads", "buffer_loads",
- * "solve_streams", "rows_staged", "rows_nontemporal", "wide_accumulate", "dt_f32", "poses_per_launch", "poll_results"};
+ * "solve_streams", "rows_staged", "rows_nontemporal", "wide_accumulate", "dt_f32", "poses_per_launch", "poll_results",
+ * "fused_iterations"};
  * value < 0 restores the default.
  * "dt_f32" = 0: an fp64 batch reads its fp64 images even where a float32 mirror holds them exactly (default: the mirror
  * when every term has one; results are bit-identical either way).  "poses_per_launch" = g > 0 caps the poses one
@@ -356,6 +357,10 @@ int ea_eval_rows_device(ea_problem *p, const double q[4], const double t[3], int
  * ea_batch_eval / ea_batch_eval_poses wait for the stream's completion signal instead of returning on the flag their last
  * fold workgroup raises in pinned memory ~6 us earlier (default 1; a caller that synchronises the whole device right behind
  * the call is better off with 0: profiles/r03_ab_poll.txt).
+ * "fused_iterations" = 0: ea_solve / ea_batch_solve always run (evaluate, step) pairs; default: a solve of problems small
+ * enough for one workgroup per CU (LM strategy, one plain residual family each) runs ONE launch per iteration, every workgroup
+ * taking the LM step itself before it evaluates -- the same iterates bit for bit (ea_batch_get_info "fused_iterations"
+ * reports which form the last solve took).
  * "wide_accumulate" = 1: an fp32 batch sums in fp64 from a lane's sum of <= points_per_thread products on (default: a
  * lane's and a wavefront's sums are fp32, everything above fp64).  Plain functor on the L2 path; ignored for fp64
  * batches, variant functors and the LDS-staged form (ea_batch_get_info "wide_accumulate" reports what is in effect).
