@@ -75,9 +75,23 @@ __device__ int g_lm_probe_row = 0;
       g_lm_stamp_buf[((eval) & 63) * 8 + (slot)] = t_;                                              \
     }                                                                                               \
   } while (0)
+// (a stamp taken before its row index is known: read the clock now, store later)
+#define EA_LM_CLOCK(var)                                                                            \
+  unsigned long long var = 0;                                                                       \
+  do {                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");                    \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+  } while (0)
+#define EA_LM_STAMP_PUT(slot, eval, var)                                                            \
+  do {                                                                                              \
+    if (g_lm_stamp_buf && threadIdx.x == 0 && blockIdx.x == 0) g_lm_stamp_buf[((eval) & 63) * 8 + (slot)] = var; \
+  } while (0)
 #else
 #define EA_STAMP(slot) do {} while (0)
 #define EA_LM_STAMP(slot, eval) do {} while (0)
+#define EA_LM_CLOCK(var) do {} while (0)
+#define EA_LM_STAMP_PUT(slot, eval, var) do {} while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -1720,19 +1734,21 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_step_kernel(
 // path when the whole grid is resident at once (<= 256 workgroups), see solve_start.
 template <typename T, int PPT, bool BUF, bool IMG32>
 __global__ __launch_bounds__(kLmThreads) void ea_lm_iter_kernel(
+    // the 14 preloaded dwords: what problem 0's point loads and ROW loads need -- the fold is the head of every workgroup's
+    // dependent chain, and its loads must not wait for a scalar load of the argument segment (tile0_* = problem 0's row range)
     const void *__restrict__ x0, const void *__restrict__ y0, const void *__restrict__ z0, int n0,
-    int shape, int chunks_per_xcd,
+    int shape, int chunks_per_xcd, const double *__restrict__ rows_in, int tile0_begin, int tile0_end,
     const ProblemDesc *__restrict__ probs, PoseState *__restrict__ poses,
-    const double *__restrict__ rows_in, double *__restrict__ rows_out, const GroupDesc *__restrict__ groups,
+    double *__restrict__ rows_out, const GroupDesc *__restrict__ groups,
     const LMState *__restrict__ st_in, LMState *__restrict__ st_out, const LMCold *__restrict__ cold_in,
     LMCold *__restrict__ cold_out, LMTrace *__restrict__ traces, LMOptions opt_arg,
     int *__restrict__ progress /* pinned host: [running x n | evals x n] */,
-    LMState *__restrict__ host_states, LMTrace *__restrict__ host_traces, GroupDesc first) {
+    LMState *__restrict__ host_states, LMTrace *__restrict__ host_traces) {
   constexpr int NT = kLmThreads;
   __shared__ __align__(16) double s_part[reduce_tiles_lds<NT>()];
   __shared__ double s_acc[kAccSlots];
   __shared__ LMState s_st;
-  __shared__ PoseState s_ps;
+  __shared__ PoseState s_pose[NT / 64];  // one per wavefront (the writer uses the first)
   __shared__ int s_trace_it, s_store_system;
   extern __shared__ __align__(16) unsigned char smem[];
   double *s_red = reinterpret_cast<double *>(smem);
@@ -1768,12 +1784,17 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_iter_kernel(
       }
     }
   }
+  EA_LM_CLOCK(t_enter_);  // (diagnostic build: kernel entered)
   const ProblemDesc pd = probs[p];
   const int active = poses[p].active;
-  GroupDesc gd = first;
+  GroupDesc gd = {tile0_begin, tile0_end, 0, 1};
   if (p != 0) gd = groups[p];  // (uniform)
   const int evals_before = st_in[p].num_evals;
   const double state_word = tid < kStateWords ? reinterpret_cast<const double *>(st_in + p)[tid] : 0.0;
+  // ---- the step, in every workgroup: fold of the previous launch's rows + the state machine on lane 0.
+  // The rows are fetched at once, beside the uniforms above and not behind them (as ea_lm_step_kernel does): a launch that
+  // finds its problem finished has folded rows nobody reads and leaves below.
+  reduce_tiles<NT, 8>(rows_in, gd.tile_begin, gd.tile_end, s_part, s_acc);
   asm volatile("" ::"s"(pd.x), "s"(pd.y), "s"(pd.z), "s"(IMG32 ? pd.dt32 : pd.dt), "s"(pd.n), "s"(pd.W), "s"(pd.H), "s"(pd.pitch),
                "s"(Uni<T>::fx(pd)), "s"(Uni<T>::fy(pd)), "s"(Uni<T>::cx(pd)), "s"(Uni<T>::cy(pd)),
                "s"(Uni<T>::loss_a(pd)), "s"(Uni<T>::loss_inv_b(pd)), "s"(Uni<T>::z_guard(pd)), "s"(Uni<T>::z_eps(pd)),
@@ -1782,7 +1803,7 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_iter_kernel(
   const bool evaluator = start < pd.n;
   if (!evaluator && !writer) return;
   const int count = evaluator ? min(chunk, (int)(pd.n - start)) : 0;
-  if (evaluator && !early) {
+  if (evaluator && !early) {  // (problems behind the first of a batch, or flat addressing: their points wait for the descriptor)
     const T *px = static_cast<const T *>(pd.x) + start, *py = static_cast<const T *>(pd.y) + start, *pz = static_cast<const T *>(pd.z) + start;
     if constexpr (BUF) {
       const __amdgpu_buffer_rsrc_t rx = make_raw_buffer(px, (unsigned)count * (unsigned)sizeof(T));
@@ -1801,44 +1822,43 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_iter_kernel(
       }
     }
   }
-  // ---- the step, in every workgroup: fold of the previous launch's rows + the state machine on lane 0
-  reduce_tiles<NT, 8>(rows_in, gd.tile_begin, gd.tile_end, s_part, s_acc);
   if (tid < kStateWords) reinterpret_cast<double *>(&s_st)[tid] = state_word;
   __syncthreads();
-  if (writer && tid == 64)
-    __hip_atomic_store(progress + gridDim.y + p, evals_before + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  LMPending pend;
-  double acc[kAccSlots];
-  if (tid == 0) {
-    LMState st;
-    lm_copy_state(&st, &s_st);
-#pragma unroll
-    for (int i = 0; i < kAccSlots; ++i) acc[i] = s_acc[i];
-    // (the LM strategy reads the cold system -- JtJ, Jtr at x after a rejected step -- and never writes it; the trace rows of
-    // invalid steps are the writer's)
-    LMCold *cold = const_cast<LMCold *>(cold_in) + p;
-    LMTrace *tr = writer ? traces + p : nullptr;
-    if (EA_UNLIKELY(st.num_evals == 0)) lm_begin<0>(&st, cold, tr, &opt, acc, &pend);
-    else lm_advance<0>(&st, cold, tr, &opt, acc, &pend);
-    make_pose_core(st.cand, st.rot_transposed, st.running, &s_ps, /*zero_unused_G=*/false);
-    lm_copy_state(&s_st, &st);
-    s_trace_it = pend.trace_it;
-    s_store_system = pend.store_system;
-  }
-  __syncthreads();
-  const int running = s_st.running;
+  EA_LM_STAMP_PUT(0, evals_before, t_enter_);
+  EA_LM_STAMP(1, evals_before);  // folded
   if (writer) {
+    // ---- the writer: the full state machine on lane 0, then everything that is stored
+    if (tid == 64)
+      __hip_atomic_store(progress + gridDim.y + p, evals_before + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    LMPending pend;
+    double acc[kAccSlots];
+    if (tid == 0) {
+      LMState st;
+      lm_copy_state(&st, &s_st);
+#pragma unroll
+      for (int i = 0; i < kAccSlots; ++i) acc[i] = s_acc[i];
+      // (the LM strategy reads the cold system -- JtJ, Jtr at x after a rejected step -- and never writes it)
+      LMCold *cold = const_cast<LMCold *>(cold_in) + p;
+      if (EA_UNLIKELY(st.num_evals == 0)) lm_begin<0>(&st, cold, traces + p, &opt, acc, &pend);
+      else lm_advance<0>(&st, cold, traces + p, &opt, acc, &pend);
+      make_pose_core(st.cand, st.rot_transposed, st.running, &s_pose[0], /*zero_unused_G=*/false);
+      lm_copy_state(&s_st, &st);
+      s_trace_it = pend.trace_it;
+      s_store_system = pend.store_system;
+    }
+    __syncthreads();
+    const int running = s_st.running;
     if (tid < kStateWords) reinterpret_cast<double *>(st_out + p)[tid] = reinterpret_cast<const double *>(&s_st)[tid];
     {
-      const double *pd_src = reinterpret_cast<const double *>(&s_ps);
+      const double *pd_src = reinterpret_cast<const double *>(&s_pose[0]);
       const int a = tid - 64, f = tid - 128;
-      const bool skip_g = s_ps.unit_q != 0;
+      const bool skip_g = s_pose[0].unit_q != 0;
       if (a >= 0 && a < kPoseDoubles) reinterpret_cast<double *>(poses + p)[a] = (skip_g && a >= 16) ? 0.0 : pd_src[a];
       if (f >= 0 && f < kPoseFloats) {
-        const double v = f < 9 ? s_ps.R[f] : (f < 12 ? s_ps.t[f - 9] : (skip_g ? 0.0 : s_ps.G[f - 12]));
+        const double v = f < 9 ? s_pose[0].R[f] : (f < 12 ? s_pose[0].t[f - 9] : (skip_g ? 0.0 : s_pose[0].G[f - 12]));
         (&poses[p].Rf[0])[f] = (float)v;
       }
-      if (tid == 192) { poses[p].unit_q = s_ps.unit_q; poses[p].active = s_ps.active; }
+      if (tid == 192) { poses[p].unit_q = s_pose[0].unit_q; poses[p].active = s_pose[0].active; }
     }
     // the cold system of the next launch: this evaluation's (accepted step) or the one this launch read (rejected step)
     if (!s_store_system && tid < kColdWords)
@@ -1877,11 +1897,32 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_iter_kernel(
     }
     return;
   }
+  // ---- the evaluators: every WAVEFRONT takes the step itself, in the form that yields the candidate pose and nothing else
+  // (lm_take_system<LITE>) -- four identical computations on four SIMDs, so the pose reaches the lanes of a wavefront without a
+  // workgroup barrier: lane 0 leaves it in the wavefront's own LDS slot and its wavefront reads it back (LDS operations of one
+  // wavefront execute in order).
+  PoseState &s_ps = s_pose[tid >> 6];
+  int running_v = 0;
+  if ((tid & 63) == 0) {
+    LMState st;
+    LMPending pend;
+    double acc[kAccSlots];
+    lm_copy_state(&st, &s_st);
+#pragma unroll
+    for (int i = 0; i < kAccSlots; ++i) acc[i] = s_acc[i];
+    LMCold *cold = const_cast<LMCold *>(cold_in) + p;
+    if (EA_UNLIKELY(st.num_evals == 0)) lm_begin<0, true>(&st, cold, nullptr, &opt, acc, &pend);
+    else lm_advance<0, true>(&st, cold, nullptr, &opt, acc, &pend);
+    EA_LM_STAMP(2, evals_before);  // state machine done
+    make_pose_core(st.cand, st.rot_transposed, st.running, &s_ps, /*zero_unused_G=*/false);
+    running_v = st.running;
+  }
+  const int running = __builtin_amdgcn_readfirstlane(running_v);
+  EA_LM_STAMP(3, evals_before);  // pose in LDS
   if (!running) return;  // (uniform: every workgroup of the problem arrived at the same state)
-  // ---- the evaluation at the candidate pose, which this workgroup holds in LDS
+  // ---- the evaluation at the candidate pose
   if (!s_ps.unit_q) {  // (uniform, rare) the general-quaternion Jacobian reads G through the pose pointer
-    if (tid < 27) s_ps.Gf[tid] = (float)s_ps.G[tid];
-    __syncthreads();
+    if ((tid & 63) < 27) s_ps.Gf[tid & 63] = (float)s_ps.G[tid & 63];
   }
   PoseLite<T> ps;
 #pragma unroll
@@ -1892,7 +1933,12 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_iter_kernel(
   ps.full = &s_ps;
   const double sum = fused_chunk<T, PPT, 0, NT, false, BUF, IMG32, PoseLite<T>>(pd, ps, X, Y, Z, count, s_red, s_box, (T *)nullptr, 0,
                                                                             tid < kAccSlots ? tid : -1);
+  EA_LM_STAMP(4, evals_before);  // evaluated
   if (tid < kAccSlots) rows_out[(size_t)(pd.tile_begin + c) * kAccSlots + tid] = sum;
+#ifdef EA_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  EA_LM_STAMP(5, evals_before);  // row stored
 }
 
 // q (w, x, y, z) and t of n = K x count poses, 7 doubles each -> the PoseState the evaluation kernels read, built on the
@@ -2276,8 +2322,8 @@ hipError_t launch_lm_iter(int dtype, int ppt, const ProblemDesc *probs, int coun
   const size_t shmem = (size_t)kHdrBytes;
 #define EA_ITER(T, P, B, I)                                                                                                \
   hipLaunchKernelGGL((ea_lm_iter_kernel<T, P, B, I>), grid, dim3(kLmThreads), shmem, stream, x0, y0, z0, n0, shape,        \
-                     chunks_per_xcd, probs, poses, rows_in, rows_out, groups, st_in, st_out, cold_in, cold_out, traces, opt, \
-                     progress, host_states, host_traces, first)
+                     chunks_per_xcd, rows_in, first.tile_begin, first.tile_end, probs, poses, rows_out, groups, st_in, st_out, \
+                     cold_in, cold_out, traces, opt, progress, host_states, host_traces)
 #define EA_ITER_B(T, P, I) do { if (buffer_loads) EA_ITER(T, P, true, I); else EA_ITER(T, P, false, I); } while (0)
   if (dtype == 1) {
     if (img32) return hipErrorInvalidValue;

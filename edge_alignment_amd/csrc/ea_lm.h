@@ -355,9 +355,15 @@ EA_HD inline void lm_init(LMState *s, const LMOptions *o, const double q[4], con
 // The evaluation at s->x delivered `acc`: take the cost and
 // gradient_max_norm = || x - Plus(x, -gradient) ||_inf  (ambient space); the unscaled system itself goes to the
 // cold state in lm_flush.
+// LITE (device only, ea_lm_iter_kernel): the caller wants the next candidate pose and nothing else -- whatever only feeds the
+// stored state, the trace or the gradient-tolerance test is left out (gradient_max_norm's Plus() through sqrt / sincos /
+// division, the norm of the accepted x).  Every workgroup of an evaluation runs this form; one more runs the full one and
+// owns the state, so a solve that ends on the gradient tolerance merely finds one evaluation launched in vain.
+template <bool LITE = false>
 EA_HD inline void lm_take_system(LMState *s, LMPending *pend, const double acc[kAccSlots]) {
   pend->store_system = 1;
   s->cost = acc[kAccCost];
+  if constexpr (LITE) return;
   double neg[6], xp[7], m = 0.0;
 #pragma unroll
   for (int i = 0; i < 6; ++i) neg[i] = -acc[kAccJtr + i];
@@ -453,14 +459,15 @@ EA_HD inline bool lm_strategy_step(LMState *s, LMCold *c, const LMOptions *o, co
 // s->running == 0 or s->cand holds the pose to evaluate next.
 // `fresh`: acc holds the evaluation at s->x (accepted step, first iteration) and is used from registers; otherwise
 // the system is re-read from the cold state (after a rejected step).
-template <int STRAT>
+template <int STRAT, bool LITE = false>
 EA_HD inline void lm_prepare_next(LMState *s, LMCold *c, LMTrace *tr, const LMOptions *o,
                                   const double acc[kAccSlots], bool fresh) {
   double As[21], gs[6];
   bool have_system = false;
   for (;;) {
     if (EA_UNLIKELY(s->iteration >= o->max_num_iterations)) { lm_finish(s, 1, 4); return; }
-    if (EA_UNLIKELY(s->gradient_max_norm <= o->gradient_tolerance)) { lm_finish(s, 0, 2); return; }
+    if constexpr (!LITE)
+      if (EA_UNLIKELY(s->gradient_max_norm <= o->gradient_tolerance)) { lm_finish(s, 0, 2); return; }
     if (EA_UNLIKELY(s->radius <= o->min_trust_region_radius)) { lm_finish(s, 0, 5); return; }
     s->iteration += 1;
     if (EA_LIKELY(!have_system)) {
@@ -539,7 +546,7 @@ EA_HD inline bool lm_eval_usable(const double acc[kAccSlots]) {
 }
 
 // after the evaluation at the initial pose
-template <int STRAT>
+template <int STRAT, bool LITE = false>
 EA_HD inline void lm_begin(LMState *s, LMCold *c, LMTrace *tr, const LMOptions *o, const double acc[kAccSlots],
                            LMPending *pend) {
   pend->store_system = 0;
@@ -548,15 +555,15 @@ EA_HD inline void lm_begin(LMState *s, LMCold *c, LMTrace *tr, const LMOptions *
   // a functor returning false, or a non-finite residual / Jacobian (lm_eval_usable), fails the evaluation: at the start
   // point the solve ends with FAILURE and the parameters untouched
   if (EA_UNLIKELY(!lm_eval_usable(acc))) { lm_finish(s, 2, 6); return; }
-  lm_take_system(s, pend, acc);
+  lm_take_system<LITE>(s, pend, acc);
   if (o->jacobi_scaling)
     for (int i = 0; i < 6; ++i) s->S[i] = 1.0 / (1.0 + sqrt(acc[kAccJtJ + sym6(i, i)]));
   lm_pend_trace(s, pend, 0, 0.0, 0.0, 0.0, 1);
-  lm_prepare_next<STRAT>(s, c, tr, o, acc, true);
+  lm_prepare_next<STRAT, LITE>(s, c, tr, o, acc, true);
 }
 
 // after the evaluation at s->cand
-template <int STRAT>
+template <int STRAT, bool LITE = false>
 EA_HD inline void lm_advance(LMState *s, LMCold *c, LMTrace *tr, const LMOptions *o, const double acc[kAccSlots],
                              LMPending *pend) {
   pend->store_system = 0;
@@ -585,8 +592,8 @@ EA_HD inline void lm_advance(LMState *s, LMCold *c, LMTrace *tr, const LMOptions
   if (EA_LIKELY(rel > o->min_relative_decrease)) {
 #pragma unroll
     for (int i = 0; i < 7; ++i) s->x[i] = s->cand[i];
-    s->x_norm = norm_n(s->x, 7);
-    lm_take_system(s, pend, acc);
+    if constexpr (!LITE) s->x_norm = norm_n(s->x, 7);
+    lm_take_system<LITE>(s, pend, acc);
     fresh = true;
     EA_LM_PROBE(1);
     s->num_successful += 1;
@@ -617,7 +624,7 @@ EA_HD inline void lm_advance(LMState *s, LMCold *c, LMTrace *tr, const LMOptions
     lm_pend_trace(s, pend, s->iteration, cost_change, step_norm, rel, 0);
   }
   EA_LM_PROBE(7);
-  lm_prepare_next<STRAT>(s, c, tr, o, acc, fresh);
+  lm_prepare_next<STRAT, LITE>(s, c, tr, o, acc, fresh);
 }
 
 // run-time strategy (host shim)

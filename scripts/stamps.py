@@ -33,6 +33,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'eval':   # (needs a library built with 
 def run_lm(name, cfg):
     P = capi.Problem(*cfg['K'], dtype=capi.EA_F64); P.set_points(cfg['xyz']); P.set_dt_grid(cfg['grid']); P.set_loss(capi.LOSS_CAUCHY, 1.0)
     B = capi.Batch([P])
+    B.set_tuning('fused_iterations', 0)   # the (evaluate, step) pairs
     q, t, summ = B.solve(q0, t0)   # warm
     assert L.ea_debug_lm_stamps_begin() == 0
     q, t, summ = B.solve(q0, t0)
@@ -53,3 +54,29 @@ def run_lm(name, cfg):
     print('   total median %.0f; eval-to-eval period median %.0f' % (np.median(st[:, 5] - st[:, 0]), np.median(np.diff(np.sort(st[:, 0])))))
     P.close()
 run_lm('lm1e5 f64', synth.config_c2_twin(seed=7, n_points=100000))
+
+
+def run_lm_fused(name, cfg, dtype=capi.EA_F64):
+    """ea_lm_iter_kernel (one launch per iteration): stamps of workgroup 0 (an evaluator), lane 0"""
+    P = capi.Problem(*cfg['K'], dtype=dtype); P.set_points(cfg['xyz']); P.set_dt_grid(cfg['grid']); P.set_loss(capi.LOSS_CAUCHY, 1.0)
+    B = capi.Batch([P])
+    q, t, summ = B.solve(q0, t0)   # warm
+    assert B.info('fused_iterations') == 1
+    assert L.ea_debug_lm_stamps_begin() == 0
+    q, t, summ = B.solve(q0, t0)
+    st = np.zeros((128, 8), dtype=np.uint64)
+    assert L.ea_debug_lm_stamps_end(st.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
+    st = st.astype(np.int64)[:64]
+    st = st[(st[:, 5] > 0) & (st[:, 0] > 0)]
+    st = st[np.argsort(st[:, 0])]
+    d = np.diff(st[:, :6], axis=1)
+    print('%s fused LM iteration kernel (%d launches captured), s_memtime ticks median / max:' % (name, len(st)))
+    for i, nm in enumerate(['entry -> folded', 'state machine', 'pose -> LDS + barrier', 'evaluate', 'row store']):
+        print('   %-22s %7.0f %7.0f' % (nm, np.median(d[:, i]), d[:, i].max()))
+    print('   in-kernel total median %.0f; launch-to-launch period median %.0f; gap (row stored -> entry of the next) median %.0f'
+          % (np.median(st[:, 5] - st[:, 0]), np.median(np.diff(st[:, 0])), np.median(st[1:, 0] - st[:-1, 5])))
+    P.close()
+
+
+run_lm_fused('c2 5e4 f64', synth.config_c2_twin())
+run_lm_fused('lm1e5 f64', synth.config_c2_twin(seed=7, n_points=100000))
