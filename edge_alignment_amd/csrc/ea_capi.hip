@@ -1097,6 +1097,15 @@ static int batch_build(ea_batch *b) {
   } else {
     ppt_auto = total >= 80000 ? 2 : 1;  // same kernel time at 1e5 points, half the rows for the LM step to fold
   }
+  if (terms.size() == 1 && b->t_fused != 0 && !any_variant) {
+    // A single problem whose evaluation fits one workgroup per CU can run one launch per LM iteration (ea_lm_iter_kernel:
+    // 256-thread workgroups, at most 255 chunks + the writer), which beats every pair-form shape measured
+    // (profiles/r03_ab_fused_shapes.txt: fp64 7e4 points 13.1 -> 11.9 us per iteration, fp32 2e5 points 12.6 -> 12.0): take
+    // the fewest points per lane that fit.
+    const int max_ppt = b->dtype == EA_F32 ? 4 : 2;
+    for (int pp = 1; pp <= max_ppt; pp *= 2)
+      if ((max_n + 256 * pp - 1) / (256 * pp) <= 255) { nt_auto = 256; ppt_auto = pp; break; }
+  }
   int nt = (b->t_nt == 1024 || b->t_nt == 256) ? b->t_nt : nt_auto;
   int ppt = b->t_ppt;
   if (ppt != 1 && ppt != 2 && ppt != 4) ppt = ppt_auto;
@@ -1582,12 +1591,12 @@ static int solve_start(SolveRun &r, const ea_options &o, const LMOptions &lo, co
                              (void *)(intptr_t)b->t_test_stall_ms));
   HIPCHK(hipMemcpyAsync(b->d_lm_block, b->h_lm_block, (size_t)count * (sizeof(PoseState) + sizeof(LMState)),
                         hipMemcpyHostToDevice, b->stream));
-  // One launch per iteration when every workgroup of the evaluation can run the LM step itself for free: LM strategy, one
+  // One launch per iteration when every workgroup of the evaluation can run the LM step itself for free: one
   // plain residual family per problem in 256-thread workgroups on the L2 path, and the whole grid (chunks + the writer,
   // rounded to the XCDs) resident at once -- the kernel holds one workgroup per CU (ea_lm_iter_kernel).
   {
     const int gx = b->xcd_remap ? 8 * ((b->max_chunks + 1 + 7) / 8) : b->max_chunks + 1;
-    r.fused = b->t_fused != 0 && lo.strategy == 0 && b->nt == 256 && !b->any_variant && b->lds_bytes == 0 && !b->wide &&
+    r.fused = b->t_fused != 0 && b->nt == 256 && !b->any_variant && b->lds_bytes == 0 && !b->wide &&
               b->terms_are_groups && b->max_chunks > 0 && (int64_t)gx * count <= 256;
     if (r.fused) {
       if (b->iter_alt_count < count) {

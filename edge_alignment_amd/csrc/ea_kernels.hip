@@ -1730,9 +1730,11 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_step_kernel(
 // into pinned host memory, exactly as ea_lm_step_kernel does them.  Its stores do not sit in any evaluator's memory counter.
 // A finished problem is recognised by every later launch from poses[p].active == 0 (written once, by the writer of the
 // launch in which the state machine stopped; in that launch every workgroup finds out by itself).
-// LM strategy, one plain residual family per problem, 256-thread workgroups, stencil rows from L2; the host only takes this
-// path when the whole grid is resident at once (<= 256 workgroups), see solve_start.
-template <typename T, int PPT, bool BUF, bool IMG32>
+// The cold system (JtJ, Jtr at x for the step after a rejected one; the dogleg's vectors) is read into LDS, one copy per
+// wavefront, and the state machine works on that copy; the writer stores its copy for the next launch.
+// One plain residual family per problem, 256-thread workgroups, stencil rows from L2; the host only takes this path when the
+// whole grid is resident at once (<= 256 workgroups), see solve_start.
+template <typename T, int PPT, bool BUF, bool IMG32, int STRAT>
 __global__ __launch_bounds__(kLmThreads) void ea_lm_iter_kernel(
     // the 14 preloaded dwords: what problem 0's point loads and ROW loads need -- the fold is the head of every workgroup's
     // dependent chain, and its loads must not wait for a scalar load of the argument segment (tile0_* = problem 0's row range)
@@ -1749,6 +1751,7 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_iter_kernel(
   __shared__ double s_acc[kAccSlots];
   __shared__ LMState s_st;
   __shared__ PoseState s_pose[NT / 64];  // one per wavefront (the writer uses the first)
+  __shared__ LMCold s_cold[NT / 64];
   __shared__ int s_trace_it, s_store_system;
   extern __shared__ __align__(16) unsigned char smem[];
   double *s_red = reinterpret_cast<double *>(smem);
@@ -1791,6 +1794,7 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_iter_kernel(
   if (p != 0) gd = groups[p];  // (uniform)
   const int evals_before = st_in[p].num_evals;
   const double state_word = tid < kStateWords ? reinterpret_cast<const double *>(st_in + p)[tid] : 0.0;
+  const double cold_word = (tid & 63) < kColdWords ? reinterpret_cast<const double *>(cold_in + p)[tid & 63] : 0.0;
   // ---- the step, in every workgroup: fold of the previous launch's rows + the state machine on lane 0.
   // The rows are fetched at once, beside the uniforms above and not behind them (as ea_lm_step_kernel does): a launch that
   // finds its problem finished has folded rows nobody reads and leaves below.
@@ -1823,6 +1827,7 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_iter_kernel(
     }
   }
   if (tid < kStateWords) reinterpret_cast<double *>(&s_st)[tid] = state_word;
+  if ((tid & 63) < kColdWords) reinterpret_cast<double *>(&s_cold[tid >> 6])[tid & 63] = cold_word;  // (own wavefront's copy)
   __syncthreads();
   EA_LM_STAMP_PUT(0, evals_before, t_enter_);
   EA_LM_STAMP(1, evals_before);  // folded
@@ -1837,10 +1842,8 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_iter_kernel(
       lm_copy_state(&st, &s_st);
 #pragma unroll
       for (int i = 0; i < kAccSlots; ++i) acc[i] = s_acc[i];
-      // (the LM strategy reads the cold system -- JtJ, Jtr at x after a rejected step -- and never writes it)
-      LMCold *cold = const_cast<LMCold *>(cold_in) + p;
-      if (EA_UNLIKELY(st.num_evals == 0)) lm_begin<0>(&st, cold, traces + p, &opt, acc, &pend);
-      else lm_advance<0>(&st, cold, traces + p, &opt, acc, &pend);
+      if (EA_UNLIKELY(st.num_evals == 0)) lm_begin<STRAT>(&st, &s_cold[0], traces + p, &opt, acc, &pend);
+      else lm_advance<STRAT>(&st, &s_cold[0], traces + p, &opt, acc, &pend);
       make_pose_core(st.cand, st.rot_transposed, st.running, &s_pose[0], /*zero_unused_G=*/false);
       lm_copy_state(&s_st, &st);
       s_trace_it = pend.trace_it;
@@ -1860,9 +1863,10 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_iter_kernel(
       }
       if (tid == 192) { poses[p].unit_q = s_pose[0].unit_q; poses[p].active = s_pose[0].active; }
     }
-    // the cold system of the next launch: this evaluation's (accepted step) or the one this launch read (rejected step)
-    if (!s_store_system && tid < kColdWords)
-      reinterpret_cast<double *>(cold_out + p)[tid] = reinterpret_cast<const double *>(cold_in + p)[tid];
+    // the cold system of the next launch: JtJ, Jtr of this evaluation (accepted step: lm_flush) or what this launch read
+    // (rejected step); the dogleg's vectors as the state machine left them
+    if (tid < kColdWords && !(s_store_system && tid < 27))
+      reinterpret_cast<double *>(cold_out + p)[tid] = reinterpret_cast<const double *>(&s_cold[0])[tid];
     if (tid == 0) lm_flush(&pend, cold_out + p, traces + p, acc);
     if (!running) {
       if (host_states) {
@@ -1910,9 +1914,9 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_iter_kernel(
     lm_copy_state(&st, &s_st);
 #pragma unroll
     for (int i = 0; i < kAccSlots; ++i) acc[i] = s_acc[i];
-    LMCold *cold = const_cast<LMCold *>(cold_in) + p;
-    if (EA_UNLIKELY(st.num_evals == 0)) lm_begin<0, true>(&st, cold, nullptr, &opt, acc, &pend);
-    else lm_advance<0, true>(&st, cold, nullptr, &opt, acc, &pend);
+    LMCold *cold = &s_cold[tid >> 6];
+    if (EA_UNLIKELY(st.num_evals == 0)) lm_begin<STRAT, true>(&st, cold, nullptr, &opt, acc, &pend);
+    else lm_advance<STRAT, true>(&st, cold, nullptr, &opt, acc, &pend);
     EA_LM_STAMP(2, evals_before);  // state machine done
     make_pose_core(st.cand, st.rot_transposed, st.running, &s_ps, /*zero_unused_G=*/false);
     running_v = st.running;
@@ -2315,15 +2319,16 @@ hipError_t launch_lm_iter(int dtype, int ppt, const ProblemDesc *probs, int coun
                           const LMOptions &opt, int *progress, LMState *host_states, LMTrace *host_traces,
                           const GroupDesc &first, hipStream_t stream) {
   if (count <= 0) return hipSuccess;
-  if (chunk <= 0 || chunk > 0xffff || chunk != kLmThreads * ppt || opt.strategy != 0) return hipErrorInvalidValue;
+  if (chunk <= 0 || chunk > 0xffff || chunk != kLmThreads * ppt) return hipErrorInvalidValue;
   const int chunks_per_xcd = (max_chunks + 1 + 7) / 8;
   const dim3 grid(xcd_remap ? chunks_per_xcd * 8 : max_chunks + 1, count);
   const int shape = chunk | ((xcd_remap ? 1 : 0) << 16) | (1 << 17);
   const size_t shmem = (size_t)kHdrBytes;
-#define EA_ITER(T, P, B, I)                                                                                                \
-  hipLaunchKernelGGL((ea_lm_iter_kernel<T, P, B, I>), grid, dim3(kLmThreads), shmem, stream, x0, y0, z0, n0, shape,        \
+#define EA_ITER_S(T, P, B, I, S)                                                                                           \
+  hipLaunchKernelGGL((ea_lm_iter_kernel<T, P, B, I, S>), grid, dim3(kLmThreads), shmem, stream, x0, y0, z0, n0, shape,     \
                      chunks_per_xcd, rows_in, first.tile_begin, first.tile_end, probs, poses, rows_out, groups, st_in, st_out, \
                      cold_in, cold_out, traces, opt, progress, host_states, host_traces)
+#define EA_ITER(T, P, B, I) do { if (opt.strategy == 0) EA_ITER_S(T, P, B, I, 0); else EA_ITER_S(T, P, B, I, 1); } while (0)
 #define EA_ITER_B(T, P, I) do { if (buffer_loads) EA_ITER(T, P, true, I); else EA_ITER(T, P, false, I); } while (0)
   if (dtype == 1) {
     if (img32) return hipErrorInvalidValue;
@@ -2336,6 +2341,7 @@ hipError_t launch_lm_iter(int dtype, int ppt, const ProblemDesc *probs, int coun
   }
 #undef EA_ITER_B
 #undef EA_ITER
+#undef EA_ITER_S
   return hipGetLastError();
 }
 

@@ -2,7 +2,8 @@
 (evaluate, step) pairs it replaces: the same iterates BIT FOR BIT -- same fold order, same state machine, same chunks --
 on the bundled pair, on random small problems (accepted and rejected steps, the three losses, both dtypes, iteration caps,
 a non-unit start quaternion, the transposed-rotation flavour), on small batches, and when a solve is repeated on the same
-handles.  Solves that do not qualify (dogleg, more workgroups than CUs) must take the pair form and say so.  The pair form
+handles, LM and dogleg.  Solves that do not qualify (1024-thread workgroups, more workgroups than CUs) must take the pair
+form and say so.  The pair form
 itself is checked against the oracle in test_gpu_lm_random.py / test_gpu_parity.py."""
 import numpy as np
 import pytest
@@ -70,7 +71,8 @@ def test_random_problems_bit_identical(hip):
                                 planted_q=q_pl, planted_t=t_pl, normalize=bool(trial % 2), pixel_centres=bool(trial % 3))
         loss = [(0, 1.0), (1, 1.0), (1, 0.2), (2, 0.3)][trial % 4]
         dtype = hip.EA_F32 if trial % 3 == 1 else hip.EA_F64
-        opts = dict(max_num_iterations=int(rng.choice([3, 25])))
+        opts = dict(max_num_iterations=int(rng.choice([3, 25])),
+                    strategy=hip.STRATEGY_DOGLEG if trial % 3 == 2 else hip.STRATEGY_LM)
         if trial % 2 == 1:
             opts["min_relative_decrease"] = 0.97
         if trial % 5 == 4:
@@ -129,20 +131,33 @@ def test_solves_that_do_not_qualify_take_the_pairs(hip):
     P = _problem(hip, pr, hip.EA_F64, (1, 1.0))
     B = hip.Batch([P])
     B.solve([1.0, 0, 0, 0], [0.0, 0, 0], strategy=hip.STRATEGY_DOGLEG)
-    assert B.info("fused_iterations") == 0
+    assert B.info("fused_iterations") == 1
     B.solve([1.0, 0, 0, 0], [0.0, 0, 0])
     assert B.info("fused_iterations") == 1
     B.set_tuning("threads", 1024)  # 1024-thread workgroups: the step's registers do not fit beside them
     B.solve([1.0, 0, 0, 0], [0.0, 0, 0])
     assert B.info("fused_iterations") == 0
     B.close(); P.close()
-    # more workgroups than CUs: 8e4 points at one point per lane
+    # more workgroups than CUs: 7e4 points take two points per lane (274 chunks otherwise) and still qualify;
+    # forced to one point per lane they do not
     pr = synth.make_problem(240, 320, 70000, 60, 10, 260.0, 260.0, 159.5, 119.5)
     P = _problem(hip, pr, hip.EA_F64, (1, 1.0))
     B = hip.Batch([P])
     B.solve([1.0, 0, 0, 0], [0.0, 0, 0], max_num_iterations=3)
+    assert B.info("fused_iterations") == 1 and B.info("points_per_thread") == 2
+    B.set_tuning("points_per_thread", 1)
+    B.solve([1.0, 0, 0, 0], [0.0, 0, 0], max_num_iterations=3)
     assert B.info("fused_iterations") == 0
     B.close(); P.close()
+    # two problems of 1.4e5 fp32 points: 2 x 274 chunks
+    pr = synth.make_problem(240, 320, 70000, 60, 11, 260.0, 260.0, 159.5, 119.5)
+    Ps = [_problem(hip, pr, hip.EA_F32, (1, 1.0)) for _ in range(2)]
+    B = hip.Batch(Ps)
+    B.solve([[1.0, 0, 0, 0]] * 2, [[0.0, 0, 0]] * 2, max_num_iterations=3)
+    assert B.info("fused_iterations") == 0
+    B.close()
+    for P in Ps:
+        P.close()
 
 
 def test_start_that_cannot_be_evaluated(hip):
