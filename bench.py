@@ -694,7 +694,25 @@ def main():
                   "lm_iterations_per_solve": its / reps,
                   "lm_solve_ms": lib_ms / reps, "lm_solve_ms_through_ctypes": el / reps * 1e3, "pose_gather_ms": gather_ms,
                   "lm_pose_err_vs_planted": {"rad": err_rot, "m": err_t}})
+        extras["lm_form"] = ("one launch per iteration: every workgroup of the evaluation folds the previous rows, takes the trust-region "
+                             "step itself and evaluates at the candidate pose (ea_lm_iter_kernel); iterates bit-identical to the "
+                             "(evaluate, step) pairs")
         if rank == 0 and world == 1:
+            # the same solves as (evaluate, step) pairs -- rounds 1-2's form of the loop, still what batches and large problems run
+            try:
+                Bp = capi.Batch([P2])
+                Bp.set_tuning("fused_iterations", 0)
+                Bp.solve(q0, t0)
+                itsp, libp = 0, 0.0
+                for _ in range(reps):
+                    qp, tp, sp = Bp.solve(q0, t0)
+                    itsp += sp[0]["num_iterations"]
+                    libp += sp[0]["total_time_ms"]
+                extras["lm_iters_per_s_at_1e5_pts_pair_form"] = {"iters_per_s": itsp / (libp * 1e-3), "solve_ms": libp / reps,
+                                                                 "same_pose_bits": bool(np.array_equal(qp[0], q) and np.array_equal(tp[0], t))}
+                Bp.close()
+            except Exception as e:
+                extras["lm_iters_per_s_at_1e5_pts_pair_form"] = {"error": repr(e)}
             # the same problem in fp32 (the arithmetic of BASELINE configs C3 / C5; pose tolerance 1e-4 rad / 1e-3 m)
             try:
                 P2f = capi.Problem(*cfg2["K"], dtype=capi.EA_F32, device=local_rank)

@@ -441,6 +441,46 @@ class Problem:
                                               C.byref(s)))
         return q, t, summary_to_dict(s)
 
+    def solve_sharded_rows(self, q, t, enqueue_allreduce, agree, **opts):
+        """The one-launch-per-iteration form of the point-sharded solve with the exchange supplied by the caller (what
+        ea_solve_sharded_comm does with RCCL; this binding exists so that the protocol can be rehearsed over gloo):
+        `enqueue_allreduce(ptr, count, stream_ptr)` enqueues the in-place sum over all ranks of `count` doubles of device
+        memory at `ptr`; `agree([cannot, rows]) -> [max, max]` takes two ints to their maximum over the ranks.
+        Returns (q, t, summary, used): used == 0 means some rank's shard does not qualify and nothing was solved."""
+        q = _f64(q).reshape(4).copy()
+        t = _f64(t).reshape(3).copy()
+        o = default_options(**opts)
+        s = Summary()
+        used = C.c_int()
+
+        def _cb(buf, count, stream, _user):
+            try:
+                enqueue_allreduce(int(buf or 0), int(count), int(stream or 0))
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def _agree(vals, _user):
+            try:
+                out = agree([int(vals[0]), int(vals[1])])
+                vals[0], vals[1] = int(out[0]), int(out[1])
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = DEVICE_ALLREDUCE_FN(_cb)
+        ag = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_int), C.c_void_p)(_agree)
+        L = load()
+        L.ea_internal_solve_sharded_rows.restype = C.c_int
+        L.ea_internal_solve_sharded_rows.argtypes = [C.c_void_p, C.c_void_p, DEVICE_ALLREDUCE_FN, type(ag), C.c_void_p, C.POINTER(C.c_double),
+                                                     C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_int)]
+        _check(L.ea_internal_solve_sharded_rows(self._h, C.cast(C.byref(o), C.c_void_p), cb, ag, None, _dp(q), _dp(t),
+                                                C.cast(C.byref(s), C.c_void_p), C.byref(used)))
+        return q, t, summary_to_dict(s), used.value
+
     def solve_sharded_comm(self, q, t, comm, **opts):
         """ea_solve_sharded_comm: the point-sharded solve with ncclAllReduce enqueued by the library itself (no callback)"""
         q = _f64(q).reshape(4).copy()

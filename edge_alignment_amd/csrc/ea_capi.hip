@@ -59,7 +59,7 @@ hipError_t launch_lm_iter(int dtype, int ppt, const ProblemDesc *probs, int coun
                           const void *x0, const void *y0, const void *z0, int n0, const GroupDesc *groups,
                           const LMState *st_in, LMState *st_out, const LMCold *cold_in, LMCold *cold_out, LMTrace *traces,
                           const LMOptions &opt, int *progress, LMState *host_states, LMTrace *host_traces,
-                          const GroupDesc &first, hipStream_t stream);
+                          const GroupDesc &first, int post_done, hipStream_t stream);
 hipError_t launch_pad_image(int dtype, const void *src, int H, int W, void *dst, int pitch, float *dst32, int *inexact,
                             hipStream_t stream);
 hipError_t launch_make_poses(const double *qt, int n, int count, const ProblemDesc *probs, const GroupDesc *groups,
@@ -1647,7 +1647,7 @@ static int solve_pump(SolveRun &r, const LMOptions &lo) {
       const int in = r.enq & 1, out = in ^ 1;
       HIPCHK(launch_lm_iter(b->dtype, b->ppt, b->d_probs, count, b->chunk, b->max_chunks, b->xcd_remap, b->d_poses, rows[in], rows[out],
                             b->buffer_loads, b->img32, b->x0, b->y0, b->z0, b->n0, b->d_groups, st[in], st[out], cold[in], cold[out],
-                            b->d_traces, lo, b->d_progress, b->dv_states, b->dv_traces, b->group0, b->stream));
+                            b->d_traces, lo, b->d_progress, b->dv_states, b->dv_traces, b->group0, /*post_done=*/0, b->stream));
     } else {
       int rc = batch_launch_eval(b);
       if (rc != EA_OK) return rc;
@@ -2620,6 +2620,119 @@ extern "C" int ea_solve_sharded_device(ea_problem *p, const ea_options *opt_in, 
 // level; the solve starts on levels[nlevels-1] and carries the pose down level by level.  Every level is a complete
 // problem (its own points, DT image and intrinsics scaled by the caller).  A level that fails (termination FAILURE)
 // stops the descent and its status is returned through the summaries; q, t hold the last pose reached.
+// The point-sharded solve in the one-launch-per-iteration form (ea_solve_sharded_comm).  Between evaluation and step sits the
+// exchange; with ea_lm_iter_kernel every workgroup folds the rows itself, so what is exchanged is the ROWS: launch j
+// evaluates this rank's shard into its rows, ONE in-place all-reduce sums every rank's rows (a few tens of KB instead of 256
+// bytes -- the same latency-bound collective), launch j + 1 folds the summed rows, steps and evaluates.  Per iteration: one
+// kernel launch + one collective, where the (evaluate, fold, all-reduce, step) form has three launches + one collective.
+// Every rank folds the same bits in the same order, so the replicated state machines stay in lockstep as before.
+// Ranks may hold different numbers of rows (shards differ by a point): `agree` takes {this rank cannot, its row count} to the
+// maximum over the ranks; every rank folds the widest count, its own rows beyond its shard kept at zero.
+// *used = 0: some rank's shard does not qualify (see solve_start) -- the caller falls back to ea_solve_sharded_device.
+extern "C" int ea_internal_solve_sharded_rows(ea_problem *p, const ea_options *opt_in, ea_device_allreduce_fn allreduce,
+                                              int (*agree)(int vals[2], void *user), void *user, double q[4], double t[3],
+                                              ea_summary *summary, int *used) {
+  if (!p || !allreduce || !agree || !q || !t || !used) return fail(EA_ERR_INVALID_ARG, "NULL argument");
+  *used = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  ea_options o;
+  if (opt_in) o = *opt_in; else ea_default_options(&o);
+  if (int vrc = check_options(o)) return vrc;
+  ea_batch *b = nullptr;
+  int rc = self_batch(p, &b);
+  if (rc != EA_OK) return rc;
+  LMOptions lo;
+  lo.max_num_iterations = o.max_num_iterations;
+  lo.function_tolerance = o.function_tolerance;
+  lo.gradient_tolerance = o.gradient_tolerance;
+  lo.parameter_tolerance = o.parameter_tolerance;
+  lo.initial_trust_region_radius = o.initial_trust_region_radius;
+  lo.max_trust_region_radius = o.max_trust_region_radius;
+  lo.min_trust_region_radius = o.min_trust_region_radius;
+  lo.min_relative_decrease = o.min_relative_decrease;
+  lo.min_lm_diagonal = o.min_lm_diagonal;
+  lo.max_lm_diagonal = o.max_lm_diagonal;
+  lo.max_num_consecutive_invalid_steps = o.max_num_consecutive_invalid_steps;
+  lo.jacobi_scaling = o.jacobi_scaling;
+  lo.strategy = o.strategy;
+  SolveRun r;
+  r.b = b;
+  rc = solve_start(r, o, lo, q, t);  // builds the batch, uploads pose + state, arms the progress words, decides r.fused
+  if (rc != EA_OK) return rc;
+  int vals[2] = {r.fused ? 0 : 1, b->ntiles};
+  if (agree(vals, user) != 0) return fail(EA_ERR_STATE, "the ranks could not agree on the shape of the sharded solve");
+  if (vals[0] != 0) { HIPCHK(hipStreamSynchronize(b->stream)); return EA_OK; }  // (*used = 0)
+  const int max_rows = vals[1];
+  if (max_rows > b->tiles_cap || max_rows > b->tiles_cap_alt) {
+    HIPCHK(hipStreamSynchronize(b->stream));
+    cached_free(b->d_partials); cached_free(b->d_partials_alt);
+    b->d_partials = b->d_partials_alt = nullptr;
+    b->tiles_cap = b->tiles_cap_alt = 0;
+    const int cap = max_rows + 16;
+    HIPCHK(cached_malloc(reinterpret_cast<void **>(&b->d_partials), (size_t)cap * kAccSlots * sizeof(double), b->device));
+    b->tiles_cap = cap;
+    HIPCHK(cached_malloc(reinterpret_cast<void **>(&b->d_partials_alt), (size_t)cap * kAccSlots * sizeof(double), b->device));
+    b->tiles_cap_alt = cap;
+  }
+  double *rows[2] = {b->d_partials, b->d_partials_alt};
+  if (max_rows > b->ntiles)
+    for (int k = 0; k < 2; ++k)
+      HIPCHK(hipMemsetAsync(rows[k] + (size_t)b->ntiles * kAccSlots, 0, (size_t)(max_rows - b->ntiles) * kAccSlots * sizeof(double), b->stream));
+  LMState *st[2] = {b->d_states, reinterpret_cast<LMState *>(b->d_iter_alt)};
+  LMCold *cold[2] = {b->d_cold, reinterpret_cast<LMCold *>(b->d_iter_alt + (size_t)b->iter_alt_count * sizeof(LMState))};
+  const GroupDesc fold_range = {0, max_rows, 0, 1};
+  auto exchange = [&](double *buf) -> int {
+    if (allreduce(buf, max_rows * kAccSlots, (void *)b->stream, user) != 0) {
+      b->needs_drain = true;
+      return fail(EA_ERR_STATE, "the all-reduce callback reported a failure");
+    }
+    return EA_OK;
+  };
+  // the look-ahead rule of ea_solve_sharded_device: iteration i + ahead goes out once iteration i is complete unless the solve
+  // had finished by iteration i -- every rank enqueues the same number of launches and collectives
+  const int ahead = o.iterations_per_sync > 0 ? o.iterations_per_sync : 2;
+  const double timeout_ms = resolve_timeout_ms(o);
+  rc = batch_launch_eval(b);  // launch 0: the evaluation at the start pose
+  if (rc != EA_OK) return rc;
+  if ((rc = exchange(rows[0])) != EA_OK) return rc;
+  auto enqueue_iteration = [&]() -> int {
+    const int in = r.enq & 1, out = in ^ 1;
+    HIPCHK(launch_lm_iter(b->dtype, b->ppt, b->d_probs, 1, b->chunk, b->max_chunks, b->xcd_remap, b->d_poses, rows[in], rows[out],
+                          b->buffer_loads, b->img32, b->x0, b->y0, b->z0, b->n0, b->d_groups, st[in], st[out], cold[in], cold[out],
+                          b->d_traces, lo, b->d_progress, b->dv_states, b->dv_traces, fold_range, /*post_done=*/1, b->stream));
+    int rc2 = exchange(rows[out]);
+    if (rc2 != EA_OK) return rc2;
+    ++r.enq;
+    return EA_OK;
+  };
+  for (int k = 0; k < ahead && r.enq < r.budget; ++k)
+    if ((rc = enqueue_iteration()) != EA_OK) return rc;
+  bool finished = false;
+  for (int i = 0; i < r.enq; ++i) {
+    SpinWait wait(timeout_ms);
+    int seen = -1;
+    while (__atomic_load_n(&b->h_progress[2], __ATOMIC_ACQUIRE) < i + 1) {
+      const int started = __atomic_load_n(&b->h_progress[1], __ATOMIC_ACQUIRE);
+      if (started != seen) { seen = started; wait.progress(); }
+      else if (wait.poll()) {
+        b->needs_drain = true;
+        return fail(EA_ERR_HIP, "sharded solve deadline: no progress on the device (is every rank taking part in the collective?)");
+      }
+    }
+    if (__atomic_load_n(&b->h_progress[0], __ATOMIC_ACQUIRE) == 0 && b->hd_states[0].num_evals <= i + 1) { finished = true; break; }
+    if (r.enq < r.budget && (rc = enqueue_iteration()) != EA_OK) return rc;
+  }
+  HIPCHK(hipStreamSynchronize(b->stream));
+  r.fetch = !finished;
+  r.done = true;
+  rc = solve_collect(r, o, summary != nullptr);
+  if (rc != EA_OK) return rc;
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  solve_report(r, o, ms, q, t, summary);
+  *used = 1;
+  return EA_OK;
+}
+
 extern "C" int ea_solve_pyramid(ea_problem *const *levels, int nlevels, const ea_options *opt, double q[4], double t[3],
                                 ea_summary *summaries) {
   if (!levels || nlevels < 1 || !q || !t) return fail(EA_ERR_INVALID_ARG, "bad argument");

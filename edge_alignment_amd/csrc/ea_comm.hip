@@ -20,6 +20,7 @@
 #include <unistd.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -33,6 +34,9 @@
 // ea_capi.hip
 extern "C" int ea_internal_fail(int code, const char *msg);
 extern "C" void *ea_internal_batch_stream(ea_batch *b, int *device);
+extern "C" int ea_internal_solve_sharded_rows(ea_problem *p, const ea_options *opt, ea_device_allreduce_fn allreduce,
+                                              int (*agree)(int vals[2], void *user), void *user, double q[4], double t[3],
+                                              ea_summary *summary, int *used);
 
 namespace {
 
@@ -133,7 +137,8 @@ struct ea_comm {
   int cap = 0;
   double *d_send = nullptr, *d_recv = nullptr, *h_send = nullptr, *h_recv = nullptr;
   double *d_sums = nullptr;            // the 32 accumulator slots of ea_solve_sharded_comm
-  int64_t allreduces = 0, allgathers = 0;
+  int *d_agree = nullptr;              // two ints the ranks take to their maximum before a sharded solve
+  int64_t allreduces = 0, allgathers = 0, row_solves = 0;
   bool spoke = false;                  // the first collective has run (some RCCL builds announce themselves there, not at init)
 };
 
@@ -158,6 +163,7 @@ static int comm_finish(ea_comm *c) {
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_sums), ea::kAccSlots * sizeof(double)));
   HIPCHK(hipMemset(c->d_sums, 0, ea::kAccSlots * sizeof(double)));
+  HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_agree), 2 * sizeof(int)));
   return EA_OK;
 }
 
@@ -166,7 +172,7 @@ extern "C" void ea_comm_destroy(ea_comm *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm && rccl().CommDestroy) (void)rccl().CommDestroy(c->comm);
-  (void)hipFree(c->d_send); (void)hipFree(c->d_recv); (void)hipFree(c->d_sums);
+  (void)hipFree(c->d_send); (void)hipFree(c->d_recv); (void)hipFree(c->d_sums); (void)hipFree(c->d_agree);
   (void)hipHostFree(c->h_send); (void)hipHostFree(c->h_recv);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -323,6 +329,29 @@ extern "C" int ea_solve_sharded_comm(ea_problem *p, const ea_options *opt, ea_co
     cc->allreduces += 1;
     return 0;
   };
+  // First choice: one launch per iteration with the partial ROWS all-reduced in place (ea_internal_solve_sharded_rows) -- every
+  // rank's shard has to qualify, which the ranks settle with one small MAX all-reduce up front.  EA_SHARDED_ROWS=0 in the
+  // environment keeps the (evaluate, fold, all-reduce, step) form (A/B, tests).
+  const char *env = std::getenv("EA_SHARDED_ROWS");
+  if (!(env && env[0] == '0')) {
+    auto agree = [](int vals[2], void *user) -> int {
+      ea_comm *cc = static_cast<ea_comm *>(user);
+      if (hipMemcpyAsync(cc->d_agree, vals, 2 * sizeof(int), hipMemcpyHostToDevice, cc->stream) != hipSuccess) return 1;
+      ncclResult_t r;
+      {
+        StdoutToStderr quiet;  // (may be the communicator's first collective)
+        cc->spoke = true;
+        r = rccl().AllReduce(cc->d_agree, cc->d_agree, 2, ncclInt, ncclMax, cc->comm, cc->stream);
+      }
+      if (r != ncclSuccess) return 1;
+      if (hipMemcpyAsync(vals, cc->d_agree, 2 * sizeof(int), hipMemcpyDeviceToHost, cc->stream) != hipSuccess) return 1;
+      return hipStreamSynchronize(cc->stream) == hipSuccess ? 0 : 1;
+    };
+    int used = 0;
+    int rc = ea_internal_solve_sharded_rows(p, opt, enqueue, agree, c, q, t, summary, &used);
+    if (rc != EA_OK) return rc;
+    if (used) { c->row_solves += 1; return EA_OK; }
+  }
   return ea_solve_sharded_device(p, opt, enqueue, c, c->d_sums, q, t, summary);
 }
 
@@ -331,6 +360,7 @@ extern "C" int ea_comm_get_info(const ea_comm *c, const char *key, int64_t *valu
   const std::string k(key);
   if (k == "allreduces") *value = c->allreduces;
   else if (k == "allgathers") *value = c->allgathers;
+  else if (k == "row_solves") *value = c->row_solves;  // sharded solves that exchanged partial rows (one launch per iteration)
   else if (k == "device") *value = c->device;
   else return fail(EA_ERR_INVALID_ARG, "unknown info key: " + k);
   return EA_OK;

@@ -1744,8 +1744,9 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_iter_kernel(
     double *__restrict__ rows_out, const GroupDesc *__restrict__ groups,
     const LMState *__restrict__ st_in, LMState *__restrict__ st_out, const LMCold *__restrict__ cold_in,
     LMCold *__restrict__ cold_out, LMTrace *__restrict__ traces, LMOptions opt_arg,
-    int *__restrict__ progress /* pinned host: [running x n | evals x n] */,
-    LMState *__restrict__ host_states, LMTrace *__restrict__ host_traces) {
+    int *__restrict__ progress /* pinned host: [running x n | evals x n | steps complete x n] */,
+    LMState *__restrict__ host_states, LMTrace *__restrict__ host_traces,
+    int post_done /* the writer also posts "this step is complete" (progress[2 n + p]): the point-sharded solve's look-ahead rule */) {
   constexpr int NT = kLmThreads;
   __shared__ __align__(16) double s_part[reduce_tiles_lds<NT>()];
   __shared__ double s_acc[kAccSlots];
@@ -1899,6 +1900,12 @@ __global__ __launch_bounds__(kLmThreads) void ea_lm_iter_kernel(
       __syncthreads();
       if (tid == 0) __hip_atomic_store(progress + p, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    // Point-sharded solve (ea_solve_sharded_comm): the rows of this launch are all-reduced over the ranks in place and the
+    // next launch folds the range the widest rank needs; this rank's rows past its own stay zero -- but the all-reduce left
+    // sums there two launches ago, so the writer clears them again.
+    for (int r = pd.tile_end + (tid >> 5); r < gd.tile_end; r += NT / 32) rows_out[(size_t)r * kAccSlots + (tid & 31)] = 0.0;
+    if (post_done && tid == 0)  // behind the flag (same lane, release order), as in ea_lm_step_kernel
+      __hip_atomic_store(progress + 2 * gridDim.y + p, evals_before + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
   // ---- the evaluators: every WAVEFRONT takes the step itself, in the form that yields the candidate pose and nothing else
@@ -2317,7 +2324,7 @@ hipError_t launch_lm_iter(int dtype, int ppt, const ProblemDesc *probs, int coun
                           const void *x0, const void *y0, const void *z0, int n0, const GroupDesc *groups,
                           const LMState *st_in, LMState *st_out, const LMCold *cold_in, LMCold *cold_out, LMTrace *traces,
                           const LMOptions &opt, int *progress, LMState *host_states, LMTrace *host_traces,
-                          const GroupDesc &first, hipStream_t stream) {
+                          const GroupDesc &first, int post_done, hipStream_t stream) {
   if (count <= 0) return hipSuccess;
   if (chunk <= 0 || chunk > 0xffff || chunk != kLmThreads * ppt) return hipErrorInvalidValue;
   const int chunks_per_xcd = (max_chunks + 1 + 7) / 8;
@@ -2327,7 +2334,7 @@ hipError_t launch_lm_iter(int dtype, int ppt, const ProblemDesc *probs, int coun
 #define EA_ITER_S(T, P, B, I, S)                                                                                           \
   hipLaunchKernelGGL((ea_lm_iter_kernel<T, P, B, I, S>), grid, dim3(kLmThreads), shmem, stream, x0, y0, z0, n0, shape,     \
                      chunks_per_xcd, rows_in, first.tile_begin, first.tile_end, probs, poses, rows_out, groups, st_in, st_out, \
-                     cold_in, cold_out, traces, opt, progress, host_states, host_traces)
+                     cold_in, cold_out, traces, opt, progress, host_states, host_traces, post_done)
 #define EA_ITER(T, P, B, I) do { if (opt.strategy == 0) EA_ITER_S(T, P, B, I, 0); else EA_ITER_S(T, P, B, I, 1); } while (0)
 #define EA_ITER_B(T, P, I) do { if (buffer_loads) EA_ITER(T, P, true, I); else EA_ITER(T, P, false, I); } while (0)
   if (dtype == 1) {

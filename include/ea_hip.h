@@ -258,11 +258,15 @@ int ea_comm_size(const ea_comm *c);
  * the same on every rank (BASELINE config C4: 32). */
 int ea_comm_gather_poses(ea_comm *c, ea_batch *after, const double *q, const double *t, const int *status, int count,
                          double *all_q, double *all_t, int *all_status);
-/* ea_solve_sharded_device with the exchange issued by the library itself: per iteration evaluation -> fold ->
- * ncclAllReduce(32 doubles, sum) -> step kernel on one stream, no callback, nothing leaves the device.  Every rank calls
- * it with its shard of the points (and the whole DT image), the same options and the same start pose. */
+/* The point-sharded solve with the exchange issued by the library itself, nothing leaving the device.  Every rank calls it
+ * with its shard of the points (and the whole DT image), the same options and the same start pose.  When every rank's shard
+ * is small enough for one workgroup per CU (settled by one small MAX all-reduce up front) an iteration is ONE kernel launch
+ * + ONE in-place ncclAllReduce of the shard's partial rows (a few tens of KB): the next launch folds the summed rows, takes
+ * the trust-region step in every workgroup and evaluates at the new pose.  Otherwise: evaluation -> fold ->
+ * ncclAllReduce(32 doubles, sum) -> step kernel per iteration (ea_solve_sharded_device's sequence). */
 int ea_solve_sharded_comm(ea_problem *p, const ea_options *opt, ea_comm *c, double q[4], double t[3], ea_summary *summary);
-/* key in {"allreduces", "allgathers", "device"}: collectives enqueued so far (tests: equal on every rank) */
+/* key in {"allreduces", "allgathers", "row_solves", "device"}: collectives enqueued so far (tests: equal on every rank);
+ * sharded solves that took the one-launch-per-iteration form */
 int ea_comm_get_info(const ea_comm *c, const char *key, int64_t *value);
 /* number of HIP runtimes (libamdhip64) mapped in this process.  1 is the only healthy answer: PyTorch-ROCm ships its own
  * copy under the same SONAME, so a process that imports torch FIRST shares one runtime with this library, while loading

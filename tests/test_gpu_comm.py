@@ -38,14 +38,23 @@ def test_pose_gather_and_sharded_solve_on_a_one_rank_communicator(hip):
             P = hip.Problem(*cfg["K"], dtype=dtype)
             P.set_points(cfg["xyz"]); P.set_dt_grid(cfg["grid"]); P.set_loss(hip.LOSS_CAUCHY, 1.0)
             q, t, s = P.solve(Q0, T0)
-            for ahead in (0, 1, 3):
-                before = comm.info("allreduces")
-                q2, t2, s2 = P.solve_sharded_comm(Q0, T0, comm, iterations_per_sync=ahead)
-                assert s2["num_iterations"] == s["num_iterations"] and s2["why"] == s["why"], ahead
-                assert np.abs(q - q2).max() < tol and np.abs(t - t2).max() < tol
-                assert s2["it_cost"] == pytest.approx(s["it_cost"], rel=1e-9 if dtype == hip.EA_F64 else 1e-5)
-                # the look-ahead rule: (iteration the solve finished at) + ahead collectives, on every rank alike
-                assert comm.info("allreduces") - before == s["num_iterations"] + (ahead or 2), ahead
+            for rows_form in (1, 0):
+                # first choice: one launch per iteration, the partial rows all-reduced; EA_SHARDED_ROWS=0: evaluation, fold,
+                # all-reduce of the 32 sums, step
+                os.environ["EA_SHARDED_ROWS"] = str(rows_form)
+                for ahead in (0, 1, 3):
+                    before, rows_before = comm.info("allreduces"), comm.info("row_solves")
+                    q2, t2, s2 = P.solve_sharded_comm(Q0, T0, comm, iterations_per_sync=ahead)
+                    assert comm.info("row_solves") - rows_before == rows_form
+                    assert s2["num_iterations"] == s["num_iterations"] and s2["why"] == s["why"], ahead
+                    if rows_form:   # on one rank: the very launches of ea_solve
+                        assert np.array_equal(q, q2) and np.array_equal(t, t2) and np.array_equal(s2["it_cost"], s["it_cost"])
+                    assert np.abs(q - q2).max() < tol and np.abs(t - t2).max() < tol
+                    assert s2["it_cost"] == pytest.approx(s["it_cost"], rel=1e-9 if dtype == hip.EA_F64 else 1e-5)
+                    # the look-ahead rule: (iteration the solve finished at) + ahead collectives, on every rank alike (the rows
+                    # form exchanges once more, behind the evaluation at the start pose)
+                    assert comm.info("allreduces") - before == s["num_iterations"] + (ahead or 2) + rows_form, (ahead, rows_form)
+            os.environ.pop("EA_SHARDED_ROWS")
             q3, t3, s3 = P.solve_sharded_comm(Q0, T0, comm, strategy=hip.STRATEGY_DOGLEG, max_num_iterations=25)
             q4, t4, s4 = P.solve(Q0, T0, strategy=hip.STRATEGY_DOGLEG, max_num_iterations=25)
             assert s3["num_iterations"] == s4["num_iterations"] and np.abs(q3 - q4).max() < tol

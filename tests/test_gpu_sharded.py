@@ -10,6 +10,7 @@ from edge_alignment_amd import synth
 
 pytestmark = pytest.mark.gpu
 Q0, T0 = np.array([1.0, 0, 0, 0]), np.zeros(3)
+QFAR, TFAR = np.array([np.cos(0.1), 0.6 * np.sin(0.1), 0.0, 0.8 * np.sin(0.1)]), np.array([0.05, -0.04, 0.03])  # 11.5 degrees off
 
 
 def _problem():
@@ -147,6 +148,82 @@ def test_sharded_device_two_ranks(hip, tmp_path):
     assert r0["it"] == s["num_iterations"]
     assert np.abs(r0["q"] - q).max() < 1e-10 and np.abs(r0["t"] - t).max() < 1e-10
     assert r0["cost"] == pytest.approx(s["final_cost"], rel=1e-10)
+
+
+class _DeviceDoubles:
+    """`count` doubles of device memory at `ptr` as an object torch can wrap (the library owns the rows it has all-reduced)"""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def _rows_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    torch.cuda.init()
+    from edge_alignment_amd import capi
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    cfg = _problem()
+    n = cfg["xyz"].shape[0]
+    cut = [0, 20000, n] if world == 2 else [0, n]          # uneven shards: 79 and 40 partial rows
+    X = cfg["xyz"][cut[rank]:cut[rank + 1]]
+    P = capi.Problem(*cfg["K"], dtype=capi.EA_F64, device=0)   # both ranks share the one GPU of the test box
+    P.set_points(X); P.set_dt_grid(cfg["grid"]); P.set_loss(capi.LOSS_CAUCHY, 1.0)
+    calls, counts = [0], set()
+
+    def enqueue(ptr, count, stream):
+        # gloo has no device path: the rows are staged through the host under a synchronisation of the library's stream
+        calls[0] += 1; counts.add(count)
+        ext = torch.cuda.ExternalStream(stream, device=torch.device("cuda", 0))
+        with torch.cuda.stream(ext):
+            rows = torch.as_tensor(_DeviceDoubles(ptr, count), device=torch.device("cuda", 0))
+            h = rows.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            rows.copy_(h)
+
+    def agree(vals):
+        tt = torch.tensor(vals, dtype=torch.int32)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return [int(tt[0]), int(tt[1])]
+    out = {}
+    for name, opts in (("lm", {}), ("dogleg", dict(strategy=capi.STRATEGY_DOGLEG, max_num_iterations=25)), ("capped", dict(max_num_iterations=3)),
+                       ("picky", dict(min_relative_decrease=0.97, max_num_iterations=12, initial_trust_region_radius=1e8, far=1))):
+        calls[0] = 0
+        far = opts.pop("far", 0)
+        q, t, s, used = P.solve_sharded_rows(QFAR if far else Q0, TFAR if far else T0, enqueue, agree, solve_timeout_ms=20000.0, **opts)
+        out.update({name + "_q": q, name + "_t": t, name + "_it": s["num_iterations"], name + "_cost": s["final_cost"],
+                    name + "_calls": calls[0], name + "_used": used, name + "_rej": s["num_unsuccessful_steps"]})
+    out["counts"] = sorted(counts)
+    np.savez(os.path.join(out_dir, "w%d.npz" % rank), **out)
+    P.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_rows_exchange_two_ranks(hip, tmp_path):
+    """The one-launch-per-iteration form of the sharded solve (what ea_solve_sharded_comm runs over RCCL), rehearsed over gloo
+    with two ranks on the one GPU and UNEVEN shards (79 and 40 partial rows: both ranks fold 79, the shorter one keeps zeros
+    behind its own): lockstep iterates, the same number of exchanges on both ranks, the whole problem's solution."""
+    import torch.multiprocessing as mp
+    cfg = _problem()
+    P = hip.Problem(*cfg["K"], dtype=hip.EA_F64)
+    P.set_points(cfg["xyz"]); P.set_dt_grid(cfg["grid"]); P.set_loss(hip.LOSS_CAUCHY, 1.0)
+    ref = {"lm": P.solve(Q0, T0), "dogleg": P.solve(Q0, T0, strategy=hip.STRATEGY_DOGLEG, max_num_iterations=25),
+           "capped": P.solve(Q0, T0, max_num_iterations=3),
+           "picky": P.solve(QFAR, TFAR, min_relative_decrease=0.97, max_num_iterations=12, initial_trust_region_radius=1e8)}
+    P.close()
+    mp.spawn(_rows_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "w0.npz"), np.load(tmp_path / "w1.npz")
+    assert list(r0["counts"]) == list(r1["counts"]) == [79 * 32]
+    for name, (q, t, s) in ref.items():
+        assert r0[name + "_used"] == 1 and r1[name + "_used"] == 1, name
+        assert np.array_equal(r0[name + "_q"], r1[name + "_q"]) and np.array_equal(r0[name + "_t"], r1[name + "_t"]), name   # lockstep
+        assert r0[name + "_it"] == r1[name + "_it"] == s["num_iterations"], name
+        assert r0[name + "_calls"] == r1[name + "_calls"] == s["num_iterations"] + 2 + 1, name   # prologue + look-ahead rule
+        assert np.abs(r0[name + "_q"] - q).max() < 1e-10 and np.abs(r0[name + "_t"] - t).max() < 1e-10, name
+        assert r0[name + "_cost"] == pytest.approx(s["final_cost"], rel=1e-10), name
+        assert r0[name + "_rej"] == r1[name + "_rej"] == s["num_unsuccessful_steps"], name
+    # (rejected steps -- the cold system travelling through the launches -- are exercised by tests/test_gpu_fused_iterations.py)
 
 
 def _rccl_worker(rank, world, port, out_dir):
