@@ -903,7 +903,9 @@ def main():
             P3.set_points(cfg2["xyz"][sl]); P3.set_dt_grid(cfg2["grid"]); P3.set_loss(*loss2)
             if comm is not None:
                 solve4 = lambda: P3.solve_sharded_comm(q0, t0, comm)
-                exchange = "ncclAllReduce of 32 doubles per iteration, enqueued by the library (ea_solve_sharded_comm), %d-rank communicator" % world
+                exchange = ("ea_solve_sharded_comm on a %d-rank communicator: per iteration ONE kernel launch (fold of the summed rows, "
+                            "trust-region step and evaluation in every workgroup) + ONE in-place ncclAllReduce of the shard's partial rows "
+                            "when every shard fits one workgroup per CU, else evaluation -> fold -> ncclAllReduce(32 doubles) -> step" % world)
             else:
                 sums, enqueue = ead.make_device_allreduce(world, torch.device("cuda", local_rank), force_collective=multi)
                 solve4 = lambda: P3.solve_sharded_device(q0, t0, enqueue, sums.data_ptr())
@@ -918,8 +920,14 @@ def main():
                 lib4 += s4["total_time_ms"]
             barrier_sync()
             el4 = time.perf_counter() - ts
+            rows_form = None
+            if comm is not None:
+                try:
+                    rows_form = bool(comm.info("row_solves") > 0)
+                except Exception:
+                    pass
             extras["lm_point_sharded_device_1e5_pts"] = {"iters_per_s": its4 / (lib4 * 1e-3), "iters_per_s_through_ctypes": its4 / el4,
-                                                         "solve_ms": lib4 / reps4, "exchange": exchange,
+                                                         "solve_ms": lib4 / reps4, "exchange": exchange, "rows_exchanged": rows_form,
                                                          "points_per_gpu": int(sl.stop - sl.start),
                                                          "pose_err_vs_planted": {"rad": synth.rotation_angle_between(q4, cfg2["q_true"]),
                                                                                  "m": float(np.linalg.norm(t4 - cfg2["t_true"]))}}
