@@ -397,7 +397,7 @@ def main():
     # The untimed runs of the region are rehearsals of the WHOLE bracket (barrier + sync, clock, the call, barrier + sync, clock),
     # so that the one that counts -- always the last, never the best -- does not also pay for the first execution of the
     # bracket's own host code (a one-shot bracket reads ~45 us where the same bracket in a loop reads ~37:
-    # scripts/probe_oneshot.py).
+    # scripts/archive/probe_oneshot.py).
     for _ in range(warm_replays + 1):
         barrier_sync()
         t_start = time.perf_counter()

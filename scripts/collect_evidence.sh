@@ -1,5 +1,7 @@
 #!/bin/bash
-# round 3, fifth GPU visit: the committed evidence -- bench lines, rocprofv3 kernel-trace stats of the same commands, PMC passes
+# The round's committed evidence in one GPU visit: the GPU suite, bench lines, rocprofv3 kernel-trace stats of the same commands,
+# PMC passes, the same-box A/Bs of the LM loop's forms, one run of each soak.  Summaries land in gpurun_out/r03e/ and are
+# copied into profiles/ by hand (profiles/README.md says which).
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03e; mkdir -p $O
 cd $R
@@ -15,6 +17,11 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_sharded -o k -- python3 $R/scripts/prof_sharded.py > $O/kt_sharded.log 2>&1; echo "kernel-trace sharded rc=$?"
 tail -3 $O/kt_sharded.log
 cd $R
+timeout -k 10 300 python scripts/ab_fused_iterations.py 5 > $O/ab_fused_iterations.txt 2>&1; echo "ab fused iterations rc=$?"; grep -v "^{" $O/ab_fused_iterations.txt | cut -c1-260
+timeout -k 10 300 python scripts/ab_sharded_rows.py > $O/ab_sharded_rows.txt 2>&1; echo "ab sharded rows rc=$?"; grep "it/s" $O/ab_sharded_rows.txt
+timeout -k 10 200 python scripts/stamps.py > $O/lm_stamps.txt 2>&1; echo "stamps rc=$?"; tail -16 $O/lm_stamps.txt
+timeout -k 10 400 python scripts/soak.py 120 777 > $O/soak.txt 2>&1; echo "soak rc=$?"; tail -2 $O/soak.txt | cut -c1-400
+timeout -k 10 400 python scripts/soak_variants.py 100 4321 > $O/soak_variants.txt 2>&1; echo "soak variants rc=$?"; tail -2 $O/soak_variants.txt | cut -c1-400
 STEPS=20 bash scripts/pmc_traffic_bench.sh > $O/pmc_traffic_bench.txt 2>&1; echo "pmc traffic (20 poses) rc=$?"
 STEPS=2000 bash scripts/pmc_traffic_bench.sh >> $O/pmc_traffic_bench.txt 2>&1; echo "pmc traffic (2000 poses) rc=$?"; grep -n "hbm_bytes_per_launch\|_poses_" $O/pmc_traffic_bench.txt | tail -12
 STEPS=20 bash scripts/pmc_busy.sh > $O/pmc_busy.txt 2>&1; echo "pmc busy (20) rc=$?"
