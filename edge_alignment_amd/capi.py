@@ -28,7 +28,7 @@ EXPORTED = [
     "ea_problem_set_points_device", "ea_problem_set_dt", "ea_problem_set_dt_image_device",
     "ea_problem_set_loss", "ea_problem_set_flavour", "ea_problem_num_points",
     "ea_eval", "ea_eval_points", "ea_cost", "ea_problem_pixel_cost", "ea_solve",
-    "ea_release_cached_memory", "ea_batch_create", "ea_batch_destroy", "ea_batch_count", "ea_batch_eval", "ea_batch_solve",
+    "ea_release_cached_memory", "ea_host_alloc", "ea_host_free", "ea_batch_create", "ea_batch_destroy", "ea_batch_count", "ea_batch_eval", "ea_batch_solve",
     "ea_batch_eval_poses", "ea_batch_set_poses", "ea_batch_eval_resident_poses",
     "ea_solve_pyramid", "ea_solve_sharded", "ea_solve_sharded_device",
     "ea_comm_get_unique_id", "ea_comm_create", "ea_comm_create_all", "ea_comm_destroy", "ea_comm_rank", "ea_comm_size",
@@ -679,6 +679,36 @@ class Comm:
         v = C.c_int64()
         _check(load().ea_comm_get_info(self._h, key.encode(), C.byref(v)))
         return v.value
+
+
+class _Pinned:
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            load().ea_host_free(C.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+def pinned_array(shape, dtype, device=0):
+    """a numpy array in page-locked host memory (ea_host_alloc): frames handed to the producers / the tracker from such an
+    array go up as direct DMA.  The memory is freed when the array (and every view of it) is gone."""
+    L = load()
+    L.ea_host_alloc.restype = C.c_void_p
+    L.ea_host_alloc.argtypes = [C.c_size_t, C.c_int]
+    L.ea_host_free.restype = None
+    L.ea_host_free.argtypes = [C.c_void_p]
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    ptr = L.ea_host_alloc(max(n, 1), int(device))
+    if not ptr:
+        raise EAError(-1, L.ea_last_error().decode())
+    owner = _Pinned(ptr)
+    buf = (C.c_uint8 * max(n, 1)).from_address(ptr)
+    buf._owner = owner   # keeps the block alive as long as the ctypes buffer (the array's base) lives
+    return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
 
 
 def graph_floor_ms(device=0, nodes=200, grid=196, block=256):

@@ -480,6 +480,20 @@ static int check_device(int device) {
 }
 
 extern "C" const char *ea_last_error(void) { return g_err.c_str(); }
+
+extern "C" void *ea_host_alloc(size_t bytes, int device) {
+  if (bytes == 0) { fail(EA_ERR_INVALID_ARG, "ea_host_alloc: zero bytes"); return nullptr; }
+  if (check_device(device) != EA_OK) return nullptr;
+  void *p = nullptr;
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipHostMalloc(&p, bytes, hipHostMallocPortable);
+  if (e != hipSuccess) { fail(EA_ERR_ALLOC, std::string("ea_host_alloc: ") + hipGetErrorString(e)); return nullptr; }
+  return p;
+}
+
+extern "C" void ea_host_free(void *p) {
+  if (p) (void)hipHostFree(p);
+}
 extern "C" const char *ea_version(void) { return "edge_alignment_amd 0.2 (gfx950)"; }
 
 extern "C" int ea_device_count(int *count) {

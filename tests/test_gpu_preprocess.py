@@ -319,6 +319,29 @@ def test_frame_to_frame_tracker(hip, flavour):
     T.close(); P.close()
 
 
+def test_frames_in_page_locked_memory(hip):
+    """ea_host_alloc: frames handed over from page-locked memory (direct DMA instead of the runtime's staged copy) give
+    what the same frames give from ordinary memory, bit for bit; the block is plain host memory and can be freed."""
+    from oracle import preprocess_np as pp
+    seq = [(pp.load_rgb_as_bgr(os.path.join(G, "rgb_%d.png" % i)), pp.load_depth_u16(os.path.join(G, "depth_%d.png" % i))) for i in range(1, 4)]
+    TA, TB = hip.Tracker(*K, dtype=hip.EA_F64, loss=(hip.LOSS_CAUCHY, 1.0)), hip.Tracker(*K, dtype=hip.EA_F64, loss=(hip.LOSS_CAUCHY, 1.0))
+    for bgr, depth in seq:
+        pb = hip.pinned_array(bgr.shape, bgr.dtype); pb[...] = bgr
+        pd = hip.pinned_array(depth.shape, depth.dtype); pd[...] = depth
+        qa, ta, sa = TA.push_frame(bgr, depth)
+        qb, tb, sb = TB.push_frame(pb, pd)
+        assert np.array_equal(qa, qb) and np.array_equal(ta, tb)
+        assert (sa is None) == (sb is None) and (sa is None or sa["final_cost"] == sb["final_cost"])
+        del pb, pd   # (freed: the library copied what it needs)
+    TA.close(); TB.close()
+    L = hip.load()
+    import ctypes as C
+    L.ea_host_alloc.restype = C.c_void_p
+    L.ea_host_alloc.argtypes = [C.c_size_t, C.c_int]
+    assert L.ea_host_alloc(0, 0) is None and b"zero" in L.ea_last_error()
+    assert L.ea_host_alloc(64, 9999) is None
+
+
 def test_random_frame_sizes_all_flavours(hip, frames):
     """Widths / heights on both sides of the kernels' tile sizes (16, 32, 64, 256), tiny frames, thin strips, dense
     noise: every producer of the three flavours bit for bit against the restatement; frames with an extent below 3
