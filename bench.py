@@ -525,13 +525,14 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_launch, "algorithmic_bytes_per_evaluation": bytes_eval,
                 "launch_floor_ms": floor_ms,
                 # (what the launch mechanism alone would allow this grid; above 1 it has stopped being the bound)
-                "frac_ceiling_at_floor": (bytes_launch / (floor_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if floor_ms else None,
+                # (what the launch mechanism alone allows: 1.0 = the launch is long enough for the floor not to bind)
+                "frac_ceiling_at_floor": min(1.0, bytes_launch / (floor_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if floor_ms else None,
                 # the same kernel with ONE pose per launch (what an LM iteration launches; rounds 1-2's headline kernel):
                 # a launch of 196 workgroups is bounded by the launch mechanism, not by the chip
                 "one_pose_per_launch": {"kernel_ms_back_to_back": ms_kernel_b2b,
                                         "frac": bytes_eval / (ms_kernel_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                         "launch_floor_ms": floor_one_ms,
-                                        "frac_ceiling_at_floor": (bytes_eval / (floor_one_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if floor_one_ms else None,
+                                        "frac_ceiling_at_floor": min(1.0, bytes_eval / (floor_one_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if floor_one_ms else None,
                                         "kernel_ms_isolated": ms_kernel_isolated, "fold_kernel_ms": ms_fold,
                                         "step_ms_events_serial_dependent": step_ms_serial, "step_ms_events_eager_launches": step_ms_eager,
                                         "counter_busy": counter_busy(args.workload, ms_kernel_b2b)},

@@ -562,12 +562,107 @@ EA_HD inline void lm_begin(LMState *s, LMCold *c, LMTrace *tr, const LMOptions *
   lm_prepare_next<STRAT, LITE>(s, c, tr, o, acc, true);
 }
 
+// The usual iteration of the LM strategy as ONE straight line: usable evaluation, no convergence test fires, the step is
+// accepted, the factorisation succeeds and the model cost decreases.  It is lm_advance's own arithmetic, statement for
+// statement and in the same order (so both give the same bits), minus the joins: in the general form every variable that the
+// accept and the reject branch, the fresh and the stored system, the valid and the invalid step set differently is copied at
+// the join, and on the one lane that runs this code a register move costs what an FMA costs -- roughly a third of the
+// instructions of an iteration were moves.  Works on locals and commits at the end: on anything unusual it returns false with
+// *s and *pend untouched, and the caller runs the general form.
+template <bool LITE>
+EA_HD inline bool lm_advance_fast(LMState *s, const LMOptions *o, const double acc[kAccSlots], LMPending *pend) {
+  if (EA_UNLIKELY(!lm_eval_usable(acc))) return false;
+  const double cand_cost = acc[kAccCost];
+  double dx[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) dx[i] = s->x[i] - s->cand[i];
+  const double step_norm = norm_n(dx, 7);
+  if (EA_UNLIKELY(step_norm <= o->parameter_tolerance * (s->x_norm + o->parameter_tolerance))) return false;
+  const double cost_change = s->cost - cand_cost;
+  if (EA_UNLIKELY(fabs(cost_change) <= o->function_tolerance * s->cost)) return false;
+  const double rel = cost_change / s->model_cost_change;
+  if (EA_UNLIKELY(!(rel > o->min_relative_decrease))) return false;
+  // accepted: the system of this evaluation is the system at the new x
+  double x_norm = s->x_norm, gradient_max_norm = s->gradient_max_norm;
+  if constexpr (!LITE) {
+    x_norm = norm_n(s->cand, 7);
+    double neg[6], xp[7], m = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) neg[i] = -acc[kAccJtr + i];
+    pose_plus(s->cand, neg, xp, /*small_expected=*/false);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) m = fmax(m, fabs(s->cand[i] - xp[i]));
+    gradient_max_norm = m;
+  }
+  const double f = 2.0 * rel - 1.0;
+  double radius = s->radius / fmax(1.0 / 3.0, 1.0 - f * f * f);
+  radius = fmin(o->max_trust_region_radius, radius);
+  // top of the next iteration
+  if (EA_UNLIKELY(s->iteration >= o->max_num_iterations)) return false;
+  if constexpr (!LITE)
+    if (EA_UNLIKELY(gradient_max_norm <= o->gradient_tolerance)) return false;
+  if (EA_UNLIKELY(radius <= o->min_trust_region_radius)) return false;
+  double As[21], gs[6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    gs[a] = acc[kAccJtr + a] * s->S[a];
+#pragma unroll
+    for (int b = a; b < 6; ++b) As[sym6(a, b)] = acc[kAccJtJ + sym6(a, b)] * s->S[a] * s->S[b];
+  }
+  double diagonal[6], D2[6], y[6], step[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) diagonal[i] = fmin(fmax(As[sym6(i, i)], o->min_lm_diagonal), o->max_lm_diagonal);
+  const double inv_radius = ea_rcp(radius);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) D2[i] = diagonal[i] * inv_radius;
+  if (EA_UNLIKELY(!solve_spd6(As, D2, gs, y))) return false;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) step[i] = -y[i];
+  double gts = 0.0, diag = 0.0, off = 0.0;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    gts += gs[a] * step[a];
+    diag += step[a] * As[sym6(a, a)] * step[a];
+#pragma unroll
+    for (int b = a + 1; b < 6; ++b) off += step[a] * As[sym6(a, b)] * step[b];
+  }
+  const double model_cost_change = -(gts + 0.5 * (diag + 2.0 * off));
+  if (EA_UNLIKELY(!(model_cost_change > 0.0))) return false;
+  double delta[6], cand[7];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) delta[i] = step[i] * s->S[i];
+  pose_plus(s->cand, delta, cand);
+  // ---- commit (the order of lm_advance: trace row of the accepted step, then the new iteration's state)
+  pend->store_system = 1;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) s->x[i] = s->cand[i];
+  s->x_norm = x_norm;
+  s->cost = cand_cost;
+  s->gradient_max_norm = gradient_max_norm;
+  s->num_evals += 1;
+  s->num_successful += 1;
+  s->radius = radius;
+  s->decrease_factor = 2.0;
+  lm_pend_trace(s, pend, s->iteration, cost_change, step_norm, rel, 1);
+  s->iteration += 1;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) s->diagonal[i] = diagonal[i];
+  s->reuse_diagonal = 1;
+  s->model_cost_change = model_cost_change;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) s->cand[i] = cand[i];
+  s->num_consecutive_invalid = 0;
+  return true;
+}
+
 // after the evaluation at s->cand
 template <int STRAT, bool LITE = false>
 EA_HD inline void lm_advance(LMState *s, LMCold *c, LMTrace *tr, const LMOptions *o, const double acc[kAccSlots],
                              LMPending *pend) {
   pend->store_system = 0;
   pend->trace_it = -1;
+  if constexpr (STRAT == 0)
+    if (EA_LIKELY(lm_advance_fast<LITE>(s, o, acc, pend))) return;
   s->num_evals += 1;
   const bool eval_ok = lm_eval_usable(acc);  // (false: the step is rejected like one that raised the cost)
   const double cand_cost = eval_ok ? acc[kAccCost] : DBL_MAX;

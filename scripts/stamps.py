@@ -40,11 +40,16 @@ def run_lm(name, cfg):
     st = np.zeros((128, 8), dtype=np.uint64)
     assert L.ea_debug_lm_stamps_end(st.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
     st = st.astype(np.int64); pr = st[64:]; st = st[:64]
+    st_all = st
     keep = (st[:, 5] > 0) & (pr[:, 5] > 0) & (pr[:, 1] > 0)
     pr = pr[keep]; st = st[keep]
     seq = np.concatenate([st[:, 2:3], pr[:, :2], pr[:, 6:8], pr[:, 2:6], st[:, 3:4]], axis=1)
     dd = np.diff(seq, axis=1)
-    for i, nm in enumerate(['tests+rel', 'take_system', 'radius update', 'trace', 'checks+scale', 'strategy step', 'model change', 'pose_plus', 'tail']):
+    if len(dd) == 0:
+        # (the usual iteration runs lm_advance_fast, which carries no probes: only launches that took the general form have them)
+        print('      no iteration with state-machine probes captured (the usual iteration takes lm_advance_fast)')
+        st = st_all[st_all[:, 5] > 0]
+    for i, nm in enumerate([] if len(dd) == 0 else ['tests+rel', 'take_system', 'radius update', 'trace', 'checks+scale', 'strategy step', 'model change', 'pose_plus', 'tail']):
         print('      probe %-14s %7.0f %7.0f' % (nm, np.median(dd[:, i]), dd[:, i].max()))
     d = np.diff(st[:, :6], axis=1)
     names = ['running load', 'stage+fold', 'lm_advance', 'make_pose_state', 'publish+store']

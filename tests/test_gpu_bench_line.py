@@ -44,8 +44,8 @@ def test_driver_command_prints_one_valid_line(hip):
     assert r["traffic"] is None or r["traffic"] / r["algorithmic_bytes_per_launch"] < 2.0
     assert r["secondary"]["bound"].startswith("valu")
     assert 5e-4 < r["launch_floor_ms"] < r["kernel_ms"]
-    assert abs(r["frac_ceiling_at_floor"] - r["algorithmic_bytes_per_launch"] / (r["launch_floor_ms"] * 1e-3) / 1e9 / r["peak"]) <= 1e-9
-    assert r["frac"] < min(1.0, r["frac_ceiling_at_floor"])
+    assert abs(r["frac_ceiling_at_floor"] - min(1.0, r["algorithmic_bytes_per_launch"] / (r["launch_floor_ms"] * 1e-3) / 1e9 / r["peak"])) <= 1e-9
+    assert r["frac"] < r["frac_ceiling_at_floor"] <= 1.0
     # the same kernel at one pose per launch (an LM iteration's launch) and the dependent two-launch step, beside the headline
     o = r["one_pose_per_launch"]
     assert 1e-3 < o["kernel_ms_back_to_back"] < 1e-2 and 5e-4 < o["launch_floor_ms"] < o["kernel_ms_back_to_back"]
