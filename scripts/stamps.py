@@ -83,5 +83,6 @@ def run_lm_fused(name, cfg, dtype=capi.EA_F64):
     P.close()
 
 
+run_lm_fused('c1-size 1482 f64', synth.config_c2_twin(seed=7, n_points=1482))
 run_lm_fused('c2 5e4 f64', synth.config_c2_twin())
 run_lm_fused('lm1e5 f64', synth.config_c2_twin(seed=7, n_points=100000))
