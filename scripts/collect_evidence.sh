@@ -22,6 +22,7 @@ timeout -k 10 300 python scripts/ab_sharded_rows.py > $O/ab_sharded_rows.txt 2>&
 timeout -k 10 200 python scripts/stamps.py > $O/lm_stamps.txt 2>&1; echo "stamps rc=$?"; tail -16 $O/lm_stamps.txt
 timeout -k 10 400 python scripts/soak.py 120 777 > $O/soak.txt 2>&1; echo "soak rc=$?"; tail -2 $O/soak.txt | cut -c1-400
 timeout -k 10 400 python scripts/soak_variants.py 100 4321 > $O/soak_variants.txt 2>&1; echo "soak variants rc=$?"; tail -2 $O/soak_variants.txt | cut -c1-400
+timeout -k 10 400 python scripts/soak_fused.py 100 2025 > $O/soak_fused.txt 2>&1; echo "soak fused rc=$?"; tail -1 $O/soak_fused.txt | cut -c1-400
 STEPS=20 bash scripts/pmc_traffic_bench.sh > $O/pmc_traffic_bench.txt 2>&1; echo "pmc traffic (20 poses) rc=$?"
 STEPS=2000 bash scripts/pmc_traffic_bench.sh >> $O/pmc_traffic_bench.txt 2>&1; echo "pmc traffic (2000 poses) rc=$?"; grep -n "hbm_bytes_per_launch\|_poses_" $O/pmc_traffic_bench.txt | tail -12
 STEPS=20 bash scripts/pmc_busy.sh > $O/pmc_busy.txt 2>&1; echo "pmc busy (20) rc=$?"
