@@ -661,8 +661,10 @@ EA_HD inline void lm_advance(LMState *s, LMCold *c, LMTrace *tr, const LMOptions
                              LMPending *pend) {
   pend->store_system = 0;
   pend->trace_it = -1;
+#ifndef EA_LM_NO_FAST_PATH  // (tests/test_lm_host_logic.py builds the host shim both ways: the two must agree bit for bit)
   if constexpr (STRAT == 0)
     if (EA_LIKELY(lm_advance_fast<LITE>(s, o, acc, pend))) return;
+#endif
   s->num_evals += 1;
   const bool eval_ok = lm_eval_usable(acc);  // (false: the step is rejected like one that raised the cost)
   const double cand_cost = eval_ok ? acc[kAccCost] : DBL_MAX;

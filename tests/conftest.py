@@ -76,6 +76,21 @@ def lm_host_shim():
 
 
 @pytest.fixture(scope="session")
+def lm_host_shim_general(lm_host_shim):
+    """the same shim without lm_advance_fast (-DEA_LM_NO_FAST_PATH): every iteration through the general form"""
+    import ctypes as C
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    so = os.path.join(out_dir, "libea_lm_host_general.so")
+    src = os.path.join(ROOT, "tests", "lm_host_shim.cpp")
+    deps = [src, os.path.join(ROOT, "edge_alignment_amd", "csrc", "ea_lm.h"),
+            os.path.join(ROOT, "edge_alignment_amd", "csrc", "ea_types.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-DEA_LM_NO_FAST_PATH",
+                               "-I", os.path.join(ROOT, "edge_alignment_amd", "csrc"), "-o", so, src])
+    return C.CDLL(so)
+
+
+@pytest.fixture(scope="session")
 def hip():
     """libea_hip.so through the ctypes stub.  GPU tests must fail loudly (not skip) when the
     library is missing or no device is usable."""

@@ -77,6 +77,39 @@ def test_shipped_lm_follows_oracle_iterates_on_bundled_pair(lm_host_shim, oracle
     assert list(out.it_successful[:n]) == list(s["it_successful"])
 
 
+def test_fast_path_and_general_form_agree_bit_for_bit(lm_host_shim, lm_host_shim_general, oracle):
+    """lm_advance_fast (the usual iteration as one straight line) is lm_advance's own arithmetic in the same order: on the
+    host, where nothing is contracted, every iterate of random solves -- accepted and rejected steps, caps, the three
+    losses -- must come out the same with and without it."""
+    from edge_alignment_amd import synth
+    rng = np.random.default_rng(31)
+    rejected = 0
+    for trial in range(12):
+        pr = synth.make_problem(60, 80, int(rng.integers(200, 900)), 12, 700 + trial, 65.0, 65.0, 39.5, 29.5,
+                                planted_q=synth.quat_from_axis_angle(rng.standard_normal(3), np.deg2rad(rng.uniform(0.3, 2.0))),
+                                planted_t=tuple(rng.uniform(-0.03, 0.03, 3)), normalize=bool(trial % 2))
+        loss = [(0, 1.0), (1, 1.0), (1, 0.2), (2, 0.3)][trial % 4]
+        P = oracle.OracleProblem(pr["grid"], *pr["K"], loss=loss[0], loss_a=loss[1])
+        kw = dict(max_num_iterations=int(rng.choice([4, 30])))
+        if trial % 2:
+            kw["min_relative_decrease"] = 0.97
+        if trial % 3 == 2:
+            q0, t0 = synth.quat_from_axis_angle(rng.standard_normal(3), np.deg2rad(12.0)), rng.uniform(-0.2, 0.2, 3)
+            kw["initial_trust_region_radius"] = 1e8
+        else:
+            q0, t0 = np.array([1.0, 0, 0, 0]), np.zeros(3)
+        a = _run(lm_host_shim, P, oracle, pr["xyz"], q0, t0, **kw)
+        b = _run(lm_host_shim_general, P, oracle, pr["xyz"], q0, t0, **kw)
+        assert list(a.x[:]) == list(b.x[:]) and a.iteration == b.iteration and a.why == b.why and a.termination == b.termination, trial
+        assert a.num_successful == b.num_successful and a.num_unsuccessful == b.num_unsuccessful and a.num_evals == b.num_evals
+        assert a.final_cost == b.final_cost
+        n = a.iteration + 1
+        assert list(a.it_cost[:n]) == list(b.it_cost[:n]) and list(a.it_radius[:n]) == list(b.it_radius[:n])
+        assert list(a.it_successful[:n]) == list(b.it_successful[:n])
+        rejected += int(a.num_unsuccessful > 0)
+    assert rejected >= 1
+
+
 def test_shipped_lm_failure_and_limits(lm_host_shim, oracle):
     pr = synth.make_problem(120, 160, 600, 40, 21, 130.0, 130.0, 79.5, 59.5,
                             planted_q=synth.quat_from_axis_angle([1, 2, 3], np.deg2rad(1.0)), planted_t=(0.01, -0.005, 0.02), normalize=True)
