@@ -569,8 +569,8 @@ EA_HD inline void lm_begin(LMState *s, LMCold *c, LMTrace *tr, const LMOptions *
 // the join, and on the one lane that runs this code a register move costs what an FMA costs -- roughly a third of the
 // instructions of an iteration were moves.  Works on locals and commits at the end: on anything unusual it returns false with
 // *s and *pend untouched, and the caller runs the general form.
-template <bool LITE>
-EA_HD inline bool lm_advance_fast(LMState *s, const LMOptions *o, const double acc[kAccSlots], LMPending *pend) {
+template <int STRAT, bool LITE>
+EA_HD inline bool lm_advance_fast(LMState *s, LMCold *c, const LMOptions *o, const double acc[kAccSlots], LMPending *pend) {
   if (EA_UNLIKELY(!lm_eval_usable(acc))) return false;
   const double cand_cost = acc[kAccCost];
   double dx[7];
@@ -594,9 +594,16 @@ EA_HD inline bool lm_advance_fast(LMState *s, const LMOptions *o, const double a
     for (int i = 0; i < 7; ++i) m = fmax(m, fabs(s->cand[i] - xp[i]));
     gradient_max_norm = m;
   }
-  const double f = 2.0 * rel - 1.0;
-  double radius = s->radius / fmax(1.0 / 3.0, 1.0 - f * f * f);
-  radius = fmin(o->max_trust_region_radius, radius);
+  double radius = s->radius;
+  if constexpr (STRAT == 0) {
+    const double f = 2.0 * rel - 1.0;
+    radius = s->radius / fmax(1.0 / 3.0, 1.0 - f * f * f);
+    radius = fmin(o->max_trust_region_radius, radius);
+  } else {
+    if (rel < 0.25) radius *= 0.5;
+    if (rel > 0.75) radius = fmax(radius, 3.0 * s->dogleg_step_norm);
+    radius = fmin(radius, o->max_trust_region_radius);
+  }
   // top of the next iteration
   if (EA_UNLIKELY(s->iteration >= o->max_num_iterations)) return false;
   if constexpr (!LITE)
@@ -610,14 +617,72 @@ EA_HD inline bool lm_advance_fast(LMState *s, const LMOptions *o, const double a
     for (int b = a; b < 6; ++b) As[sym6(a, b)] = acc[kAccJtJ + sym6(a, b)] * s->S[a] * s->S[b];
   }
   double diagonal[6], D2[6], y[6], step[6];
+  // (dogleg) what lm_strategy_step<1> keeps for the steps after a rejected one, and the scalars it moves
+  double dl_diag[6], dl_grad[6], dl_gn[6], mu = s->mu, alpha = s->alpha, dogleg_step_norm = s->dogleg_step_norm;
+  if constexpr (STRAT == 0) {
 #pragma unroll
-  for (int i = 0; i < 6; ++i) diagonal[i] = fmin(fmax(As[sym6(i, i)], o->min_lm_diagonal), o->max_lm_diagonal);
-  const double inv_radius = ea_rcp(radius);
+    for (int i = 0; i < 6; ++i) diagonal[i] = fmin(fmax(As[sym6(i, i)], o->min_lm_diagonal), o->max_lm_diagonal);
+    const double inv_radius = ea_rcp(radius);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) D2[i] = diagonal[i] * inv_radius;
-  if (EA_UNLIKELY(!solve_spd6(As, D2, gs, y))) return false;
+    for (int i = 0; i < 6; ++i) D2[i] = diagonal[i] * inv_radius;
+    if (EA_UNLIKELY(!solve_spd6(As, D2, gs, y))) return false;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) step[i] = -y[i];
+    for (int i = 0; i < 6; ++i) step[i] = -y[i];
+  } else {
+    // traditional dogleg after an accepted step (dl_reuse == 0): lm_strategy_step<1>'s statements, the Gauss-Newton solve at
+    // the first mu only (a failed factorisation goes to the general form and its loop over mu)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dl_diag[i] = sqrt(fmin(fmax(As[sym6(i, i)], o->min_lm_diagonal), o->max_lm_diagonal));
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dl_grad[i] = gs[i] / dl_diag[i];
+    double v[6], qf = 0.0, g2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = dl_grad[i] / dl_diag[i];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < 6; ++b) qf += v[a] * As[sym6(a, b)] * v[b];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) g2 += dl_grad[i] * dl_grad[i];
+    alpha = g2 / qf;
+    if (EA_UNLIKELY(!(mu < 1.0))) return false;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) D2[i] = dl_diag[i] * dl_diag[i] * mu;
+    if (EA_UNLIKELY(!solve_spd6(As, D2, gs, y))) return false;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dl_gn[i] = y[i];
+    mu = fmax(1e-8, 2.0 * mu / 10.0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dl_gn[i] *= -dl_diag[i];
+    const double gn_norm = norm_n(dl_gn, 6);
+    if (gn_norm <= radius) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) step[i] = dl_gn[i] / dl_diag[i];
+      dogleg_step_norm = gn_norm;
+    } else {
+      const double gradient_norm = norm_n(dl_grad, 6);
+      if (gradient_norm * alpha >= radius) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) step[i] = -(radius / gradient_norm) * dl_grad[i] / dl_diag[i];
+        dogleg_step_norm = radius;
+      } else {
+        double b_dot_a = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) b_dot_a += -alpha * dl_grad[i] * dl_gn[i];
+        const double a_sq = (alpha * gradient_norm) * (alpha * gradient_norm);
+        const double bma_sq = a_sq - 2.0 * b_dot_a + gn_norm * gn_norm;
+        const double cc = b_dot_a - a_sq;
+        const double d = sqrt(cc * cc + bma_sq * (radius * radius - a_sq));
+        const double beta = (cc <= 0) ? (d - cc) / bma_sq : (radius * radius - a_sq) / (d + cc);
+        double dl[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dl[i] = (-alpha * (1.0 - beta)) * dl_grad[i] + beta * dl_gn[i];
+        dogleg_step_norm = norm_n(dl, 6);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) step[i] = dl[i] / dl_diag[i];
+      }
+    }
+  }
   double gts = 0.0, diag = 0.0, off = 0.0;
 #pragma unroll
   for (int a = 0; a < 6; ++a) {
@@ -642,12 +707,19 @@ EA_HD inline bool lm_advance_fast(LMState *s, const LMOptions *o, const double a
   s->num_evals += 1;
   s->num_successful += 1;
   s->radius = radius;
-  s->decrease_factor = 2.0;
+  if constexpr (STRAT == 0) s->decrease_factor = 2.0;
   lm_pend_trace(s, pend, s->iteration, cost_change, step_norm, rel, 1);
   s->iteration += 1;
+  if constexpr (STRAT == 0) {
 #pragma unroll
-  for (int i = 0; i < 6; ++i) s->diagonal[i] = diagonal[i];
-  s->reuse_diagonal = 1;
+    for (int i = 0; i < 6; ++i) s->diagonal[i] = diagonal[i];
+    s->reuse_diagonal = 1;
+  } else {
+    s->mu = mu; s->alpha = alpha; s->dogleg_step_norm = dogleg_step_norm;
+    s->dl_reuse = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { c->dl_diag[i] = dl_diag[i]; c->dl_grad[i] = dl_grad[i]; c->dl_gn[i] = dl_gn[i]; }
+  }
   s->model_cost_change = model_cost_change;
 #pragma unroll
   for (int i = 0; i < 7; ++i) s->cand[i] = cand[i];
@@ -662,8 +734,7 @@ EA_HD inline void lm_advance(LMState *s, LMCold *c, LMTrace *tr, const LMOptions
   pend->store_system = 0;
   pend->trace_it = -1;
 #ifndef EA_LM_NO_FAST_PATH  // (tests/test_lm_host_logic.py builds the host shim both ways: the two must agree bit for bit)
-  if constexpr (STRAT == 0)
-    if (EA_LIKELY(lm_advance_fast<LITE>(s, o, acc, pend))) return;
+  if (EA_LIKELY((lm_advance_fast<STRAT, LITE>(s, c, o, acc, pend)))) return;
 #endif
   s->num_evals += 1;
   const bool eval_ok = lm_eval_usable(acc);  // (false: the step is rejected like one that raised the cost)

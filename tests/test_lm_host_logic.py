@@ -84,13 +84,13 @@ def test_fast_path_and_general_form_agree_bit_for_bit(lm_host_shim, lm_host_shim
     from edge_alignment_amd import synth
     rng = np.random.default_rng(31)
     rejected = 0
-    for trial in range(12):
+    for trial in range(18):
         pr = synth.make_problem(60, 80, int(rng.integers(200, 900)), 12, 700 + trial, 65.0, 65.0, 39.5, 29.5,
                                 planted_q=synth.quat_from_axis_angle(rng.standard_normal(3), np.deg2rad(rng.uniform(0.3, 2.0))),
                                 planted_t=tuple(rng.uniform(-0.03, 0.03, 3)), normalize=bool(trial % 2))
         loss = [(0, 1.0), (1, 1.0), (1, 0.2), (2, 0.3)][trial % 4]
         P = oracle.OracleProblem(pr["grid"], *pr["K"], loss=loss[0], loss_a=loss[1])
-        kw = dict(max_num_iterations=int(rng.choice([4, 30])))
+        kw = dict(max_num_iterations=int(rng.choice([4, 30])), strategy=1 if trial % 3 == 1 else 0)   # (LM and traditional dogleg)
         if trial % 2:
             kw["min_relative_decrease"] = 0.97
         if trial % 3 == 2:
