@@ -360,7 +360,7 @@ int ea_eval_rows_device(ea_problem *p, const double q[4], const double t[3], int
 /* ---- tuning ---------------------------------------------------------------------------- */
 /* tuning knobs: key in {"lds_bytes", "points_per_thread", "use_lds", "xcd_remap", "threads", "buffer_loads",
  * "solve_streams", "rows_staged", "rows_nontemporal", "wide_accumulate", "dt_f32", "poses_per_launch", "poll_results",
- * "fused_iterations"};
+ * "fused_iterations", "zero_copy_poses"};
  * value < 0 restores the default.
  * "dt_f32" = 0: an fp64 batch reads its fp64 images even where a float32 mirror holds them exactly (default: the mirror
  * when every term has one; results are bit-identical either way).  "poses_per_launch" = g > 0 caps the poses one
@@ -368,6 +368,9 @@ int ea_eval_rows_device(ea_problem *p, const double q[4], const double t[3], int
  * ea_batch_eval / ea_batch_eval_poses wait for the stream's completion signal instead of returning on the flag their last
  * fold workgroup raises in pinned memory ~6 us earlier (default 1; a caller that synchronises the whole device right behind
  * the call is better off with 0: profiles/r03_ab_poll.txt).
+ * "zero_copy_poses" = 0: ea_batch_eval / ea_eval always upload the pose constants before the launch (default: for up to four
+ * problems the kernel reads them from the pinned host block they were written to -- one transfer less in front of a lone
+ * evaluation, 26 -> 24 us per call).
  * "fused_iterations" = 0: ea_solve / ea_batch_solve always run (evaluate, step) pairs; default: a solve of problems small
  * enough for one workgroup per CU (LM strategy, one plain residual family each) runs ONE launch per iteration, every workgroup
  * taking the LM step itself before it evaluates -- the same iterates bit for bit (ea_batch_get_info "fused_iterations"
