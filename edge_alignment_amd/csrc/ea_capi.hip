@@ -371,8 +371,11 @@ struct ea_batch {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   // device
+  // descriptors on the device: ONE block [ProblemDesc x nterms | GroupDesc x count], the layout of the staging block, so that a
+  // build is one upload (a frame pair that changes its points / image every solve pays it every solve)
+  unsigned char *d_desc_block = nullptr;
   ProblemDesc *d_probs = nullptr;       // one per term (problem + its additional terms), groups contiguous
-  GroupDesc *d_groups = nullptr;         // one per problem (= pose)
+  GroupDesc *d_groups = nullptr;         // one per problem (= pose); behind the terms of the current build
   // descriptors go up from a pinned staging block with asynchronous copies on the batch's stream (a frame pair that
   // changes its points / DT every solve would otherwise pay two blocking copies per solve)
   unsigned char *h_desc = nullptr;
@@ -905,7 +908,8 @@ static void batch_free_device(ea_batch *b) {
   if (b->bench_e0) { (void)hipEventDestroy(b->bench_e0); b->bench_e0 = nullptr; }
   if (b->bench_e1) { (void)hipEventDestroy(b->bench_e1); b->bench_e1 = nullptr; }
   (void)hipFree(b->d_one_row); b->d_one_row = nullptr;
-  cached_free(b->d_probs); cached_free(b->d_groups); cached_free(b->d_lm_block); cached_free(b->d_cold);
+  cached_free(b->d_desc_block); cached_free(b->d_lm_block); cached_free(b->d_cold);
+  b->d_desc_block = nullptr;
   cached_free(b->d_iter_alt); cached_free(b->d_partials_alt);
   b->d_iter_alt = nullptr; b->d_partials_alt = nullptr; b->iter_alt_count = 0; b->tiles_cap_alt = 0;
   cached_free(b->d_partials); cached_free(b->d_out); cached_free(b->d_done_count);
@@ -940,8 +944,7 @@ extern "C" int ea_batch_create(ea_batch **out, ea_problem *const *problems, int 
   b->own_stream = true;
   const size_t c = (size_t)count;
   const size_t lm_bytes = c * (sizeof(LMState) + sizeof(LMTrace) + sizeof(PoseState));
-  e = cached_malloc(reinterpret_cast<void **>(&b->d_groups), c * sizeof(GroupDesc), b->device);
-  if (e == hipSuccess) e = cached_malloc(reinterpret_cast<void **>(&b->d_lm_block), lm_bytes, b->device);
+  e = cached_malloc(reinterpret_cast<void **>(&b->d_lm_block), lm_bytes, b->device);
   if (e == hipSuccess) e = cached_malloc(reinterpret_cast<void **>(&b->d_out), c * sizeof(EvalOut), b->device);
   if (e == hipSuccess) e = cached_malloc(reinterpret_cast<void **>(&b->d_cold), c * sizeof(LMCold), b->device);
   if (e == hipSuccess) e = cached_host_malloc(reinterpret_cast<void **>(&b->h_lm_block), lm_bytes, hipHostMallocDefault, b->device);
@@ -1172,12 +1175,16 @@ static int batch_build(ea_batch *b) {
   b->row_offsets = row_offsets;
   b->total_rows = row_begin;
   b->max_n = max_n;
-  if (b->nterms > b->terms_cap) {
-    cached_free(b->d_probs);
-    b->d_probs = nullptr;
+  if (b->nterms > b->terms_cap || !b->d_desc_block) {
+    cached_free(b->d_desc_block);
+    b->d_desc_block = nullptr; b->d_probs = nullptr; b->d_groups = nullptr;
     b->terms_cap = b->nterms + 8;
-    HIPCHK(cached_malloc(reinterpret_cast<void **>(&b->d_probs), (size_t)b->terms_cap * sizeof(ProblemDesc), b->device));
+    HIPCHK(cached_malloc(reinterpret_cast<void **>(&b->d_desc_block),
+                         (size_t)b->terms_cap * sizeof(ProblemDesc) + b->probs.size() * sizeof(GroupDesc), b->device));
   }
+  static_assert(sizeof(ProblemDesc) % alignof(GroupDesc) == 0, "the groups sit right behind the terms");
+  b->d_probs = reinterpret_cast<ProblemDesc *>(b->d_desc_block);
+  b->d_groups = reinterpret_cast<GroupDesc *>(b->d_desc_block + (size_t)b->nterms * sizeof(ProblemDesc));
   if (b->t_test_fail_build) {  // (tests/test_gpu_robustness.py: a build that fails here must leave the batch dirty)
     b->t_test_fail_build = 0;
     return fail(EA_ERR_ALLOC, "batch build: injected allocation failure (test hook)");
@@ -1203,8 +1210,7 @@ static int batch_build(ea_batch *b) {
     }
     std::memcpy(b->h_desc, descs.data(), pb);
     std::memcpy(b->h_desc + pb, groups.data(), gb);
-    HIPCHK(hipMemcpyAsync(b->d_probs, b->h_desc, pb, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipMemcpyAsync(b->d_groups, b->h_desc + pb, gb, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->d_desc_block, b->h_desc, pb + gb, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipEventRecord(b->desc_done, b->stream));
   }
   // LDS staging of the DT footprint is available but off by default: on MI355X the unaligned 16-byte
