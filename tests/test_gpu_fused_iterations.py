@@ -113,6 +113,14 @@ def test_small_batches_and_repeated_solves(hip):
     # a cap that cuts some problems short while others have finished: states come back from the device
     f, u = _both(hip, probs, q0, t0, max_num_iterations=6)
     _same(f, u, "batch of 4, capped")
+    # a problem without a single point among them: its writer workgroup alone steps it (zero system: converged at once)
+    E = hip.Problem(*synth.make_problem(120, 160, 500, 30, 77, 130.0, 130.0, 79.5, 59.5)["K"], dtype=hip.EA_F64)
+    pr = synth.make_problem(120, 160, 500, 30, 77, 130.0, 130.0, 79.5, 59.5)
+    E.set_points(pr["xyz"][:0]); E.set_dt_grid(pr["grid"]); E.set_loss(1, 1.0)
+    f, u = _both(hip, [probs[0], E, probs[1]], q0[:3], t0[:3])
+    assert f[3] == 1 and f[2][1]["num_iterations"] == 0 and f[2][1]["termination"] == 0
+    _same(f, u, "batch with an empty problem")
+    E.close()
     # the same handles again, and again (buffers of either parity hold what the last solve left)
     B = hip.Batch(probs[:1])
     first = B.solve(q0[0], t0[0])
