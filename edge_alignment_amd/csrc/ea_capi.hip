@@ -2803,6 +2803,16 @@ extern "C" int ea_solve_pyramid(ea_problem *const *levels, int nlevels, const ea
 
 static int ref_points_from_last_now(ea_problem *p, int kind, const uint16_t *depth, int height, int width, double z_scaling,
                                     int threshold);  // (with the frame producers below)
+struct RefPointsJob;
+static int ref_points_begin(ea_problem *p, int kind, const uint16_t *depth, int height, int width, int threshold, RefPointsJob *job);
+static int ref_points_finish(ea_problem *p, const RefPointsJob &job, int height, int width, double z_scaling, int threshold);
+// what ref_points_begin left in flight on the null stream: the depth frame on its way up and the per-block edge counts
+struct RefPointsJob {
+  bool started = false;
+  uint8_t *d_edges = nullptr;
+  uint16_t *d_depth = nullptr;
+  int *d_counts = nullptr, *d_total = nullptr;
+};
 
 // ---- frame-to-frame driver (the reference aligns one stored pair, src/ea.cpp:155-200) -------------
 // Every pushed frame is aligned against the previous one: its DT image is produced, the previous frame's edge points
@@ -2850,16 +2860,23 @@ extern "C" int ea_tracker_push_frame(ea_tracker *tr, const uint8_t *bgr, const u
   double q_new[4], t_new[3];
   std::memcpy(q_new, tr->q, sizeof(q_new));
   std::memcpy(t_new, tr->t, sizeof(t_new));
+  RefPointsJob job;
   if (tr->frames > 0 && ea_problem_num_points(tr->p) > 0) {
     rc = tr->flavour == 0 ? ea_problem_set_now_frame(tr->p, bgr, height, width, 35, 1, 1)
                           : ea_problem_set_now_frame_canny(tr->p, bgr, nullptr, height, width, 30, 90, 1, 0.0, 1.0);
     if (rc != EA_OK) return rc;
+    // the new frame's depth goes up and its edge pixels are counted WHILE the previous reference is solved against the image
+    // just produced (null stream beside the solve's non-blocking stream; neither touches what the other uses)
+    (void)ref_points_begin(tr->p, tr->flavour == 0 ? 1 : 2, depth, height, width, tr->flavour == 0 ? 35 : 0, &job);
     double q[4], t[3];
     std::memcpy(q, tr->q, sizeof(q));
     std::memcpy(t, tr->t, sizeof(t));
     ea_summary s;
     rc = ea_solve(tr->p, opt, q, t, &s);
-    if (rc != EA_OK) return rc;
+    if (rc != EA_OK) {
+      if (job.started) (void)hipDeviceSynchronize();  // (nothing of this frame may stay in flight behind a failed push)
+      return rc;
+    }
     if (s.termination != EA_FAILURE) {
       std::memcpy(q_new, q, sizeof(q));
       std::memcpy(t_new, t, sizeof(t));
@@ -2868,7 +2885,8 @@ extern "C" int ea_tracker_push_frame(ea_tracker *tr, const uint8_t *bgr, const u
     if (aligned) *aligned = 1;
   }
   // the frame's edge strength / edge map is still in the workspace when it has just been the "now" frame
-  rc = ref_points_from_last_now(tr->p, tr->flavour == 0 ? 1 : 2, depth, height, width, z_scaling, tr->flavour == 0 ? 35 : 0);
+  rc = job.started ? ref_points_finish(tr->p, job, height, width, z_scaling, tr->flavour == 0 ? 35 : 0)
+                   : ref_points_from_last_now(tr->p, tr->flavour == 0 ? 1 : 2, depth, height, width, z_scaling, tr->flavour == 0 ? 35 : 0);
   if (rc == EA_ERR_STATE)
     rc = tr->flavour == 0 ? ea_problem_set_ref_frame(tr->p, bgr, depth, height, width, z_scaling, 35)
                           : ea_problem_set_ref_frame_canny(tr->p, bgr, depth, height, width, z_scaling, 30, 90);
@@ -2989,8 +3007,12 @@ static int ref_frame_impl(ea_problem *p, const uint8_t *bgr, const uint8_t *mask
 // (Laplacian strength / Canny edge map): only the depth image goes up, no second upload or filtering of the colour
 // frame.  Same thresholds, same compaction and back-projection as ea_problem_set_ref_frame[_canny] => the same points.
 // Returns EA_ERR_STATE when the workspace does not hold that frame (the caller then takes the full path).
-static int ref_points_from_last_now(ea_problem *p, int kind, const uint16_t *depth, int height, int width, double z_scaling,
-                                    int threshold) {
+// The new reference frame's edge points from what the "now" producer left in the workspace, in two halves so that the tracker
+// can put the first -- depth upload and per-block edge counts, both asynchronous on the null stream -- in front of the solve of
+// the previous reference (which runs on the batch's own non-blocking stream and touches neither the workspace nor the depth)
+// and the second -- count read-back, compaction -- behind it.
+static int ref_points_begin(ea_problem *p, int kind, const uint16_t *depth, int height, int width, int threshold, RefPointsJob *job) {
+  job->started = false;
   if (p->ws_now_kind != kind || p->ws_now_h != height || p->ws_now_w != width || (int64_t)height * width < 4096)
     return EA_ERR_STATE;
   HIPCHK(hipSetDevice(p->device));
@@ -3016,18 +3038,33 @@ static int ref_points_from_last_now(ea_problem *p, int kind, const uint16_t *dep
   p->ws_now_kind = 0;
   HIPCHK(hipMemcpyAsync(d_depth, depth, np * 2, hipMemcpyHostToDevice, nullptr));
   HIPCHK(launch_edge_count_scan(d_edges, d_depth, height, width, threshold, d_counts, d_total, nullptr));
+  job->started = true;
+  job->d_edges = d_edges; job->d_depth = d_depth; job->d_counts = d_counts; job->d_total = d_total;
+  return EA_OK;
+}
+
+static int ref_points_finish(ea_problem *p, const RefPointsJob &job, int height, int width, double z_scaling, int threshold) {
+  if (!job.started) return EA_ERR_STATE;
   int total = 0;
-  HIPCHK(hipMemcpy(&total, d_total, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&total, job.d_total, sizeof(int), hipMemcpyDeviceToHost));
   p->version++;
   int rc = reserve_points(p, total);
   if (rc != EA_OK) return rc;
   if (total > 0) {
-    HIPCHK(launch_edge_scatter(p->dtype, d_edges, d_depth, height, width, threshold, d_counts, p->cam.fx, p->cam.fy, p->cam.cx,
+    HIPCHK(launch_edge_scatter(p->dtype, job.d_edges, job.d_depth, height, width, threshold, job.d_counts, p->cam.fx, p->cam.fy, p->cam.cx,
                                p->cam.cy, z_scaling, p->d_x, p->d_y, p->d_z, total, nullptr));
     HIPCHK(hipDeviceSynchronize());
   }
   p->n = total;
   return EA_OK;
+}
+
+static int ref_points_from_last_now(ea_problem *p, int kind, const uint16_t *depth, int height, int width, double z_scaling,
+                                    int threshold) {
+  RefPointsJob job;
+  int rc = ref_points_begin(p, kind, depth, height, width, threshold, &job);
+  if (rc != EA_OK) return rc;
+  return ref_points_finish(p, job, height, width, z_scaling, threshold);
 }
 
 extern "C" int ea_problem_set_ref_frame(ea_problem *p, const uint8_t *bgr, const uint16_t *depth, int height, int width,

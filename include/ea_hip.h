@@ -125,7 +125,7 @@ const char *ea_last_error(void);
 int ea_release_cached_memory(void);
 /* Page-locked host memory for the caller's frames (the buffers handed to ea_problem_set_*_frame*, ea_tracker_push_frame,
  * ea_problem_set_points / _set_dt): the uploads of those calls then run as direct DMA instead of being staged through the
- * runtime's bounce buffers -- ea_tracker_push_frame 0.33 -> 0.30 ms per VGA frame (profiles/r03_tracker_pinned.txt).
+ * runtime's bounce buffers -- ea_tracker_push_frame 0.31 -> 0.28 ms per VGA frame (profiles/r03_tracker_pinned.txt).
  * Plain memory to the host (cv::Mat can wrap it); NULL on failure (ea_last_error).  Free with ea_host_free only. */
 void *ea_host_alloc(size_t bytes, int device);
 void ea_host_free(void *p);
