@@ -130,7 +130,23 @@ while time.time() < t_end:
             if so["termination"] != 2 and s1["termination"] != 2:
                 dr, dt = synth.rotation_angle_between(q1, qo), float(np.linalg.norm(t1 - to))
                 lim = (1e-7, 1e-7) if dtype == capi.EA_F64 else (1e-4, 1e-3)
-                if dtype == capi.EA_F64:
+                # (a perfect fit -- trivial loss, cost down at 1e-24 -- ends on whichever tolerance rounding noise trips first:
+                # seed 4242, case 49620 stops on the gradient tolerance in the oracle and one iteration later on the parameter
+                # tolerance on the device, in both forms of the loop; the iteration count is compared while the cost means something)
+                noise_floor = so["final_cost"] <= 1e-18 * max(so["initial_cost"], 1e-300)
+                if dtype == capi.EA_F64 and not noise_floor and s1["num_iterations"] != so["num_iterations"]:
+                    # keep what is needed to look at the case off-line (tests/ and scripts/ only: the oracle is the checker)
+                    os.makedirs("gpurun_out", exist_ok=True)
+                    np.savez("gpurun_out/soak_solve_mismatch_%d_%d.npz" % (seed, cases), xyz=Xs[i], grid=prs[i]["grid"], K=np.array(prs[i]["K"]),
+                             loss=np.array(loss), it_gpu=s1["it_cost"], it_oracle=so["it_cost"], ok_gpu=s1["it_successful"], ok_oracle=so["it_successful"])
+                    Bs = capi.Batch([Ps[i]]); Bs.set_tuning("fused_iterations", 0)
+                    qp, tp, sp = Bs.solve([1, 0, 0, 0], [0, 0, 0]); Bs.close()
+                    print("solve mismatch, case %d problem %d (%d points, loss %s): gpu %d iterations (%s), pairs form %d (%s), oracle %d (%s)"
+                          % (cases, i, Xs[i].shape[0], loss, s1["num_iterations"], s1["why"], sp[0]["num_iterations"], sp[0]["why"], so["num_iterations"], so["why"]))
+                    print("  gpu    costs", ["%.12g" % c for c in s1["it_cost"]], list(s1["it_successful"]))
+                    print("  oracle costs", ["%.12g" % c for c in so["it_cost"]], list(so["it_successful"]))
+                    print("  gpu rel", ["%.6g" % c for c in s1["it_relative_decrease"]], "step", ["%.3g" % c for c in s1["it_step_norm"]])
+                if dtype == capi.EA_F64 and not noise_floor:
                     assert s1["num_iterations"] == so["num_iterations"], (cases, i)
                 # (fp32 on a few hundred points: the function-tolerance stop leaves more slack than the bar; report, assert
                 # the bar from 5000 points up, where the bundled frames and every BASELINE config live)
