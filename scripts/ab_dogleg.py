@@ -1,3 +1,5 @@
+"""LM and traditional dogleg at C2 (25 iterations allowed), one launch per iteration and as pairs: it/s through ctypes.
+usage: python scripts/ab_dogleg.py   (to compare two builds: set capi.LIB_PATH before running the body, as gpu A/Bs do)"""
 import sys, time, numpy as np
 sys.path.insert(0, '.')
 import torch; torch.cuda.init()
