@@ -1,5 +1,6 @@
 #!/bin/bash
-# PMC passes (counters only, SQ block) for the LM-step kernel on the 1e5-point solve; summary under gpurun_out/pmc_lm
+# PMC passes (counters only, SQ block) for the kernels of the 1e5-point solve -- ea_lm_iter_kernel (one launch per iteration) and,
+# for problems that do not qualify, ea_lm_step_kernel + the evaluation; summary under gpurun_out/pmc_lm
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -18,7 +19,7 @@ agg = collections.OrderedDict()
 for f in sorted(glob.glob(out + '/p*/**/*counter_collection.csv', recursive=True)):
     for r in csv.DictReader(open(f)):
         kn = r.get('Kernel_Name', '')
-        tag = 'lm_step' if 'ea_lm_step' in kn else ('reduce' if 'ea_reduce' in kn else ('eval' if 'ea_eval_fused' in kn else None))
+        tag = 'lm_iter' if 'ea_lm_iter' in kn else 'lm_step' if 'ea_lm_step' in kn else ('reduce' if 'ea_reduce' in kn else ('eval' if 'ea_eval_fused' in kn else None))
         if tag is None: continue
         agg.setdefault((tag, r['Counter_Name']), []).append(float(r['Counter_Value']))
 with open(out + '/summary.txt', 'w') as fh:
