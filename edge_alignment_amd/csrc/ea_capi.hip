@@ -2772,7 +2772,11 @@ extern "C" int ea_internal_solve_sharded_rows(ea_problem *p, const ea_options *o
     if (__atomic_load_n(&b->h_progress[0], __ATOMIC_ACQUIRE) == 0 && b->hd_states[0].num_evals <= i + 1) { finished = true; break; }
     if (r.enq < r.budget && (rc = enqueue_iteration()) != EA_OK) return rc;
   }
-  HIPCHK(hipStreamSynchronize(b->stream));
+  // A finished solve has delivered its result into pinned host memory in front of the flag seen above: return on it.  The
+  // launches and collectives queued past the end (every rank alike) drain behind our back -- they touch only buffers the
+  // library owns, and whatever uses this stream or the communicator next is ordered behind them (ea_comm_destroy waits for
+  // the stream of its last solve).  Only a solve cut short by the launch budget has to wait and fetch.
+  if (!finished) HIPCHK(hipStreamSynchronize(b->stream));
   r.fetch = !finished;
   r.done = true;
   rc = solve_collect(r, o, summary != nullptr);

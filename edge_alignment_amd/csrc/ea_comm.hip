@@ -138,6 +138,7 @@ struct ea_comm {
   double *d_send = nullptr, *d_recv = nullptr, *h_send = nullptr, *h_recv = nullptr;
   double *d_sums = nullptr;            // the 32 accumulator slots of ea_solve_sharded_comm
   int *d_agree = nullptr;              // two ints the ranks take to their maximum before a sharded solve
+  hipStream_t last_solve_stream = nullptr;  // collectives of the last sharded solve may still be draining on it (waited for in destroy)
   int64_t allreduces = 0, allgathers = 0, row_solves = 0;
   bool spoke = false;                  // the first collective has run (some RCCL builds announce themselves there, not at init)
 };
@@ -171,6 +172,7 @@ extern "C" void ea_comm_destroy(ea_comm *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->last_solve_stream) (void)hipStreamSynchronize(c->last_solve_stream);
   if (c->comm && rccl().CommDestroy) (void)rccl().CommDestroy(c->comm);
   (void)hipFree(c->d_send); (void)hipFree(c->d_recv); (void)hipFree(c->d_sums); (void)hipFree(c->d_agree);
   (void)hipHostFree(c->h_send); (void)hipHostFree(c->h_recv);
@@ -314,6 +316,7 @@ extern "C" int ea_solve_sharded_comm(ea_problem *p, const ea_options *opt, ea_co
   HIPCHK(hipSetDevice(c->device));
   auto enqueue = [](void *buf, int count, void *stream, void *user) -> int {
     ea_comm *cc = static_cast<ea_comm *>(user);
+    cc->last_solve_stream = static_cast<hipStream_t>(stream);
     ncclResult_t r;
     if (!cc->spoke) {
       StdoutToStderr quiet;
